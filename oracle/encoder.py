@@ -1,0 +1,117 @@
+"""Oracle: HF-free fp32 restatement of the dual-encoder forward (CPU, torch).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Follows, line by line:
+  * /root/reference/model/models.py:129-148  RobertaDot_NLL_LN.query_emb/body_emb
+      roberta(ids, mask) -> CLS (models.py:43, use_mean=False for every registered
+      config: models.py:295,300,307) -> embeddingHead Linear(H,768) -> LayerNorm(768)
+  * /root/reference/model/models.py:191-262  HFBertEncoder / BiEncoder
+      two BERT towers, embedding = raw last-layer CLS (models.py:210), no head
+  * /root/reference/model/models.py:32-35    masked_mean (use_mean=True branch)
+  * /root/reference/model/models.py:66-75    NLL.forward triple branch
+The encoder arithmetic itself is third-party (transformers==2.3.0,
+requirements.txt:1, not vendored).  Restated from its published architecture
+(modeling_bert.py / modeling_roberta.py of that release):
+  embeddings   = LayerNorm(word[ids] + pos[position_ids] + type[0])
+  RoBERTa pos  = cumsum(ids != pad_idx) * (ids != pad_idx) + pad_idx   (pad_idx = 1)
+  BERT pos     = 0..L-1
+  self-attn    = softmax(Q K^T / sqrt(d) + (1 - mask) * -10000) V
+  attn output  = LayerNorm(dense(ctx) + x)
+  ffn          = LayerNorm(dense2(gelu_erf(dense1(x))) + x)
+Dropout is identity here (eval mode / p = 0); train-mode dropout RNG cannot be
+matched (SURVEY.md §7 hard part 4).
+
+Weights are addressed by the reference's state_dict names so the same dict
+feeds the reference module, this oracle and ``convdr_amd.model.models``.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def roberta_position_ids(input_ids, padding_idx=1):
+    """HF create_position_ids_from_input_ids: pads (id == padding_idx) get
+    padding_idx, every other token counts up from padding_idx + 1.  Note the
+    reference pads with id 0 (utils/util.py:146-185), which is NOT the RoBERTa
+    pad id, so right-pad positions keep counting (SURVEY.md §7 hard part 7)."""
+    m = input_ids.ne(padding_idx).to(torch.int64)
+    return torch.cumsum(m, dim=1) * m + padding_idx
+
+
+def _ln(x, w, b, eps):
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def gelu_erf(x):
+    return x * 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def encoder_hidden(sd, prefix, input_ids, attention_mask, *, kind, num_layers,
+                   num_heads, eps, return_all=False):
+    """Last-layer hidden states [B, L, H] of the BERT/RoBERTa tower stored under
+    ``prefix`` (e.g. 'roberta.' or 'question_model.') in state dict ``sd``."""
+    ids = input_ids.long()
+    B, L = ids.shape
+    g = lambda n: sd[prefix + n].float()
+    if kind == "roberta":
+        pos = roberta_position_ids(ids, 1)
+    elif kind == "bert":
+        pos = torch.arange(L).unsqueeze(0).expand(B, L)
+    else:
+        raise KeyError(kind)
+    x = (g("embeddings.word_embeddings.weight")[ids]
+         + g("embeddings.position_embeddings.weight")[pos]
+         + g("embeddings.token_type_embeddings.weight")[0])
+    x = _ln(x, g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"), eps)
+    H = x.shape[-1]
+    d = H // num_heads
+    add_mask = (1.0 - attention_mask.float())[:, None, None, :] * -10000.0
+    hs = [x]
+    for i in range(num_layers):
+        p = "encoder.layer.%d." % i
+        lin = lambda t, n: F.linear(t, g(p + n + ".weight"), g(p + n + ".bias"))
+        q = lin(x, "attention.self.query").view(B, L, num_heads, d).transpose(1, 2)
+        k = lin(x, "attention.self.key").view(B, L, num_heads, d).transpose(1, 2)
+        v = lin(x, "attention.self.value").view(B, L, num_heads, d).transpose(1, 2)
+        s = q @ k.transpose(-1, -2) / math.sqrt(d) + add_mask
+        ctx = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, L, H)
+        x = _ln(lin(ctx, "attention.output.dense") + x,
+                g(p + "attention.output.LayerNorm.weight"),
+                g(p + "attention.output.LayerNorm.bias"), eps)
+        h = gelu_erf(lin(x, "intermediate.dense"))
+        x = _ln(lin(h, "output.dense") + x, g(p + "output.LayerNorm.weight"),
+                g(p + "output.LayerNorm.bias"), eps)
+        hs.append(x)
+    return hs if return_all else x
+
+
+def masked_mean(t, mask):
+    """models.py:32-35."""
+    s = torch.sum(t * mask.unsqueeze(-1).float(), dim=1)
+    return s / mask.sum(dim=1, keepdim=True).float()
+
+
+def rdot_nll_emb(sd, input_ids, attention_mask, *, num_layers, num_heads,
+                 eps=1e-5, use_mean=False):
+    """RobertaDot_NLL_LN.query_emb == body_emb (models.py:140-148)."""
+    h = encoder_hidden(sd, "roberta.", input_ids, attention_mask, kind="roberta",
+                       num_layers=num_layers, num_heads=num_heads, eps=eps)
+    full = masked_mean(h, attention_mask) if use_mean else h[:, 0]
+    y = F.linear(full, sd["embeddingHead.weight"].float(), sd["embeddingHead.bias"].float())
+    return _ln(y, sd["norm.weight"].float(), sd["norm.bias"].float(), 1e-5)  # nn.LayerNorm(768) default eps
+
+
+def dpr_emb(sd, input_ids, attention_mask, *, tower, num_layers, num_heads, eps=1e-12):
+    """BiEncoder.query_emb (tower='question_model') / body_emb ('ctx_model'),
+    models.py:227-235: raw CLS of the last layer (models.py:210)."""
+    h = encoder_hidden(sd, tower + ".", input_ids, attention_mask, kind="bert",
+                       num_layers=num_layers, num_heads=num_heads, eps=eps)
+    return h[:, 0]
+
+
+def pairwise_nll(q, a, b):
+    """NLL.forward triple branch models.py:66-75 == BiEncoder.forward :254-262."""
+    logits = torch.stack([(q * a).sum(-1), (q * b).sum(-1)], dim=1)
+    return (-F.log_softmax(logits, dim=1)[:, 0]).mean()

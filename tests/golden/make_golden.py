@@ -1,0 +1,367 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by IMPORTING AND RUNNING the
+reference (thunlp/ConvDR at /root/reference) in the build container.
+
+Run here only (the reference never travels to the GPU box):
+
+    python tests/golden/make_golden.py            # all groups
+    python tests/golden/make_golden.py encoder    # one group
+
+Nothing of the reference's source is stored: fixtures are inputs + outputs
+(.npz) and, for text outputs, the produced lines.  The shims below are the ones
+listed in SURVEY.md §8(c); they replace *absent third-party packages*, never
+reference code:
+  faiss / pytrec_eval / tensorboardX  -> empty module stubs
+  transformers.AdamW (removed from HF) -> ``HFAdamW230`` below: a restatement of
+      the pinned transformers==2.3.0 optimizer from its published algorithm
+      (the arithmetic itself is therefore "parity unpinned"; what the fixture
+      pins is the reference's *use* of it: param groups, lr, eps, clip, schedule)
+  RobertaConfig.pretrained_config_archive_map -> {}
+  configs built with return_dict=False (models.py:39 asserts a tuple)
+  HFBertEncoder.init_encoder -> random-init tiny BERT (no network)
+  FlatIP stand-in for faiss.IndexFlatIP: exact fp32 ``q @ x.T`` + stable
+      descending argsort
+"""
+import importlib.machinery
+import json
+import os
+import pickle
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def _stub(name):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    for n in ("faiss", "pytrec_eval", "tensorboardX"):
+        _stub(n)
+    sys.modules["tensorboardX"].SummaryWriter = object
+    import torch
+    from transformers import (RobertaConfig, RobertaModel, BertModel, BertConfig,  # noqa: F401
+                              RobertaForSequenceClassification)
+    sys.modules["transformers"].AdamW = HFAdamW230()
+    RobertaConfig.pretrained_config_archive_map = {}
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import model.models as M
+    import utils.util as U
+    import utils.dpr_utils as DU
+    import data.tokenizing as T
+    return M, U, DU, T
+
+
+def HFAdamW230():
+    import math
+    import torch
+
+    class AdamW(torch.optim.Optimizer):
+        """transformers==2.3.0 optimization.AdamW, restated."""
+
+        def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+            super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                          correct_bias=correct_bias))
+
+        def step(self, closure=None):
+            for group in self.param_groups:
+                for p in group["params"]:
+                    if p.grad is None:
+                        continue
+                    grad = p.grad.data
+                    state = self.state[p]
+                    if len(state) == 0:
+                        state["step"] = 0
+                        state["exp_avg"] = torch.zeros_like(p.data)
+                        state["exp_avg_sq"] = torch.zeros_like(p.data)
+                    m, v = state["exp_avg"], state["exp_avg_sq"]
+                    b1, b2 = group["betas"]
+                    state["step"] += 1
+                    m.mul_(b1).add_(grad, alpha=1.0 - b1)
+                    v.mul_(b2).addcmul_(grad, grad, value=1.0 - b2)
+                    denom = v.sqrt().add_(group["eps"])
+                    step_size = group["lr"]
+                    if group["correct_bias"]:
+                        step_size = step_size * math.sqrt(1.0 - b2 ** state["step"]) / (1.0 - b1 ** state["step"])
+                    p.data.addcdiv_(m, denom, value=-step_size)
+                    if group["weight_decay"] > 0.0:
+                        p.data.add_(p.data, alpha=-group["lr"] * group["weight_decay"])
+    return AdamW
+
+
+# ----------------------------------------------------------------------------
+TINY = dict(vocab_size=200, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+            intermediate_size=128, max_position_embeddings=514)
+
+
+def tiny_roberta_config(dropout=0.0):
+    from transformers import RobertaConfig
+    return RobertaConfig(type_vocab_size=1, pad_token_id=1, layer_norm_eps=1e-5, return_dict=False,
+                         hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout,
+                         num_labels=2, **TINY)
+
+
+def tiny_bert_config():
+    from transformers import BertConfig
+    return BertConfig(type_vocab_size=2, pad_token_id=0, layer_norm_eps=1e-12, return_dict=False,
+                      hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **TINY)
+
+
+def synth_ids(rng, B, L, lens, bos=0, vocab=200, pad1_at=None):
+    """right-padded with id 0 / mask 0 like utils/util.py:163-185."""
+    ids = rng.randint(3, vocab, size=(B, L)).astype(np.int64)
+    ids[:, 0] = bos
+    mask = np.zeros((B, L), np.int64)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+        ids[b, n:] = 0
+    if pad1_at is not None:          # a real token equal to RoBERTa's pad id 1
+        ids[pad1_at[0], pad1_at[1]] = 1
+    return ids, mask
+
+
+def sd_to_np(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def gen_encoder():
+    import torch
+    M, U, DU, T = import_reference()
+    torch.manual_seed(0)
+    rng = np.random.RandomState(0)
+    # ---- rdot_nll -----------------------------------------------------------
+    cfg = tiny_roberta_config()
+    model = M.MSMarcoConfigDict["rdot_nll"].model_class(cfg)
+    # non-trivial LayerNorm/bias values so the fixture exercises them
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.05)
+            elif "LayerNorm.weight" in n or n == "norm.weight":
+                p.add_(torch.randn_like(p) * 0.1)
+    model.eval()
+    out = {"config": json.dumps({**TINY, "layer_norm_eps": 1e-5, "type_vocab_size": 1, "pad_token_id": 1})}
+    for k, v in sd_to_np(model.state_dict()).items():
+        out["w/" + k] = v
+    cases = {
+        "L16": (4, 16, [16, 9, 1, 12], (3, 5)),
+        "L64": (3, 64, [64, 33, 50], None),
+        "L510": (2, 510, [510, 77], None),
+    }
+    for name, (B, L, lens, pad1) in cases.items():
+        ids, mask = synth_ids(rng, B, L, lens, pad1_at=pad1)
+        with torch.no_grad():
+            tid, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+            q = model(tid, tm)                              # NLL.forward -> query_emb
+            b = model(tid, tm, is_query=False)              # -> body_emb
+            hs = model.roberta(input_ids=tid, attention_mask=tm, output_hidden_states=True)
+        assert torch.equal(q, b)
+        out[name + "/ids"], out[name + "/mask"] = ids, mask
+        out[name + "/emb"] = q.numpy()
+        out[name + "/cls_last"] = hs[0][:, 0].numpy()
+        if name == "L16":
+            hidden = hs[-1] if isinstance(hs[-1], (tuple, list)) else hs[2]
+            out[name + "/hidden_states"] = np.stack([h.numpy() for h in hidden])
+    # triple-loss entry (models.py:66-75)
+    ids_q, m_q = synth_ids(rng, 4, 12, [12, 7, 9, 12])
+    ids_a, m_a = synth_ids(rng, 4, 20, [20, 15, 20, 3])
+    ids_b, m_b = synth_ids(rng, 4, 20, [11, 20, 18, 20])
+    with torch.no_grad():
+        loss = model(*(torch.from_numpy(x) for x in (ids_q, m_q, ids_a, m_a, ids_b, m_b)))[0]
+    for n, v in dict(ids_q=ids_q, m_q=m_q, ids_a=ids_a, m_a=m_a, ids_b=ids_b, m_b=m_b).items():
+        out["triple/" + n] = v
+    out["triple/loss"] = np.array(loss.item(), np.float64)
+    np.savez_compressed(os.path.join(HERE, "encoder_rdot_nll.npz"), **out)
+
+    # ---- dpr ----------------------------------------------------------------
+    bcfg = tiny_bert_config()
+    M.HFBertEncoder.init_encoder = classmethod(lambda cls, args, dropout=0.1: cls(bcfg))
+    torch.manual_seed(1)
+    bi = M.MSMarcoConfigDict["dpr"].model_class(None)
+    with torch.no_grad():
+        for n, p in bi.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.05)
+            elif "LayerNorm.weight" in n:
+                p.add_(torch.randn_like(p) * 0.1)
+    bi.eval()
+    out = {"config": json.dumps({**TINY, "layer_norm_eps": 1e-12, "type_vocab_size": 2, "pad_token_id": 0})}
+    for k, v in sd_to_np(bi.state_dict()).items():
+        out["w/" + k] = v
+    ids, mask = synth_ids(rng, 4, 24, [24, 10, 17, 2], bos=101)
+    with torch.no_grad():
+        tid, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+        out["q_emb"] = bi(tid, tm).numpy()
+        out["b_emb"] = bi(tid, tm, is_query=False).numpy()
+        qa = bi(tid, tm, tid, tm)
+        assert isinstance(qa, tuple) and len(qa) == 2
+        out["pair_loss"] = np.array(bi(tid, tm, tid, tm, torch.flip(tid, [0]), torch.flip(tm, [0]))[0].item())
+    out["ids"], out["mask"] = ids, mask
+    np.savez_compressed(os.path.join(HERE, "encoder_dpr.npz"), **out)
+    print("encoder fixtures written")
+
+
+# ----------------------------------------------------------------------------
+class FlatIPStandIn:
+    """SURVEY.md §8(c) shim 6."""
+
+    def __init__(self, d):
+        self.x = None
+
+    def add(self, x):
+        self.x = np.asarray(x, np.float32)
+
+    def search(self, q, k):
+        s = np.asarray(q, np.float32) @ self.x.T
+        I = np.argsort(-s, axis=1, kind="stable")[:, :k]
+        return np.take_along_axis(s, I, 1), I.astype(np.int64)
+
+    def reset(self):
+        self.x = None
+
+
+def synth_corpus(seed, n, d):
+    return np.random.RandomState(seed).randn(n, d).astype(np.float32)
+
+
+def gen_search():
+    import contextlib
+    import io
+    sys.argv = sys.argv[:1]
+    M, U, DU, T = import_reference()
+    # the driver module imports fine once faiss is stubbed
+    sys.path.insert(0, os.path.join(REF, "drivers"))
+    import run_convdr_inference as R
+
+    def run(case, blocks, Q, topN):
+        with tempfile.TemporaryDirectory() as td:
+            for b, (emb, embid) in enumerate(blocks):
+                for pre, arr in (("passage__emb_p_", emb), ("passage__embid_p_", embid)):
+                    with open(os.path.join(td, "%s_data_obj_%d.pb" % (pre, b)), "wb") as h:
+                        pickle.dump(arr, h, protocol=4)      # == utils/util.py:108-111
+            with contextlib.redirect_stdout(io.StringIO()):
+                mD, mI = R.search_one_by_one(td, FlatIPStandIn(768), Q, topN)
+        # record the smallest adjacent score gap: the parity tests treat ranks whose
+        # reference scores differ by < 1e-3 as exchangeable (SURVEY.md §7 hard part 1)
+        gaps = []
+        for emb, _ in blocks:
+            s = np.sort((Q.astype(np.float64) @ emb.astype(np.float64).T), axis=1)[:, ::-1][:, :topN + 1]
+            gaps.append(np.min(s[:, :-1] - s[:, 1:]))
+        print("case", case, "min adjacent gap", min(gaps))
+        return mD, mI
+
+    out = {}
+    # (a) three ragged blocks, round-robin ids like a 3-rank encode run (util.py:422-424)
+    d, topN, nq = 768, 100, 16
+    sizes, seeds = [1500, 1000, 700], [11, 12, 13]
+    total = sum(sizes)
+    blocks = []
+    for r, (n, s) in enumerate(zip(sizes, seeds)):
+        blocks.append((synth_corpus(s, n, d), (np.arange(n, dtype=np.int64) * 3 + r)))
+    Q = synth_corpus(1234, nq, d)
+    mD, mI = run("a", blocks, Q, topN)
+    out["a/sizes"], out["a/seeds"], out["a/qseed"] = np.array(sizes), np.array(seeds), np.array(1234)
+    out["a/topN"], out["a/merged_D"], out["a/merged_I"] = np.array(topN), mD, mI
+    # (b) one block -> [nq, topN]
+    mD, mI = run("b", blocks[:1], Q, topN)
+    out["b/merged_D"], out["b/merged_I"] = mD, mI
+    # (c) exact ties: duplicated vectors inside a block and across blocks, small k
+    base = synth_corpus(21, 300, d)
+    b0 = np.concatenate([base[:200], base[50:60]])            # dup rows 50..59 at 200..209
+    b1 = np.concatenate([base[40:70], base[200:300]])         # rows 40..69 again in the next block
+    blocks_c = [(b0, np.arange(len(b0), dtype=np.int64)), (b1, 1000 + np.arange(len(b1), dtype=np.int64))]
+    Qc = base[45:53] + 0.0                                     # queries = corpus rows -> top hits are the dups
+    mD, mI = run("ties", blocks_c, Qc, 10)
+    out["c/merged_D"], out["c/merged_I"], out["c/topN"] = mD, mI, np.array(10)
+    # (d) EvalDevQuery text outputs for case (a) with duplicate pids
+    with tempfile.TemporaryDirectory() as td:
+        rs = np.random.RandomState(5)
+        offset2pid = (rs.permutation(3 * max(sizes)) // 2 * 2 + 7).tolist()       # every pid appears twice
+        qids = ["%d_%d" % (31 + i // 4, 1 + i % 4) for i in range(nq)]
+        with open(os.path.join(td, "queries.raw.tsv"), "w") as f:
+            for q in qids:
+                f.write("%s\tquery text %s\n" % (q, q))
+        with open(os.path.join(td, "collection.tsv"), "w") as f:
+            for pid in sorted(set(offset2pid)):
+                f.write("%d\tpassage %d body\n" % (pid, pid))
+        raw = [["hist %s" % q, "cur %s" % q] for q in qids]
+        pos = {qids[0]: {offset2pid[int(out["a/merged_I"][0, 0])]: 2}}
+        R.EvalDevQuery(qids, out["a/merged_D"], pos, out["a/merged_I"], topN,
+                       os.path.join(td, "o.jsonl"), os.path.join(td, "o.trec"), offset2pid, td, "raw",
+                       raw_sequences=raw)
+        out["d/offset2pid"] = np.array(offset2pid, np.int64)
+        out["d/qids"] = np.array(qids)
+        out["d/pos_qid"], out["d/pos_pid"], out["d/pos_label"] = np.array(qids[0]), np.array(list(pos[qids[0]])[0]), np.array(2)
+        out["d/trec"] = np.array(open(os.path.join(td, "o.trec")).read())
+        out["d/jsonl"] = np.array(open(os.path.join(td, "o.jsonl")).read())
+    np.savez_compressed(os.path.join(HERE, "search.npz"), **out)
+    print("search fixtures written")
+
+
+# ----------------------------------------------------------------------------
+def gen_encode_loop():
+    """Drive gen_passage_embeddings.StreamInferenceDoc under a 1-rank gloo group
+    (SURVEY.md §8(c) shim 7) -> real block files; keep their bytes' content."""
+    import torch
+    import torch.distributed as dist
+    sys.argv = sys.argv[:1]
+    M, U, DU, T = import_reference()
+    sys.path.insert(0, os.path.join(REF, "drivers"))
+    import gen_passage_embeddings as G
+    torch.manual_seed(3)
+    model = M.MSMarcoConfigDict["rdot_nll"].model_class(tiny_roberta_config())
+    model.eval()
+    rng = np.random.RandomState(3)
+    N, L = 37, 16
+    lens = rng.randint(1, L + 1, size=N)
+    lens[0] = L
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "passages")
+        rows = []
+        with open(path, "wb") as f:           # byte layout of tokenizing.py:116 minus the 8-byte pid prefix (:44)
+            for n in lens:
+                ids = [0] + rng.randint(3, 200, size=n - 1).tolist()
+                rows.append(ids)
+                f.write(int(n).to_bytes(4, "big") + np.array((ids + [0] * L)[:L], np.int32).tobytes())
+        with open(path + "_meta", "w") as f:
+            json.dump({"type": "int32", "total_number": N, "embedding_size": L}, f)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        args = types.SimpleNamespace(per_gpu_eval_batch_size=8, local_rank=0, rank=0, world_size=1,
+                                     device=torch.device("cpu"), output_dir=os.path.join(td, "out"),
+                                     max_seq_length=L, max_query_length=L)
+        wrapped = types.SimpleNamespace(module=model, eval=model.eval)
+        cache = U.EmbeddingCache(path)
+        with cache as emb:
+            G.StreamInferenceDoc(args, wrapped, T.GetProcessingFn(args, query=False), "passage_", emb,
+                                 is_query_inference=False, merge=False)
+        dist.destroy_process_group()
+        e = pickle.load(open(os.path.join(td, "out", "passage__emb_p__data_obj_0.pb"), "rb"))
+        i = pickle.load(open(os.path.join(td, "out", "passage__embid_p__data_obj_0.pb"), "rb"))
+        token_bytes = open(path, "rb").read()
+    out = {"token_cache": np.frombuffer(token_bytes, np.uint8), "N": np.array(N), "L": np.array(L),
+           "lens": lens.astype(np.int64), "emb": e, "embid": i,
+           "emb_dtype": np.array(str(e.dtype)), "embid_dtype": np.array(str(i.dtype))}
+    for k, v in sd_to_np(model.state_dict()).items():
+        out["w/" + k] = v
+    np.savez_compressed(os.path.join(HERE, "encode_loop.npz"), **out)
+    print("encode-loop fixture written", e.shape, i[:5])
+
+
+GROUPS = {"encoder": gen_encoder, "search": gen_search, "encode_loop": gen_encode_loop}
+
+if __name__ == "__main__":
+    want = sys.argv[1:] or list(GROUPS)
+    sys.argv = sys.argv[:1]
+    for g in want:
+        GROUPS[g]()

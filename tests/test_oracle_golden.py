@@ -1,0 +1,111 @@
+"""Pin the CPU oracle against fixtures produced by running the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import encoder as OE
+from oracle import search as OS
+from tests.helpers import assert_topk_equivalent, cosine
+from tests.golden.make_golden import synth_corpus
+
+
+def _sd(z):
+    return {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}
+
+
+def test_rdot_nll_embeddings_match_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "encoder_rdot_nll.npz"))
+    cfg = json.loads(str(z["config"]))
+    sd = _sd(z)
+    for case in ("L16", "L64", "L510"):
+        ids, mask = torch.from_numpy(z[case + "/ids"]), torch.from_numpy(z[case + "/mask"])
+        emb = OE.rdot_nll_emb(sd, ids, mask, num_layers=cfg["num_hidden_layers"],
+                              num_heads=cfg["num_attention_heads"], eps=cfg["layer_norm_eps"]).numpy()
+        np.testing.assert_allclose(emb, z[case + "/emb"], atol=2e-5, rtol=0)
+        assert cosine(emb, z[case + "/emb"]).min() > 1 - 1e-6
+    hs = OE.encoder_hidden(sd, "roberta.", torch.from_numpy(z["L16/ids"]), torch.from_numpy(z["L16/mask"]),
+                           kind="roberta", num_layers=2, num_heads=4, eps=1e-5, return_all=True)
+    ref = z["L16/hidden_states"]
+    m = z["L16/mask"].astype(bool)
+    for l in range(3):  # padded query rows are don't-care (mask constant differs: -1e4 vs dtype-min)
+        np.testing.assert_allclose(hs[l].numpy()[m], ref[l][m], atol=2e-5, rtol=0)
+
+
+def test_rdot_nll_triple_loss_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "encoder_rdot_nll.npz"))
+    sd = _sd(z)
+    e = lambda i, m: OE.rdot_nll_emb(sd, torch.from_numpy(z["triple/" + i]), torch.from_numpy(z["triple/" + m]),
+                                     num_layers=2, num_heads=4)
+    loss = OE.pairwise_nll(e("ids_q", "m_q"), e("ids_a", "m_a"), e("ids_b", "m_b"))
+    assert abs(loss.item() - float(z["triple/loss"])) < 1e-4 * max(1, abs(float(z["triple/loss"])))
+
+
+def test_dpr_embeddings_match_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "encoder_dpr.npz"))
+    sd = _sd(z)
+    ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    q = OE.dpr_emb(sd, ids, mask, tower="question_model", num_layers=2, num_heads=4)
+    b = OE.dpr_emb(sd, ids, mask, tower="ctx_model", num_layers=2, num_heads=4)
+    np.testing.assert_allclose(q.numpy(), z["q_emb"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(b.numpy(), z["b_emb"], atol=2e-5, rtol=0)
+    loss = OE.pairwise_nll(q, b, torch.flip(b, [0]))
+    assert abs(loss.item() - float(z["pair_loss"])) < 1e-4
+
+
+def _blocks_a(z):
+    return [(synth_corpus(int(s), int(n), 768), np.arange(int(n), dtype=np.int64) * 3 + r)
+            for r, (n, s) in enumerate(zip(z["a/sizes"], z["a/seeds"]))]
+
+
+def test_search_one_by_one_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "search.npz"))
+    blocks = _blocks_a(z)
+    Q = synth_corpus(int(z["a/qseed"]), 16, 768)
+    topN = int(z["a/topN"])
+    mD, mI = OS.search_one_by_one(blocks, Q, topN)
+    assert mD.shape == z["a/merged_D"].shape == (16, 2 * topN) and mD.dtype == np.float64 and mI.dtype == np.int64
+    assert_topk_equivalent(z["a/merged_D"], z["a/merged_I"], mD, mI, k=topN)
+    mD, mI = OS.search_one_by_one(blocks[:1], Q, topN)
+    assert mD.shape == z["b/merged_D"].shape == (16, topN)
+    assert_topk_equivalent(z["b/merged_D"], z["b/merged_I"], mD, mI, k=topN)
+
+
+def test_search_ties_match_reference(golden_dir):
+    """Exact duplicates: lower index first inside a block, earlier block first across blocks."""
+    z = np.load(os.path.join(golden_dir, "search.npz"))
+    base = synth_corpus(21, 300, 768)
+    b0 = np.concatenate([base[:200], base[50:60]])
+    b1 = np.concatenate([base[40:70], base[200:300]])
+    blocks = [(b0, np.arange(len(b0), dtype=np.int64)), (b1, 1000 + np.arange(len(b1), dtype=np.int64))]
+    mD, mI = OS.search_one_by_one(blocks, base[45:53] + 0.0, 10)
+    k = 10
+    # canonical scores of identical vectors tie exactly -> documented rule decides:
+    # lower index first inside a block, earlier block first across blocks (:218 `>=`).
+    # (The fp32-BLAS stand-in behind the fixture does NOT tie exactly: its scores for
+    # identical rows differ in the 7th digit, so vs the fixture they are exchangeable.)
+    for j, r in enumerate(range(45, 53)):
+        want = [r] + ([200 + r - 50] if r >= 50 else []) + [1000 + r - 40]
+        assert mI[j, :len(want)].tolist() == want
+        assert len(set(mD[j, :len(want)].tolist())) == 1
+    assert_topk_equivalent(z["c/merged_D"], z["c/merged_I"], mD, mI, k=k)
+
+
+def test_eval_dev_query_text_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "search.npz"))
+    topN = int(z["a/topN"])
+    rows = OS.eval_dev_query_rows([str(q) for q in z["d/qids"]], z["a/merged_D"], z["a/merged_I"], topN,
+                                  z["d/offset2pid"].tolist())
+    assert "".join(OS.trec_lines(rows, topN)) == str(z["d/trec"])
+    first = json.loads(str(z["d/jsonl"]).splitlines()[0])
+    assert first["doc_id"] == str(rows[str(z["d/qids"][0])][0][0]) and first["label"] == 2
+
+
+def test_canonical_score_is_fp64_accurate():
+    rs = np.random.RandomState(0)
+    Q, P = rs.randn(3, 768).astype(np.float32), rs.randn(50, 768).astype(np.float32)
+    S = OS.canonical_scores(Q, P)
+    ref = Q.astype(np.float64) @ P.astype(np.float64).T
+    np.testing.assert_allclose(S, ref, rtol=1e-13, atol=1e-11)
