@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""bench.py -- ConvDR hot path on MI355X.  One JSON line on rank 0 (see the driver contract).
+
+Workload (BASELINE.json configs[1]): 1M synthetic passages x 768-d, 1k queries, brute-force
+inner-product top-100; per step the engine (i) encodes a batch of synthetic 128-token passages
+into embeddings (when the encoder kernels are built) and (ii) runs the full 1k x 1M exact top-100
+search over the resident block.  With N > 1 every rank owns its own 1M-passage shard (weak scaling;
+the corpus partitions by block = rank) and the query set is replicated, so there is
+no data-path collective inside the timed region except the barrier.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
+
+
+def cpu_baseline_ip(nq, d, k, seconds_budget=20.0):
+    """FAISS-CPU IndexFlatIP restated (SGEMM + per-query partial sort), timed on the host cores on a
+    bounded sample of the same workload: all nq queries against as many passages as fit the budget."""
+    import numpy as np
+    import torch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = 50_000
+    g = torch.Generator().manual_seed(0)
+    P = torch.randn(n, d, generator=g)
+    Q = torch.randn(nq, d, generator=g)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        S = Q @ P.T
+        torch.topk(S, k, dim=1)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or reps >= 40:
+            break
+    return {"value": nq * n * reps / el, "unit": "query x passage pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d queries x %d passages x %d reps, torch fp32 SGEMM + topk(%d) (FAISS-CPU IndexFlatIP restated; "
+                      "FAISS itself is not installed)" % (nq, n, reps, k)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--passages", type=int, default=1_000_000)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--topk", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from convdr_amd import _lib
+    from convdr_amd.search import FlatIPIndex
+    L = _lib.lib()
+
+    n, nq, k, d = args.passages, args.queries, args.topk, 768
+    g = torch.Generator(device="cuda").manual_seed(rank)
+    P = torch.randn(n, d, device="cuda", generator=g)
+    Q = torch.randn(nq, d, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1234))
+    index = FlatIPIndex(d)
+    index.add(P)
+    del P
+
+    def step():
+        return index.search_device(Q, k)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    sync_all()
+    assert int(out[2].abs().sum().item()) == 0, "uncertified queries in warmup"
+    L.convdr_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync_all()
+    el = time.perf_counter() - t0
+    status_bad = int((out[2] != 0).sum().item())
+    scan_ms, scan_n = _lib.prof_collect("ip_scan_emit")
+    samp_ms, _ = _lib.prof_collect("ip_scan_sample")
+    resc_ms, _ = _lib.prof_collect("ip_rescore")
+    L.convdr_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    pairs_per_s = world * nq * n * args.steps / el
+    scan_s = scan_ms / 1e3 / max(1, scan_n)
+    flops = 2.0 * nq * n * d
+    line = {
+        "metric": "passages encoded/sec + query x passage IP-scored/sec, 768-d",
+        "value": pairs_per_s, "unit": "query x passage pairs/s (exact top-%d, whole job)" % k,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 scan + f64 rescore",
+        "data": "synthetic N(0,1) embeddings, seed=rank; queries seed 1234",
+        "config": {"workload": "configs[1]: %d passages x 768-d per GPU, %d-query brute-force IP top-%d "
+                               "(encode leg not built yet)" % (n, nq, k),
+                   "passages_per_gpu": n, "queries": nq, "topk": k, "parallelism": "corpus-sharded x%d" % world},
+        "uncertified_queries": status_bad,
+        "kernel_ms": {"ip_scan_emit": scan_s * 1e3, "ip_scan_sample": samp_ms / max(1, scan_n),
+                      "ip_rescore": resc_ms / max(1, scan_n)},
+        "roofline": {"kernel": "k_ip_scan<EMIT>", "bound": "mfma", "achieved": flops / scan_s / 1e12,
+                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flops / scan_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                     "hbm_GBps_algorithmic": n * d * 2 / scan_s / 1e9},
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_ip(nq, d, k)
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,74 @@
+"""ctypes binding of libconvdr_hip.so (the C ABI declared in include/convdr_hip.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libconvdr_hip.so")
+
+_lib = None
+
+_p = C.c_void_p
+_SIGNATURES = {
+    "convdr_version": (C.c_int, []),
+    "convdr_last_error": (C.c_char_p, []),
+    "convdr_prof_enable": (C.c_int, [C.c_int]),
+    "convdr_prof_collect": (C.c_int, [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "convdr_ip_prepare_block": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p, _p]),
+    "convdr_ip_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "convdr_ip_search": (C.c_int, [_p, C.c_int, _p, _p, C.c_int64, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int,
+                                   _p, C.c_size_t, _p, _p, _p, _p, _p]),
+    "convdr_ip_debug_counts": (_p, [_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
+}
+
+
+class ConvdrError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Names declared in include/convdr_hip.h that the library must export."""
+    return sorted(_SIGNATURES)
+
+
+def register(name, restype, argtypes):
+    _SIGNATURES[name] = (restype, argtypes)
+    if _lib is not None:
+        f = getattr(_lib, name)
+        f.restype, f.argtypes = restype, argtypes
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built: the product
+    path never falls back to a CPU implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ConvdrError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C convdr_amd/csrc`" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            f = getattr(_lib, name)
+            f.restype, f.argtypes = restype, argtypes
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise ConvdrError("%s failed (%d): %s" % (what, rc, lib().convdr_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def prof_collect(name):
+    """(total_ms, launches) of the spans recorded under `name` since convdr_prof_enable(1)."""
+    ms, cnt = C.c_float(0), C.c_int(0)
+    check(lib().convdr_prof_collect(name.encode(), C.byref(ms), C.byref(cnt)), "convdr_prof_collect")
+    return ms.value, cnt.value

@@ -1,0 +1,474 @@
+// Exact brute-force inner-product top-k over a resident passage-embedding block (gfx950).
+//
+// Replaces faiss.IndexFlatIP.add/.search as driven by the reference at
+//   /root/reference/drivers/run_convdr_inference.py:180-182  (gpu_index.add(block); D, I = gpu_index.search(Q, topN))
+//
+// Design (see DESIGN.md §"IP scan"): never materialise [nq, n].
+//   prepare   fp32 block -> bf16 scan copy + max row norm                      (HBM-bound, once per .add)
+//   sample    bf16 MFMA GEMM over ~1/32 of the block, epilogue keeps per-(query, 32 passages) top-2,
+//             per-query LDS bitonic sort -> tau[q] ~ score of rank `rank_target` in the whole block
+//   scan      bf16 MFMA GEMM  P_bf16[n,d] * Q_bf16[nq,d]^T  (gemm_nt.hpp), epilogue compares each fp32
+//             accumulator with tau[q] and appends (index, score) of the rare hits to a per-query list
+//   rescore   one wave per candidate: fp64 dot of the fp32 originals, canonical order (oracle/search.py)
+//   select    per query LDS bitonic sort by (exact score desc, index asc), top-k out, certificate:
+//             OK iff  kth_exact >= tau + eps,  eps = 0.0079 * |q| * max|p|   (bf16 rounding bound)
+#include "gemm_nt.hpp"
+
+#include <float.h>
+#include <math.h>
+
+#include "../../include/convdr_hip.h"
+
+namespace convdr {
+
+constexpr int IP_MODE_FULL = 0, IP_MODE_TOP2 = 1, IP_MODE_EMIT = 2;
+constexpr int IP_FULL_MAX_N = 32768;      // <= this many passages: "sample" = all scores, exact rank select
+constexpr int IP_SAMPLE_MIN = 32768;      // sampled passages (>= 1/32 of the block)
+constexpr int IP_SAMPLE_MAX = 262144;
+constexpr float IP_EPS_COEF = 0.0079f;    // 2u + u^2 + K*2^-24 with u = 2^-8, rounded up (K <= 4096)
+
+// ------------------------------------------------------------------------------------------
+// rows fp32 -> bf16 (+ per-row L2 norm, + global max norm).  One wave per row, float4 loads.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rows_to_bf16(const float* __restrict__ X, int64_t n, int d,
+                                                      bf16_t* __restrict__ Y, float* __restrict__ row_norm,
+                                                      float* __restrict__ max_norm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float wmax = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n; row += (int64_t)gridDim.x * 4) {
+    const float* x = X + row * d;
+    bf16_t* y = Y + row * d;
+    float ss = 0.f;
+    for (int e = lane * 4; e < d; e += 256) {
+      const float4 v = *(const float4*)(x + e);
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      uint2 o;
+      o.x = pack_bf16x2(v.x, v.y);
+      o.y = pack_bf16x2(v.z, v.w);
+      *(uint2*)(y + e) = o;
+    }
+    ss = wave_sum(ss);
+    const float nm = sqrtf(ss);
+    if (row_norm && lane == 0) row_norm[row] = nm;
+    wmax = fmaxf(wmax, nm);
+  }
+  if (max_norm) {
+    __shared__ float sm[4];
+    if (lane == 0) sm[wave] = wmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+      atomicMax((int*)max_norm, __float_as_int(m));  // non-negative floats order like ints
+    }
+  }
+}
+
+__global__ void k_fill_f32(float* p, int n, float v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// The scan GEMM.  A = passages (rows -> accumulator rows), B = queries (-> accumulator columns,
+// one query per lane), so the per-query threshold lives in one VGPR per 32-column MFMA tile.
+// Grid: 1-D, nPt * nQt blocks, XCD-remapped so the nQt query tiles of one passage tile run
+// back-to-back on one XCD (the passage tile is fetched from HBM once, then hits that XCD's L2).
+// ------------------------------------------------------------------------------------------
+struct ScanArgs {
+  const bf16_t* P;   // [n, d]
+  const bf16_t* Qb;  // [nq_pad, d] (rows >= nq are zero)
+  int64_t n;
+  int nq, nq_pad, d;
+  int nPt, nQt;      // tiles actually visited / query tiles
+  int pt_stride;     // visited passage tile t -> tile t * pt_stride
+  const float* tau;  // EMIT: [nq_pad]
+  uint32_t* counts;  // EMIT: [nq]
+  uint32_t* cand_id; // EMIT: [nq, cap]
+  float* cand_s;     // EMIT: [nq, cap]
+  int cap;
+  float* T;          // FULL: [nPt*128, nq_pad]; TOP2: [nPt*8, nq_pad]
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(GEMM_THREADS, 2) k_ip_scan(const ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int ts = logical / a.nQt, qt = logical - ts * a.nQt;
+  const int64_t m0 = (int64_t)ts * a.pt_stride * GEMM_BM;
+  const int64_t n0 = (int64_t)qt * GEMM_BN;
+
+  GemmAcc acc;
+  gemm_acc_zero(acc);
+  gemm_nt_mainloop(a.P, a.d, a.n, a.Qb, a.d, a.nq_pad, a.d, m0, n0, smem, acc);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1, hi = lane >> 5;
+
+  if constexpr (MODE == IP_MODE_EMIT) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int q = (int)n0 + gemm_acc_col(wn, nt, lane);
+      const float tau = q < a.nq ? a.tau[q] : INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const f32x16 v = acc.c[mt][nt];
+        float mx = v[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, v[r]);
+        if (mx >= tau) {  // rare: ~rank_target hits per query in the whole block
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = m0 + gemm_acc_row(wm, mt, r, lane);
+            if (v[r] >= tau && row < a.n) {
+              const uint32_t slot = atomicAdd(&a.counts[q], 1u);
+              if (slot < (uint32_t)a.cap) {
+                a.cand_id[(int64_t)q * a.cap + slot] = (uint32_t)row;
+                a.cand_s[(int64_t)q * a.cap + slot] = v[r];
+              }
+            }
+          }
+        }
+      }
+    }
+  } else if constexpr (MODE == IP_MODE_FULL) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int q = (int)n0 + gemm_acc_col(wn, nt, lane);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + gemm_acc_row(wm, mt, r, lane);
+          a.T[row * a.nq_pad + q] = row < a.n ? acc.c[mt][nt][r] : -INFINITY;
+        }
+    }
+  } else {  // TOP2: best two of this lane's 32 scores (one query, 32 of the tile's passages)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int q = (int)n0 + gemm_acc_col(wn, nt, lane);
+      float b0 = -INFINITY, b1 = -INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + gemm_acc_row(wm, mt, r, lane);
+          const float s = row < a.n ? acc.c[mt][nt][r] : -INFINITY;
+          const float lo = fminf(b0, s);
+          b0 = fmaxf(b0, s);
+          b1 = fmaxf(b1, lo);
+        }
+      const int64_t slot = (((int64_t)ts * 2 + wm) * 2 + hi) * 2;
+      a.T[slot * a.nq_pad + q] = b0;
+      a.T[(slot + 1) * a.nq_pad + q] = b1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS bitonic sorts (block-wide)
+// ------------------------------------------------------------------------------------------
+__device__ void bitonic_desc_f32(float* s, int n) {
+  for (int k2 = 2; k2 <= n; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int p = i ^ j;
+        if (p > i) {
+          const float x = s[i], y = s[p];
+          const bool desc = (i & k2) == 0;
+          if (desc ? (x < y) : (x > y)) { s[i] = y; s[p] = x; }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+__device__ __forceinline__ bool cand_before(double sa, uint32_t ia, double sb, uint32_t ib) {
+  return sa > sb || (sa == sb && ia < ib);
+}
+
+__device__ void bitonic_cand(double* s, uint32_t* id, int n) {
+  for (int k2 = 2; k2 <= n; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int p = i ^ j;
+        if (p > i) {
+          const double x = s[i], y = s[p];
+          const uint32_t ix = id[i], iy = id[p];
+          const bool fwd = (i & k2) == 0;
+          const bool sw = fwd ? cand_before(y, iy, x, ix) : cand_before(x, ix, y, iy);
+          if (sw) { s[i] = y; s[p] = x; id[i] = iy; id[p] = ix; }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+// tau[q] = r-th largest of T[0..nvals) for query q (column q of T, leading dim nq_pad)
+__global__ void __launch_bounds__(1024) k_tau_select(const float* __restrict__ T, int64_t nvals, int nq_pad,
+                                                     int npow2, int r, float* __restrict__ tau) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s = (float*)smem;
+  const int q = blockIdx.x;
+  for (int i = threadIdx.x; i < npow2; i += blockDim.x) s[i] = i < nvals ? T[(int64_t)i * nq_pad + q] : -INFINITY;
+  __syncthreads();
+  bitonic_desc_f32(s, npow2);
+  if (threadIdx.x == 0) tau[q] = (r >= 1 && r <= nvals) ? s[r - 1] : -INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------
+// exact rescoring: canonical fp64 inner product (see oracle/search.py: lane l owns elements
+// 256 j + 4 l + c, accumulated in (j, c) order; then butterfly 32,16,8,4,2,1)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ip_rescore(const float* __restrict__ Q, const float* __restrict__ P, int d,
+                                                    int cap, const uint32_t* __restrict__ counts,
+                                                    const uint32_t* __restrict__ cand_id,
+                                                    double* __restrict__ cand_x) {
+  const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t cnt = counts[q];
+  const uint32_t c = cnt < (uint32_t)cap ? cnt : (uint32_t)cap;
+  const float* qv = Q + (int64_t)q * d;
+  for (uint32_t slot = blockIdx.y * 4 + wave; slot < c; slot += gridDim.y * 4) {
+    const uint32_t id = cand_id[(int64_t)q * cap + slot];
+    const float* pv = P + (int64_t)id * d;
+    double acc = 0.0;
+    for (int e = lane * 4; e < d; e += 256) {
+      const float4 x = *(const float4*)(qv + e);
+      const float4 y = *(const float4*)(pv + e);
+      acc = fma((double)x.x, (double)y.x, acc);
+      acc = fma((double)x.y, (double)y.y, acc);
+      acc = fma((double)x.z, (double)y.z, acc);
+      acc = fma((double)x.w, (double)y.w, acc);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) cand_x[(int64_t)q * cap + slot] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-query final sort + certificate
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ip_select(int64_t n, int k, int cap, const uint32_t* __restrict__ counts,
+                                                   const uint32_t* __restrict__ cand_id,
+                                                   const double* __restrict__ cand_x, const float* __restrict__ tau,
+                                                   const float* __restrict__ qnorm,
+                                                   const float* __restrict__ p_max_norm, float* __restrict__ D,
+                                                   int64_t* __restrict__ I, int32_t* __restrict__ status,
+                                                   float* __restrict__ tau_retry) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int q = blockIdx.x;
+  const uint32_t cnt = counts[q];
+  const int c = cnt < (uint32_t)cap ? (int)cnt : cap;
+  int np2 = 2;
+  while (np2 < c) np2 <<= 1;
+  double* s = (double*)smem;
+  uint32_t* id = (uint32_t*)(smem + (size_t)np2 * 8);
+  for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+    s[i] = i < c ? cand_x[(int64_t)q * cap + i] : -INFINITY;
+    id[i] = i < c ? cand_id[(int64_t)q * cap + i] : 0xffffffffu;
+  }
+  __syncthreads();
+  bitonic_cand(s, id, np2);
+  for (int j = threadIdx.x; j < k; j += blockDim.x) {
+    D[(int64_t)q * k + j] = j < c ? (float)s[j] : -FLT_MAX;
+    I[(int64_t)q * k + j] = j < c ? (int64_t)id[j] : -1;
+  }
+  if (threadIdx.x == 0) {
+    const int need = (int64_t)k < n ? k : (int)n;
+    const float t = tau[q];
+    const float eps = IP_EPS_COEF * qnorm[q] * p_max_norm[0] * 1.001f + 1e-30f;
+    int st = CONVDR_IP_OK;
+    float retry = -INFINITY;
+    const double kth = (need > 0 && c >= need) ? s[need - 1] : -INFINITY;
+    if (cnt > (uint32_t)cap) {
+      // The stored candidates are a subset of {S~ >= tau}; their k-th exact score bounds the true one from
+      // below, so every true top-k member has S~ >= kth - eps.  If that does not tighten tau the caller
+      // must raise cap.
+      st = CONVDR_IP_OVERFLOW;
+      const float cand = nextafterf((float)kth - eps, -INFINITY);
+      retry = cand > t ? cand : t;
+    } else if (c < need) {
+      st = CONVDR_IP_TOO_FEW;
+    } else if (need > 0 && t > -INFINITY && !(kth >= (double)t + (double)eps)) {
+      st = CONVDR_IP_UNCERTAIN;
+      retry = nextafterf((float)kth - eps, -INFINITY);
+    }
+    status[q] = st;
+    tau_retry[q] = retry;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side plan shared by workspace sizing and the search call
+// ------------------------------------------------------------------------------------------
+struct IpPlan {
+  int nq_pad, nQt, nPt;
+  int mode;          // -1: no threshold pass (n <= cap), else IP_MODE_FULL / IP_MODE_TOP2
+  int nSt, stride;   // sampled passage tiles / tile stride
+  int64_t nvals;     // values per query handed to k_tau_select
+  int npow2;
+  size_t o_qb, o_qnorm, o_tau, o_counts, o_T, o_id, o_s, o_x, total;
+};
+
+static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
+  IpPlan p;
+  p.nq_pad = (nq + GEMM_BN - 1) / GEMM_BN * GEMM_BN;
+  p.nQt = p.nq_pad / GEMM_BN;
+  p.nPt = (int)ceil_div64(n, GEMM_BM);
+  p.nSt = 0; p.stride = 1; p.nvals = 0; p.npow2 = 2;
+  if (n <= cap) {
+    p.mode = -1;
+  } else if (n <= IP_FULL_MAX_N) {
+    p.mode = IP_MODE_FULL; p.nSt = p.nPt; p.nvals = n;
+  } else {
+    p.mode = IP_MODE_TOP2;
+    int64_t S = n / 32;
+    if (S < IP_SAMPLE_MIN) S = IP_SAMPLE_MIN;
+    if (S > IP_SAMPLE_MAX) S = IP_SAMPLE_MAX;
+    p.nSt = (int)(S / GEMM_BM);
+    if (p.nSt > p.nPt) p.nSt = p.nPt;
+    p.stride = p.nPt / p.nSt;
+    p.nvals = (int64_t)p.nSt * 8;
+  }
+  while (p.npow2 < p.nvals) p.npow2 <<= 1;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+  p.o_qb = take((size_t)p.nq_pad * d * 2);
+  p.o_qnorm = take((size_t)p.nq_pad * 4);
+  p.o_tau = take((size_t)p.nq_pad * 4);
+  p.o_counts = take((size_t)p.nq_pad * 4);
+  const size_t t_rows = p.mode == IP_MODE_FULL ? (size_t)p.nPt * GEMM_BM : (size_t)p.nvals;
+  p.o_T = take(t_rows * p.nq_pad * 4);
+  p.o_id = take((size_t)nq * cap * 4);
+  p.o_s = take((size_t)nq * cap * 4);
+  p.o_x = take((size_t)nq * cap * 8);
+  p.total = o;
+  (void)k;
+  return p;
+}
+
+template <int MODE>
+static int launch_scan(const ScanArgs& a, hipStream_t st) {
+  static bool attr_done = false;  // 64 KB dynamic LDS needs the opt-in once per kernel
+  if (!attr_done) {
+    CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_scan<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         GEMM_SMEM_BYTES));
+    attr_done = true;
+  }
+  const unsigned grid = (unsigned)a.nPt * (unsigned)a.nQt;
+  ProfScope prof(MODE == IP_MODE_EMIT ? "ip_scan_emit" : "ip_scan_sample", st);
+  hipLaunchKernelGGL(k_ip_scan<MODE>, dim3(grid), dim3(GEMM_THREADS), GEMM_SMEM_BYTES, st, a);
+  CONVDR_CHECK_LAUNCH("k_ip_scan");
+  return 0;
+}
+
+}  // namespace convdr
+
+using namespace convdr;
+
+extern "C" int convdr_ip_prepare_block(const float* p_f32, int64_t n, int d, void* p_bf16, float* max_norm,
+                                       convdr_stream_t stream) {
+  CONVDR_REQUIRE(n >= 0 && d > 0 && d % 64 == 0, "convdr_ip_prepare_block: need d %% 64 == 0 (got n=%lld d=%d)",
+                 (long long)n, d);
+  if (n == 0) return 0;
+  const int64_t blocks = ceil_div64(n, 4);
+  const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+  hipLaunchKernelGGL(k_rows_to_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, p_f32, n, d, (bf16_t*)p_bf16,
+                     (float*)nullptr, max_norm);
+  CONVDR_CHECK_LAUNCH("k_rows_to_bf16");
+  return 0;
+}
+
+extern "C" size_t convdr_ip_workspace_bytes(int nq, int64_t n, int d, int k, int cap) {
+  if (nq <= 0 || n < 0 || d <= 0) return 0;
+  return ip_plan(nq, n, d, k, cap).total;
+}
+
+extern "C" const uint32_t* convdr_ip_debug_counts(const void* workspace, int nq, int64_t n, int d, int k, int cap) {
+  return (const uint32_t*)((const char*)workspace + ip_plan(nq, n, d, k, cap).o_counts);
+}
+
+extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, const void* p_bf16, int64_t n, int d,
+                                int k, const float* p_max_norm, const float* tau_in, int cap, int rank_target,
+                                void* workspace, size_t workspace_bytes, float* D, int64_t* I, int32_t* status,
+                                float* tau_retry, convdr_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  CONVDR_REQUIRE(nq > 0 && k > 0 && n >= 0, "convdr_ip_search: bad sizes nq=%d k=%d n=%lld", nq, k, (long long)n);
+  CONVDR_REQUIRE(d > 0 && d % 64 == 0 && d <= 4096, "convdr_ip_search: need d %% 64 == 0 and d <= 4096 (got %d)", d);
+  CONVDR_REQUIRE(n < ((int64_t)1 << 31), "convdr_ip_search: block too large (n=%lld >= 2^31)", (long long)n);
+  CONVDR_REQUIRE(cap >= 1024 && cap <= 8192 && (cap & (cap - 1)) == 0,
+                 "convdr_ip_search: cap must be a power of two in [1024, 8192] (got %d)", cap);
+  CONVDR_REQUIRE(k <= cap / 2, "convdr_ip_search: k=%d too large for cap=%d", k, cap);
+  const IpPlan p = ip_plan(nq, n, d, k, cap);
+  CONVDR_REQUIRE(workspace_bytes >= p.total, "convdr_ip_search: workspace too small (%zu < %zu)", workspace_bytes,
+                 p.total);
+  char* ws = (char*)workspace;
+  bf16_t* qb = (bf16_t*)(ws + p.o_qb);
+  float* qnorm = (float*)(ws + p.o_qnorm);
+  float* tau = (float*)(ws + p.o_tau);
+  uint32_t* counts = (uint32_t*)(ws + p.o_counts);
+  float* T = (float*)(ws + p.o_T);
+  uint32_t* cand_id = (uint32_t*)(ws + p.o_id);
+  float* cand_s = (float*)(ws + p.o_s);
+  double* cand_x = (double*)(ws + p.o_x);
+
+  // queries -> bf16 (+ norms); padded rows stay zero
+  CONVDR_CHECK_HIP(hipMemsetAsync(qb, 0, (size_t)p.nq_pad * d * 2, st));
+  CONVDR_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)p.nq_pad * 4, st));
+  hipLaunchKernelGGL(k_rows_to_bf16, dim3((nq + 3) / 4), dim3(256), 0, st, q_f32, (int64_t)nq, d, qb, qnorm,
+                     (float*)nullptr);
+  CONVDR_CHECK_LAUNCH("k_rows_to_bf16(Q)");
+
+  if (n == 0) {
+    hipLaunchKernelGGL(k_fill_f32, dim3((p.nq_pad + 255) / 256), dim3(256), 0, st, tau, p.nq_pad, -INFINITY);
+  } else {
+    ScanArgs a;
+    a.P = (const bf16_t*)p_bf16; a.Qb = qb; a.n = n; a.nq = nq; a.nq_pad = p.nq_pad; a.d = d;
+    a.nQt = p.nQt; a.tau = tau; a.counts = counts; a.cand_id = cand_id; a.cand_s = cand_s; a.cap = cap; a.T = T;
+    if (tau_in) {
+      CONVDR_CHECK_HIP(hipMemcpyAsync(tau, tau_in, (size_t)nq * 4, hipMemcpyDeviceToDevice, st));
+    } else if (p.mode < 0) {
+      hipLaunchKernelGGL(k_fill_f32, dim3((p.nq_pad + 255) / 256), dim3(256), 0, st, tau, p.nq_pad, -INFINITY);
+      CONVDR_CHECK_LAUNCH("k_fill_f32");
+    } else {
+      int R = rank_target > 0 ? rank_target : 6 * k;
+      if (R > cap / 2) R = cap / 2;
+      if (R < k) R = k;
+      int r;
+      a.nPt = p.nSt; a.pt_stride = p.stride;
+      if (p.mode == IP_MODE_FULL) {
+        r = (int64_t)R < n ? R : (int)n;
+        if (int e = launch_scan<IP_MODE_FULL>(a, st)) return e;
+      } else {
+        const double frac = (double)p.nSt * GEMM_BM / (double)n;
+        r = (int)lrint(R * frac);
+        if (r < 8) r = 8;
+        if (int e = launch_scan<IP_MODE_TOP2>(a, st)) return e;
+      }
+      static bool attr_done = false;
+      if (!attr_done) {
+        CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_tau_select, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             IP_FULL_MAX_N * 4));
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(k_tau_select, dim3(nq), dim3(1024), (size_t)p.npow2 * 4, st, T, p.nvals, p.nq_pad, p.npow2,
+                         r, tau);
+      CONVDR_CHECK_LAUNCH("k_tau_select");
+    }
+    a.nPt = p.nPt; a.pt_stride = 1;
+    if (int e = launch_scan<IP_MODE_EMIT>(a, st)) return e;
+    ProfScope prof("ip_rescore", st);
+    hipLaunchKernelGGL(k_ip_rescore, dim3(nq, 16), dim3(256), 0, st, q_f32, p_f32, d, cap, counts, cand_id, cand_x);
+    CONVDR_CHECK_LAUNCH("k_ip_rescore");
+  }
+  static bool sel_attr = false;
+  if (!sel_attr) {
+    CONVDR_CHECK_HIP(
+        hipFuncSetAttribute((const void*)k_ip_select, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12));
+    sel_attr = true;
+  }
+  hipLaunchKernelGGL(k_ip_select, dim3(nq), dim3(256), (size_t)cap * 12, st, n, k, cap, counts, cand_id, cand_x, tau,
+                     qnorm, p_max_norm, D, I, status, tau_retry);
+  CONVDR_CHECK_LAUNCH("k_ip_select");
+  return 0;
+}

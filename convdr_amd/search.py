@@ -1,0 +1,236 @@
+"""Brute-force inner-product search over passage-embedding blocks on MI355X.
+
+Mirrors, name for name, what the reference does with FAISS:
+  * ``FlatIPIndex``         <-> ``faiss.IndexFlatIP(768)`` (+ ``index_cpu_to_gpu_multiple``)
+                               /root/reference/drivers/run_convdr_inference.py:353-368,
+                               ``.add`` :180, ``.search`` :182, ``.reset`` :202
+  * ``search_one_by_one``   <-> run_convdr_inference.py:157-242 (same merge rule, same output shapes)
+  * ``EvalDevQuery``        <-> run_convdr_inference.py:21-113  (same .trec / .jsonl text)
+All scoring / selection runs in libconvdr_hip.so (csrc/ip_topk.hip).
+"""
+import json
+import os
+import pickle
+
+import numpy as np
+
+from . import _lib
+
+STATUS_OK, STATUS_OVERFLOW, STATUS_TOO_FEW, STATUS_UNCERTAIN = 0, 1, 2, 3
+
+
+class FlatIPIndex:
+    """Exact inner-product index resident in HBM.  ``add`` keeps the fp32 block and
+    builds its bf16 scan copy; ``search`` returns FAISS-shaped ``(D float32 [nq,k],
+    I int64 [nq,k])`` and is certified exact (see include/convdr_hip.h)."""
+
+    def __init__(self, d, device=None, cap=4096, rank_target=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.ConvdrError("FlatIPIndex needs a GPU (no CPU fallback)")
+        _lib.lib()
+        self.d = int(d)
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.cap, self.rank_target = int(cap), int(rank_target)
+        self.stats = {}
+        self.reset()
+
+    # -- faiss-like surface ---------------------------------------------------
+    @property
+    def ntotal(self):
+        return 0 if self._p32 is None else int(self._p32.shape[0])
+
+    def reset(self):
+        import torch
+        self._p32 = None
+        self._pbf = None
+        self._max_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._ws = None
+
+    def add(self, x):
+        """x: numpy / torch [n, d] float32 (host or device).  Appends to the index."""
+        import torch
+        t = torch.as_tensor(x)
+        if t.dtype != torch.float32:
+            t = t.float()
+        t = t.to(self.device, non_blocking=True).contiguous()
+        assert t.dim() == 2 and t.shape[1] == self.d, "expected [n, %d], got %s" % (self.d, tuple(t.shape))
+        with torch.cuda.device(self.device):
+            pbf = torch.empty(t.shape, dtype=torch.bfloat16, device=self.device)
+            _lib.check(_lib.lib().convdr_ip_prepare_block(_lib.ptr(t), t.shape[0], self.d, _lib.ptr(pbf),
+                                                         _lib.ptr(self._max_norm), _lib.stream_ptr()),
+                       "convdr_ip_prepare_block")
+        if self._p32 is None:
+            self._p32, self._pbf = t, pbf
+        else:  # FAISS semantics: add() appends
+            self._p32 = torch.cat([self._p32, t], 0)
+            self._pbf = torch.cat([self._pbf, pbf], 0)
+
+    def _workspace(self, nbytes):
+        import torch
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def search_device(self, q, k, tau_in=None, cap=None):
+        """One enqueue of the kernel pipeline; q is a device fp32 [nq, d] tensor.
+        Returns device tensors (D, I, status, tau_retry); no sync."""
+        import torch
+        L = _lib.lib()
+        cap = cap or self.cap
+        nq, n = int(q.shape[0]), self.ntotal
+        D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        status = torch.empty(nq, dtype=torch.int32, device=self.device)
+        tau_retry = torch.empty(nq, dtype=torch.float32, device=self.device)
+        need = L.convdr_ip_workspace_bytes(nq, n, self.d, k, cap)
+        ws = self._workspace(need)
+        p32 = self._p32 if n else q  # never dereferenced when n == 0
+        pbf = self._pbf if n else q
+        with torch.cuda.device(self.device):
+            _lib.check(L.convdr_ip_search(_lib.ptr(q), nq, _lib.ptr(p32), _lib.ptr(pbf), n, self.d, k,
+                                          _lib.ptr(self._max_norm), _lib.ptr(tau_in), cap, self.rank_target,
+                                          _lib.ptr(ws), ws.numel(), _lib.ptr(D), _lib.ptr(I), _lib.ptr(status),
+                                          _lib.ptr(tau_retry), _lib.stream_ptr()), "convdr_ip_search")
+        return D, I, status, tau_retry
+
+    def search(self, q, k):
+        """FAISS ``index.search``: numpy in, numpy (D, I) out.  Queries whose first pass
+        is not certified are re-run with the threshold the kernel proposes (and a larger
+        candidate capacity when needed) until they are."""
+        import torch
+        qt = torch.as_tensor(q)
+        if qt.dtype != torch.float32:
+            qt = qt.float()
+        qt = qt.to(self.device).contiguous()
+        assert qt.dim() == 2 and qt.shape[1] == self.d
+        k = int(k)
+        D, I, status, tau_retry = self.search_device(qt, k)
+        st = status.cpu().numpy()
+        self.stats = {"retried": int((st != 0).sum()), "rounds": 1}
+        cap = self.cap
+        bad = np.nonzero(st != 0)[0]
+        while len(bad):
+            self.stats["rounds"] += 1
+            if self.stats["rounds"] > 8:
+                raise _lib.ConvdrError("convdr_ip_search: could not certify %d queries" % len(bad))
+            idx = torch.as_tensor(bad, device=self.device)
+            tau = tau_retry[idx].contiguous()
+            if (st[bad] == STATUS_OVERFLOW).any():
+                if cap >= 8192:
+                    raise _lib.ConvdrError("convdr_ip_search: candidate overflow at cap=8192 "
+                                           "(more than 8192 passages within the bf16 error band of the k-th score)")
+                cap *= 2
+            Db, Ib, sb, tb = self.search_device(qt[idx].contiguous(), k, tau_in=tau, cap=cap)
+            D[idx], I[idx], tau_retry[idx] = Db, Ib, tb
+            sb = sb.cpu().numpy()
+            st[bad] = sb
+            bad = bad[sb != 0]
+        return D.cpu().numpy(), I.cpu().numpy()
+
+
+def load_block(path):
+    """pickle.load, as run_convdr_inference.py:164-175 does."""
+    with open(path, "rb") as h:
+        return pickle.load(h)
+
+
+def merge_topk(merged, cand, topN):
+    """The reference's two-way list merge (run_convdr_inference.py:213-229) for all queries at
+    once.  merged/cand: (D float64 [nq, >=topN], I int64 [nq, >=topN]), rows sorted descending.
+    The reference walks two pointers until one list is exhausted and then appends the other
+    list's remainder -- i.e. a complete merge of the two sorted topN-lists in which ties keep the
+    earlier block first (`>=`, :218) -- and returns all 2*topN entries.  A stable sort of the
+    concatenation on descending score is that same permutation."""
+    aD = np.concatenate([merged[0][:, :topN], cand[0][:, :topN]], axis=1)
+    aI = np.concatenate([merged[1][:, :topN], cand[1][:, :topN]], axis=1)
+    order = np.argsort(-aD, axis=1, kind="stable")
+    return np.take_along_axis(aD, order, 1), np.take_along_axis(aI, order, 1)
+
+
+def search_one_by_one(ann_data_dir, gpu_index, query_embedding, topN, max_blocks=8):
+    """Block-by-block search + merge; same contract as the reference function."""
+    merged = None
+    for block_id in range(max_blocks):
+        try:
+            passage_embedding = load_block(os.path.join(ann_data_dir, "passage__emb_p__data_obj_%d.pb" % block_id))
+            passage_embedding2id = load_block(os.path.join(ann_data_dir, "passage__embid_p__data_obj_%d.pb" % block_id))
+        except Exception:
+            break
+        gpu_index.add(passage_embedding)
+        D, I = gpu_index.search(query_embedding, topN)
+        gpu_index.reset()
+        cand = (D.astype(np.float64), np.asarray(passage_embedding2id)[I])
+        merged = cand if merged is None else merge_topk(merged, cand, topN)
+    if merged is None:
+        raise FileNotFoundError("no passage blocks under %s" % ann_data_dir)
+    return merged
+
+
+def EvalDevQuery(query_embedding2id, merged_D, dev_query_positive_id, I_nearest_neighbor, topN, output_file,
+                 output_trec_file, offset2pid, raw_data_dir, output_query_type, raw_sequences=None,
+                 load_collection=None):
+    """Result writer with the reference's exact text output (run_convdr_inference.py:21-113)."""
+    ranked = {}
+    raw = {}
+    for query_idx in range(len(I_nearest_neighbor)):
+        seen_pid = set()
+        query_id = query_embedding2id[query_idx]
+        if query_id not in ranked:
+            ranked[query_id] = [(0, 0)] * topN
+        raw[query_id] = raw_sequences[query_idx]
+        rank = 0
+        for idx, score in zip(I_nearest_neighbor[query_idx][:topN], merged_D[query_idx][:topN].tolist()):
+            pred_pid = offset2pid[idx]
+            if pred_pid not in seen_pid:
+                ranked[query_id][rank] = (pred_pid, score)
+                rank += 1
+                seen_pid.add(pred_pid)
+    queries = {}
+    with open(os.path.join(raw_data_dir, "queries." + output_query_type + ".tsv")) as f:
+        for line in f:
+            qid, query = line.strip().split("\t")
+            queries[qid] = query
+    collection = os.path.join(raw_data_dir, "collection.jsonl")
+    if not os.path.exists(collection):
+        collection = os.path.join(raw_data_dir, "collection.tsv")
+        if not os.path.exists(collection):
+            raise FileNotFoundError("Neither collection.tsv nor collection.jsonl found in {}".format(raw_data_dir))
+    all_passages = (load_collection or _load_collection)(collection)
+    with open(output_file, "w") as f, open(output_trec_file, "w") as g:
+        for qid, passages in ranked.items():
+            for i in range(topN):
+                pid, score = passages[i]
+                label = 0 if qid not in dev_query_positive_id else dev_query_positive_id[qid].get(pid, 0)
+                f.write(json.dumps({"query": queries[qid], "doc": all_passages[pid], "label": label,
+                                    "query_id": str(qid), "doc_id": str(pid), "retrieval_score": score,
+                                    "input": raw[qid]}) + "\n")
+                g.write(str(qid) + " Q0 " + str(pid) + " " + str(i + 1) + " " + str(-i - 1 + 200) + " ance\n")
+
+
+class _Passages(dict):
+    def __missing__(self, key):
+        return "[INVALID DOC ID]"
+
+
+def _load_collection(collection_file):
+    """utils/util.py:327-352 without the 50M-entry list: a dict with the same default."""
+    all_passages = _Passages()
+    ext = collection_file[collection_file.rfind(".") + 1:]
+    if ext not in ["jsonl", "tsv"]:
+        raise TypeError("Unrecognized file type")
+    with open(collection_file) as f:
+        for line in f:
+            line = line.strip()
+            if ext == "jsonl":
+                obj = json.loads(line)
+                all_passages[int(obj["id"])] = obj["title"] + "[SEP]" + obj["text"]
+            else:
+                try:
+                    arr = line.split("\t")
+                    all_passages[int(arr[0])] = arr[1].rstrip()
+                except IndexError:
+                    print("bad passage")
+                except ValueError:
+                    print("bad pid")
+    return all_passages

@@ -21,9 +21,11 @@ Canonical score.  FAISS computes scores with an fp32 SGEMM whose summation order
 is unspecified, so no bit-exact score exists to match.  This oracle (and the HIP
 rescoring kernel, convdr_amd/csrc/ip_topk.hip) define ONE canonical value:
 
-    lane l (0..63) accumulates  sum_j  double(q[64 j + l]) * double(p[64 j + l])
-    sequentially in j (the products of two fp32 are exact in fp64), then the 64
-    partials are folded by a butterfly  x[l] += x[l ^ 32], ^16, ^8, ^4, ^2, ^1.
+    vectors are zero-padded to a multiple of 256; lane l (0..63) owns the elements
+    256 j + 4 l + c  (j = 0.., c = 0..3: one float4 per 1 KB line) and accumulates
+    double(q[e]) * double(p[e]) sequentially in (j, c) order (the product of two fp32
+    is exact in fp64, so each step is one rounding); then the 64 partials are folded
+    by a butterfly  x[l] += x[l ^ 32], ^16, ^8, ^4, ^2, ^1.
 
 Ranking is by (canonical fp64 score descending, index ascending); the reported
 ``D`` is that score rounded to fp32 (what FAISS hands back is fp32).  Any fp32
@@ -40,15 +42,19 @@ def canonical_scores(Q, P, chunk=256):
     P = np.ascontiguousarray(P, dtype=np.float32)
     nq, d = Q.shape
     n = P.shape[0]
-    dp = (d + 63) // 64 * 64
+    dp = (d + 255) // 256 * 256
+    nj = dp // 256
     Q64 = np.zeros((nq, dp), np.float64); Q64[:, :d] = Q
+    Q64 = Q64.reshape(nq, nj, 64, 4)
     out = np.empty((nq, n), np.float64)
     for s in range(0, n, chunk):
         e = min(n, s + chunk)
         P64 = np.zeros((e - s, dp), np.float64); P64[:, :d] = P[s:e]
+        P64 = P64.reshape(e - s, nj, 64, 4)
         acc = np.zeros((nq, e - s, 64), np.float64)
-        for j in range(dp // 64):
-            acc += Q64[:, None, 64 * j:64 * j + 64] * P64[None, :, 64 * j:64 * j + 64]
+        for j in range(nj):
+            for c in range(4):
+                acc += Q64[:, None, j, :, c] * P64[None, :, j, :, c]
         w = 32
         while w >= 1:
             acc = acc[..., :w] + acc[..., w:2 * w]

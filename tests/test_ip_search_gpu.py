@@ -1,0 +1,150 @@
+"""Parity of the HIP inner-product top-k (through the C ABI) with the CPU oracle and
+with the reference-run fixtures.  GPU only; `tests/test_capi_cpu.py` covers loading."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import search as OS
+from tests.helpers import assert_topk_equivalent
+from tests.golden.make_golden import synth_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+def _index(d=768, **kw):
+    from convdr_amd.search import FlatIPIndex
+    return FlatIPIndex(d, **kw)
+
+
+@pytest.mark.parametrize("n,nq,k,d", [
+    (700, 16, 100, 768),      # n <= cap: every passage is a candidate
+    (5000, 37, 100, 768),     # full-score threshold pass
+    (5000, 5, 10, 64),        # small d (one k-step), small k
+    (40000, 24, 100, 768),    # sampled threshold pass, ragged last tile
+    (33000, 130, 7, 128),     # two query tiles, ragged both ways
+])
+def test_search_matches_oracle_bit_exact(torch_cuda, n, nq, k, d):
+    P, Q = synth_corpus(100 + n % 97, n, d), synth_corpus(7, nq, d)
+    idx = _index(d)
+    idx.add(P)
+    D, I = idx.search(Q, k)
+    Dr, Ir = OS.flat_ip_search(Q, P, k)
+    np.testing.assert_array_equal(I, Ir)          # integer indexing: bit exact
+    np.testing.assert_array_equal(D, Dr)          # canonical fp64 score rounded to fp32: bit exact
+    assert D.dtype == np.float32 and I.dtype == np.int64
+
+
+def test_exact_ties_lower_index_first(torch_cuda):
+    base = synth_corpus(21, 300, 768)
+    P = np.concatenate([base[:200], base[50:60], base[50:60]])
+    Q = base[48:56] + 0.0
+    idx = _index()
+    idx.add(P)
+    D, I = idx.search(Q, 10)
+    Dr, Ir = OS.flat_ip_search(Q, P, 10)
+    np.testing.assert_array_equal(I, Ir)
+    for j, r in enumerate(range(48, 56)):
+        if r >= 50:
+            assert I[j, :3].tolist() == [r, 200 + r - 50, 210 + r - 50]
+
+
+def test_fewer_passages_than_k_and_empty(torch_cuda):
+    P, Q = synth_corpus(3, 37, 768), synth_corpus(4, 3, 768)
+    idx = _index()
+    idx.add(P)
+    D, I = idx.search(Q, 100)
+    Dr, Ir = OS.flat_ip_search(Q, P, 100)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D, Dr)
+    assert (I[:, 37:] == -1).all()
+    idx.reset()
+    assert idx.ntotal == 0
+    D, I = idx.search(Q, 5)
+    assert (I == -1).all()
+
+
+def test_add_appends_like_faiss(torch_cuda):
+    P, Q = synth_corpus(5, 3000, 768), synth_corpus(6, 9, 768)
+    idx = _index()
+    idx.add(P[:1200]); idx.add(P[1200:])
+    assert idx.ntotal == 3000
+    D, I = idx.search(Q, 50)
+    Dr, Ir = OS.flat_ip_search(Q, P, 50)
+    np.testing.assert_array_equal(I, Ir)
+
+
+def test_retry_path_is_exact(torch_cuda):
+    """Force the certificate to fail (tiny rank target -> tau above the k-th score) and a
+    candidate overflow (huge rank target on a tight capacity): the host loop must still
+    return the exact answer."""
+    P, Q = synth_corpus(8, 20000, 768), synth_corpus(9, 12, 768)
+    Dr, Ir = OS.flat_ip_search(Q, P, 100)
+    idx = _index(rank_target=100, cap=1024)       # tau ~ the 100th score: eps margin cannot hold
+    idx.add(P)
+    D, I = idx.search(Q, 100)
+    assert idx.stats["retried"] > 0
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D, Dr)
+
+
+def test_search_one_by_one_matches_reference_fixture(torch_cuda, golden_dir, tmp_path):
+    from convdr_amd.search import search_one_by_one
+    z = np.load(os.path.join(golden_dir, "search.npz"))
+    for r, (n, s) in enumerate(zip(z["a/sizes"], z["a/seeds"])):
+        for pre, arr in (("passage__emb_p_", synth_corpus(int(s), int(n), 768)),
+                         ("passage__embid_p_", np.arange(int(n), dtype=np.int64) * 3 + r)):
+            with open(tmp_path / ("%s_data_obj_%d.pb" % (pre, r)), "wb") as h:
+                pickle.dump(arr, h, protocol=4)
+    Q = synth_corpus(int(z["a/qseed"]), 16, 768)
+    topN = int(z["a/topN"])
+    mD, mI = search_one_by_one(str(tmp_path), _index(), Q, topN)
+    assert mD.shape == z["a/merged_D"].shape and mD.dtype == np.float64 and mI.dtype == np.int64
+    assert_topk_equivalent(z["a/merged_D"], z["a/merged_I"], mD, mI, k=topN)
+    # and bit-exact against the oracle restatement of the same function
+    blocks = [(synth_corpus(int(s), int(n), 768), np.arange(int(n), dtype=np.int64) * 3 + r)
+              for r, (n, s) in enumerate(zip(z["a/sizes"], z["a/seeds"]))]
+    oD, oI = OS.search_one_by_one(blocks, Q, topN)
+    np.testing.assert_array_equal(mI, oI)
+    np.testing.assert_array_equal(mD, oD)
+
+
+def test_full_size_properties_1m_x_1k(torch_cuda):
+    """BASELINE config 2 size (1M x 768, 1k queries, k=100): size-independent properties,
+    checked with an independent fp32 GEMM (torch/rocBLAS) on the same device."""
+    torch = torch_cuda
+    n, nq, k, d = 1_000_000, 1000, 100, 768
+    g = torch.Generator(device="cuda").manual_seed(0)
+    P = torch.randn(n, d, device="cuda", generator=g)
+    Q = torch.randn(nq, d, device="cuda", generator=g)
+    # planted needles: passage 1000*q+17 is strongly aligned with query q -> must be rank 1
+    needles = torch.arange(nq, device="cuda") * 1000 + 17
+    P[needles] = Q * 3.0
+    idx = _index()
+    idx.add(P)
+    D, I = idx.search(Q, k)
+    assert idx.stats["retried"] == 0, idx.stats
+    Dt, It = torch.from_numpy(D).cuda(), torch.from_numpy(I).cuda()
+    assert (It[:, 0] == needles).all()
+    assert (Dt[:, :-1] >= Dt[:, 1:]).all()                                   # sorted
+    assert ((It >= 0) & (It < n)).all()
+    assert all(len(set(row)) == k for row in I[::50].tolist())               # no duplicates
+    # scores are the true inner products of the returned ids
+    exact = torch.einsum("qd,qkd->qk", Q.double(), P[It.reshape(-1)].reshape(nq, k, d).double())
+    assert (exact.float() - Dt).abs().max().item() == 0.0 or \
+        torch.allclose(exact.float(), Dt, rtol=0, atol=1e-4)
+    # nothing outside the returned set beats the k-th score (independent fp32 GEMM, chunked)
+    kth = Dt[:, -1:].clone()
+    above = torch.zeros(nq, dtype=torch.int64, device="cuda")
+    for s in range(0, n, 125_000):
+        S = Q @ P[s:s + 125_000].T
+        above += (S > kth + 5e-3).sum(1)
+    assert (above <= k - 1).all(), above.max().item()
