@@ -18,6 +18,7 @@ _SIGNATURES = {
     "convdr_ip_search": (C.c_int, [_p, C.c_int, _p, _p, C.c_int64, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int,
                                    _p, C.c_size_t, _p, _p, _p, _p, _p]),
     "convdr_ip_debug_counts": (_p, [_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "convdr_ip_debug_band": (_p, [_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
 }
 
 

@@ -216,16 +216,95 @@ __global__ void __launch_bounds__(1024) k_tau_select(const float* __restrict__ T
 }
 
 // ------------------------------------------------------------------------------------------
+// band cut: which candidates must be re-scored exactly?
+// Let s~(k) be the k-th best bf16-pass score of the query and eps its error bound
+// (|s~ - exact| <= eps for every passage of the block).  The k best by s~ all have exact >= s~(k) - eps,
+// so the true k-th exact score t_k >= s~(k) - eps.  A passage with s~ < cut := s~(k) - 2 eps has
+// exact < s~(k) - eps <= t_k and cannot be in the true top-k.  Hence re-scoring exactly the band
+// {s~ >= cut} yields the exact top-k, PROVIDED the candidate list is complete down to cut, i.e.
+// cut >= tau and the list did not overflow.  Otherwise the query is flagged for a retry with a
+// threshold that makes the next pass complete.
+// Sorts the query's candidates by (s~ desc, index asc) in place and writes m[q] = band size.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ip_cut(int64_t n, int k, int cap, const uint32_t* __restrict__ counts,
+                                                uint32_t* __restrict__ cand_id, float* __restrict__ cand_s,
+                                                const float* __restrict__ tau, const float* __restrict__ qnorm,
+                                                const float* __restrict__ p_max_norm, uint32_t* __restrict__ m_out,
+                                                int32_t* __restrict__ status, float* __restrict__ tau_retry) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int sh_m;
+  const int q = blockIdx.x;
+  const uint32_t cnt = counts[q];
+  const int c = cnt < (uint32_t)cap ? (int)cnt : cap;
+  int np2 = 2;
+  while (np2 < c) np2 <<= 1;
+  float* s = (float*)smem;
+  uint32_t* id = (uint32_t*)(smem + (size_t)np2 * 4);
+  for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+    s[i] = i < c ? cand_s[(int64_t)q * cap + i] : -INFINITY;
+    id[i] = i < c ? cand_id[(int64_t)q * cap + i] : 0xffffffffu;
+  }
+  if (threadIdx.x == 0) sh_m = 0;
+  __syncthreads();
+  for (int k2 = 2; k2 <= np2; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+        const int p = i ^ j;
+        if (p > i) {
+          const float x = s[i], y = s[p];
+          const uint32_t ix = id[i], iy = id[p];
+          const bool fwd = (i & k2) == 0;
+          const bool y_first = y > x || (y == x && iy < ix);
+          const bool x_first = x > y || (x == y && ix < iy);
+          if (fwd ? y_first : x_first) { s[i] = y; s[p] = x; id[i] = iy; id[p] = ix; }
+        }
+      }
+      __syncthreads();
+    }
+  const int need = (int64_t)k < n ? k : (int)n;
+  const float t = tau[q];
+  const float eps = IP_EPS_COEF * qnorm[q] * p_max_norm[0] * 1.001f + 1e-30f;
+  const bool have_k = need > 0 && c >= need;
+  const float cut = have_k ? s[need - 1] - 2.f * eps : -INFINITY;
+  for (int i = threadIdx.x; i < c; i += blockDim.x)
+    if (s[i] >= cut && (i + 1 == c || !(s[i + 1] >= cut))) sh_m = i + 1;
+  for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    cand_id[(int64_t)q * cap + i] = id[i];
+    cand_s[(int64_t)q * cap + i] = s[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int st = CONVDR_IP_OK;
+    float retry = -INFINITY;
+    if (cnt > (uint32_t)cap) {
+      // stored candidates are a subset of {s~ >= tau}: their k-th s~ bounds the true s~(k) from below,
+      // so `cut` is a valid (if loose) threshold; when it does not tighten tau the caller raises cap
+      st = CONVDR_IP_OVERFLOW;
+      const float cand = nextafterf(cut, -INFINITY);
+      retry = cand > t ? cand : t;
+    } else if (c < need) {
+      st = CONVDR_IP_TOO_FEW;
+      retry = t - 4.f * eps - 1e-3f * fabsf(t);
+    } else if (need > 0 && t > -INFINITY && cut < t) {
+      st = CONVDR_IP_UNCERTAIN;  // band reaches below tau: list incomplete in [cut, tau)
+      retry = nextafterf(cut, -INFINITY);
+    }
+    m_out[q] = (uint32_t)sh_m;
+    status[q] = st;
+    tau_retry[q] = retry;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // exact rescoring: canonical fp64 inner product (see oracle/search.py: lane l owns elements
 // 256 j + 4 l + c, accumulated in (j, c) order; then butterfly 32,16,8,4,2,1)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_ip_rescore(const float* __restrict__ Q, const float* __restrict__ P, int d,
-                                                    int cap, const uint32_t* __restrict__ counts,
+                                                    int cap, const uint32_t* __restrict__ m_in,
                                                     const uint32_t* __restrict__ cand_id,
                                                     double* __restrict__ cand_x) {
   const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t cnt = counts[q];
-  const uint32_t c = cnt < (uint32_t)cap ? cnt : (uint32_t)cap;
+  const uint32_t c = m_in[q];
   const float* qv = Q + (int64_t)q * d;
   for (uint32_t slot = blockIdx.y * 4 + wave; slot < c; slot += gridDim.y * 4) {
     const uint32_t id = cand_id[(int64_t)q * cap + slot];
@@ -246,19 +325,15 @@ __global__ void __launch_bounds__(256) k_ip_rescore(const float* __restrict__ Q,
 }
 
 // ------------------------------------------------------------------------------------------
-// per-query final sort + certificate
+// per-query final sort of the re-scored band by (exact score desc, index asc) -> top-k
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ip_select(int64_t n, int k, int cap, const uint32_t* __restrict__ counts,
+__global__ void __launch_bounds__(256) k_ip_select(int k, int cap, const uint32_t* __restrict__ m_in,
                                                    const uint32_t* __restrict__ cand_id,
-                                                   const double* __restrict__ cand_x, const float* __restrict__ tau,
-                                                   const float* __restrict__ qnorm,
-                                                   const float* __restrict__ p_max_norm, float* __restrict__ D,
-                                                   int64_t* __restrict__ I, int32_t* __restrict__ status,
-                                                   float* __restrict__ tau_retry) {
+                                                   const double* __restrict__ cand_x, float* __restrict__ D,
+                                                   int64_t* __restrict__ I) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int q = blockIdx.x;
-  const uint32_t cnt = counts[q];
-  const int c = cnt < (uint32_t)cap ? (int)cnt : cap;
+  const int c = (int)m_in[q];
   int np2 = 2;
   while (np2 < c) np2 <<= 1;
   double* s = (double*)smem;
@@ -273,29 +348,6 @@ __global__ void __launch_bounds__(256) k_ip_select(int64_t n, int k, int cap, co
     D[(int64_t)q * k + j] = j < c ? (float)s[j] : -FLT_MAX;
     I[(int64_t)q * k + j] = j < c ? (int64_t)id[j] : -1;
   }
-  if (threadIdx.x == 0) {
-    const int need = (int64_t)k < n ? k : (int)n;
-    const float t = tau[q];
-    const float eps = IP_EPS_COEF * qnorm[q] * p_max_norm[0] * 1.001f + 1e-30f;
-    int st = CONVDR_IP_OK;
-    float retry = -INFINITY;
-    const double kth = (need > 0 && c >= need) ? s[need - 1] : -INFINITY;
-    if (cnt > (uint32_t)cap) {
-      // The stored candidates are a subset of {S~ >= tau}; their k-th exact score bounds the true one from
-      // below, so every true top-k member has S~ >= kth - eps.  If that does not tighten tau the caller
-      // must raise cap.
-      st = CONVDR_IP_OVERFLOW;
-      const float cand = nextafterf((float)kth - eps, -INFINITY);
-      retry = cand > t ? cand : t;
-    } else if (c < need) {
-      st = CONVDR_IP_TOO_FEW;
-    } else if (need > 0 && t > -INFINITY && !(kth >= (double)t + (double)eps)) {
-      st = CONVDR_IP_UNCERTAIN;
-      retry = nextafterf((float)kth - eps, -INFINITY);
-    }
-    status[q] = st;
-    tau_retry[q] = retry;
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -307,7 +359,7 @@ struct IpPlan {
   int nSt, stride;   // sampled passage tiles / tile stride
   int64_t nvals;     // values per query handed to k_tau_select
   int npow2;
-  size_t o_qb, o_qnorm, o_tau, o_counts, o_T, o_id, o_s, o_x, total;
+  size_t o_qb, o_qnorm, o_tau, o_counts, o_m, o_T, o_id, o_s, o_x, total;
 };
 
 static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
@@ -337,6 +389,7 @@ static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
   p.o_qnorm = take((size_t)p.nq_pad * 4);
   p.o_tau = take((size_t)p.nq_pad * 4);
   p.o_counts = take((size_t)p.nq_pad * 4);
+  p.o_m = take((size_t)p.nq_pad * 4);
   const size_t t_rows = p.mode == IP_MODE_FULL ? (size_t)p.nPt * GEMM_BM : (size_t)p.nvals;
   p.o_T = take(t_rows * p.nq_pad * 4);
   p.o_id = take((size_t)nq * cap * 4);
@@ -388,6 +441,10 @@ extern "C" const uint32_t* convdr_ip_debug_counts(const void* workspace, int nq,
   return (const uint32_t*)((const char*)workspace + ip_plan(nq, n, d, k, cap).o_counts);
 }
 
+extern "C" const uint32_t* convdr_ip_debug_band(const void* workspace, int nq, int64_t n, int d, int k, int cap) {
+  return (const uint32_t*)((const char*)workspace + ip_plan(nq, n, d, k, cap).o_m);
+}
+
 extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, const void* p_bf16, int64_t n, int d,
                                 int k, const float* p_max_norm, const float* tau_in, int cap, int rank_target,
                                 void* workspace, size_t workspace_bytes, float* D, int64_t* I, int32_t* status,
@@ -411,6 +468,7 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
   uint32_t* cand_id = (uint32_t*)(ws + p.o_id);
   float* cand_s = (float*)(ws + p.o_s);
   double* cand_x = (double*)(ws + p.o_x);
+  uint32_t* band = (uint32_t*)(ws + p.o_m);
 
   // queries -> bf16 (+ norms); padded rows stay zero
   CONVDR_CHECK_HIP(hipMemsetAsync(qb, 0, (size_t)p.nq_pad * d * 2, st));
@@ -431,7 +489,7 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
       hipLaunchKernelGGL(k_fill_f32, dim3((p.nq_pad + 255) / 256), dim3(256), 0, st, tau, p.nq_pad, -INFINITY);
       CONVDR_CHECK_LAUNCH("k_fill_f32");
     } else {
-      int R = rank_target > 0 ? rank_target : 6 * k;
+      int R = rank_target > 0 ? rank_target : 16 * k;
       if (R > cap / 2) R = cap / 2;
       if (R < k) R = k;
       int r;
@@ -457,18 +515,23 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
     }
     a.nPt = p.nPt; a.pt_stride = 1;
     if (int e = launch_scan<IP_MODE_EMIT>(a, st)) return e;
-    ProfScope prof("ip_rescore", st);
-    hipLaunchKernelGGL(k_ip_rescore, dim3(nq, 16), dim3(256), 0, st, q_f32, p_f32, d, cap, counts, cand_id, cand_x);
-    CONVDR_CHECK_LAUNCH("k_ip_rescore");
   }
-  static bool sel_attr = false;
-  if (!sel_attr) {
+  static bool attr_done2 = false;
+  if (!attr_done2) {
+    CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_cut, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
     CONVDR_CHECK_HIP(
         hipFuncSetAttribute((const void*)k_ip_select, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12));
-    sel_attr = true;
+    attr_done2 = true;
   }
-  hipLaunchKernelGGL(k_ip_select, dim3(nq), dim3(256), (size_t)cap * 12, st, n, k, cap, counts, cand_id, cand_x, tau,
-                     qnorm, p_max_norm, D, I, status, tau_retry);
+  hipLaunchKernelGGL(k_ip_cut, dim3(nq), dim3(256), (size_t)cap * 8, st, n, k, cap, counts, cand_id, cand_s, tau, qnorm,
+                     p_max_norm, band, status, tau_retry);
+  CONVDR_CHECK_LAUNCH("k_ip_cut");
+  if (n > 0) {
+    ProfScope prof("ip_rescore", st);
+    hipLaunchKernelGGL(k_ip_rescore, dim3(nq, 16), dim3(256), 0, st, q_f32, p_f32, d, cap, band, cand_id, cand_x);
+    CONVDR_CHECK_LAUNCH("k_ip_rescore");
+  }
+  hipLaunchKernelGGL(k_ip_select, dim3(nq), dim3(256), (size_t)cap * 12, st, k, cap, band, cand_id, cand_x, D, I);
   CONVDR_CHECK_LAUNCH("k_ip_select");
   return 0;
 }

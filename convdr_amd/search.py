@@ -16,6 +16,11 @@ import numpy as np
 
 from . import _lib
 
+def _torch():
+    import torch
+    return torch
+
+
 STATUS_OK, STATUS_OVERFLOW, STATUS_TOO_FEW, STATUS_UNCERTAIN = 0, 1, 2, 3
 
 
@@ -93,6 +98,16 @@ class FlatIPIndex:
                                           _lib.ptr(ws), ws.numel(), _lib.ptr(D), _lib.ptr(I), _lib.ptr(status),
                                           _lib.ptr(tau_retry), _lib.stream_ptr()), "convdr_ip_search")
         return D, I, status, tau_retry
+
+    def last_counts(self, nq, k, cap=None):
+        """(emitted, band) int32 tensors [nq] of the last search_device call (instrumentation)."""
+        L = _lib.lib()
+        cap = cap or self.cap
+        out = []
+        for fn in (L.convdr_ip_debug_counts, L.convdr_ip_debug_band):
+            off = fn(_lib.ptr(self._ws), nq, self.ntotal, self.d, k, cap) - self._ws.data_ptr()
+            out.append(self._ws[off:off + 4 * nq].view(_torch().int32))
+        return tuple(out)
 
     def search(self, q, k):
         """FAISS ``index.search``: numpy in, numpy (D, I) out.  Queries whose first pass

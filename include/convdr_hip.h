@@ -48,33 +48,37 @@ int convdr_ip_prepare_block(const float* p_f32, int64_t n, int d, void* p_bf16, 
 size_t convdr_ip_workspace_bytes(int nq, int64_t n, int d, int k, int cap);
 
 /* per-query status written by convdr_ip_search */
-#define CONVDR_IP_OK 0        /* result is the exact top-k (certified)                       */
-#define CONVDR_IP_OVERFLOW 1  /* more than `cap` candidates passed tau: retry with tau_retry  */
-#define CONVDR_IP_TOO_FEW 2   /* fewer than min(k, n) candidates passed tau: retry with -inf  */
-#define CONVDR_IP_UNCERTAIN 3 /* k-th exact score < tau + eps: retry with tau_retry           */
+#define CONVDR_IP_OK 0        /* result is the exact top-k (certified)                                  */
+#define CONVDR_IP_OVERFLOW 1  /* more than `cap` candidates passed tau: retry with tau_retry (raise cap
+                                 when tau_retry does not exceed the tau that was used)                    */
+#define CONVDR_IP_TOO_FEW 2   /* fewer than min(k, n) candidates passed tau: retry with tau_retry         */
+#define CONVDR_IP_UNCERTAIN 3 /* the re-score band reaches below tau: retry with tau_retry               */
 
 /* .search(Q, k): exact inner-product top-k of nq fp32 queries against one resident block.
- *   pass 1  bf16 MFMA scan  S~ = P_bf16 * Q_bf16^T  with a fused per-query threshold test; the
- *           passages with S~ >= tau[q] are appended to a candidate list (never a [nq, n] matrix);
- *           tau comes from a bf16 scan of a 1/32 sample of the block (or tau_in when given);
- *   pass 2  every candidate is re-scored from the fp32 originals in fp64 with the canonical
- *           summation order documented in oracle/search.py, sorted by (score desc, index asc);
- *   certificate  a passage outside the list has S~ < tau, hence exact score < tau + eps with
- *           eps = 0.0079 * ||q|| * max||p|| (rigorous bf16 rounding bound); status is OK only if
- *           the k-th exact score >= tau + eps, so OK results equal the exhaustive exact top-k.
+ *   scan     bf16 MFMA GEMM  S~ = P_bf16 * Q_bf16^T  with a fused per-query threshold test: passages with
+ *            S~ >= tau[q] are appended to a candidate list (a [nq, n] score matrix is never written);
+ *            tau comes from a bf16 scan of a 1/32 sample of the block, aimed at `rank_target` hits per
+ *            query (or tau_in when given);
+ *   cut      with eps = 0.0079 * ||q|| * max||p|| (rigorous bound on |S~ - exact|): the band
+ *            {S~ >= S~(k) - 2 eps} provably contains the exact top-k;
+ *   rescore  the band is re-scored from the fp32 originals in fp64 with the canonical summation order
+ *            documented in oracle/search.py, and sorted by (score desc, index asc).
+ * status is OK only if the candidate list is complete over the band (cut >= tau, no overflow), so an
+ * OK result equals the exhaustive exact top-k; otherwise tau_retry[q] is the threshold to pass as
+ * tau_in for that query.
  * Outputs (device): D [nq, k] fp32 scores (descending), I [nq, k] int64 row indices into the block
- * (-1 / -FLT_MAX padding when n < k, as FAISS does), status [nq] int32, tau_retry [nq] fp32 (the
- * threshold to pass as tau_in for queries whose status != OK).
+ * (-1 / -FLT_MAX padding when n < k, as FAISS does), status [nq] int32, tau_retry [nq] fp32.
  * tau_in: NULL, or device [nq] thresholds (retry path).  cap: candidate capacity per query
- * (power of two, 1024..8192).  rank_target: expected candidates per query (0 -> 6*k).          */
+ * (power of two, 1024..8192).  rank_target: expected candidates per query (0 -> 16*k, at most cap/2). */
 int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, const void* p_bf16, int64_t n, int d,
                      int k, const float* p_max_norm, const float* tau_in, int cap, int rank_target,
                      void* workspace, size_t workspace_bytes, float* D, int64_t* I, int32_t* status,
                      float* tau_retry, convdr_stream_t stream);
 
-/* Candidate counts of the last convdr_ip_search on this workspace (device uint32 [nq]); for
- * instrumentation (bench.py reports the mean). */
+/* Instrumentation of the last convdr_ip_search on this workspace (device uint32 [nq] each):
+ * candidates emitted by the scan / size of the exactly re-scored band. */
 const uint32_t* convdr_ip_debug_counts(const void* workspace, int nq, int64_t n, int d, int k, int cap);
+const uint32_t* convdr_ip_debug_band(const void* workspace, int nq, int64_t n, int d, int k, int cap);
 
 #ifdef __cplusplus
 }
