@@ -73,3 +73,27 @@ def prof_collect(name):
     ms, cnt = C.c_float(0), C.c_int(0)
     check(lib().convdr_prof_collect(name.encode(), C.byref(ms), C.byref(cnt)), "convdr_prof_collect")
     return ms.value, cnt.value
+
+
+# ---- structs of include/convdr_hip.h -------------------------------------------------------
+class EncoderConfig(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32), ("layers", C.c_int32),
+                ("intermediate", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("pad_idx", C.c_int32),
+                ("out_dim", C.c_int32), ("ln_eps", C.c_float), ("head_ln_eps", C.c_float)]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2",
+                                          "ln2_g", "ln2_b")]
+
+
+class EncoderWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b")] + \
+               [("layers", C.POINTER(LayerWeights))] + \
+               [(n, C.c_void_p) for n in ("head_w", "head_b", "head_ln_g", "head_ln_b")]
+
+
+register("convdr_cast_f32_bf16", C.c_int, [_p, _p, C.c_int64, _p])
+register("convdr_encoder_workspace_bytes", C.c_size_t, [C.POINTER(EncoderConfig), C.c_int64, C.c_int])
+register("convdr_encoder_forward", C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), _p, _p, C.c_int,
+                                             C.c_int, _p, _p, C.c_int64, C.c_int, _p, C.c_size_t, _p, _p])

@@ -1,0 +1,177 @@
+// Host orchestration + C ABI of the dual-encoder forward (inference path).
+// Reference call sites replaced:  model/models.py:140-148 (RobertaDot_NLL_LN.query_emb/body_emb),
+// :205-211 + :227-235 (HFBertEncoder / BiEncoder.query_emb/body_emb).
+#include "encoder_kernels.hpp"
+
+#include "../../include/convdr_hip.h"
+
+namespace convdr {
+
+struct EncBufs {
+  int32_t *tok_id, *tok_pos;
+  bf16_t *X, *Q, *K, *Vt, *ctx, *Hm, *cls_b;
+  float *Y, *cls_y, *cls_f, *head_y;
+  int64_t ldt;
+  size_t total;
+};
+
+static EncBufs enc_plan(const convdr_encoder_config* c, int64_t rows, int B, char* base) {
+  EncBufs p;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return base + at; };
+  const int H = c->hidden, I = c->intermediate;
+  const int64_t rs = rows + 128;  // slack: attention K tiles / clamped reads
+  p.ldt = align_up((size_t)rows + 64, 8);
+  p.tok_id = (int32_t*)take(rs * 4);
+  p.tok_pos = (int32_t*)take(rs * 4);
+  p.X = (bf16_t*)take(rs * H * 2);
+  p.Q = (bf16_t*)take(rs * H * 2);
+  p.K = (bf16_t*)take(rs * H * 2);
+  p.Vt = (bf16_t*)take((size_t)H * p.ldt * 2);
+  p.ctx = (bf16_t*)take(rs * H * 2);
+  p.Hm = (bf16_t*)take(rs * I * 2);
+  p.Y = (float*)take(rs * H * 4);
+  const int64_t Bp = B + 128;
+  p.cls_b = (bf16_t*)take(Bp * H * 2);
+  p.cls_y = (float*)take(Bp * H * 4);
+  p.cls_f = (float*)take(Bp * H * 4);
+  p.head_y = (float*)take(Bp * (c->out_dim > 0 ? c->out_dim : 1) * 4);
+  p.total = o;
+  return p;
+}
+
+template <int EPI>
+int launch_gemm(GemmArgs a, hipStream_t st, const char* prof_name) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    CONVDR_CHECK_HIP(
+        hipFuncSetAttribute((const void*)k_gemm<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES));
+    attr_done = true;
+  }
+  CONVDR_REQUIRE(a.K % GEMM_BK == 0 && a.N % 4 == 0, "gemm: need K %% 64 == 0 and N %% 4 == 0 (K=%d N=%d)", a.K, a.N);
+  a.tilesN = (a.N + 127) / 128;
+  a.tilesT = (int)ceil_div64(a.rows, 128);
+  if (a.tilesT == 0) return 0;
+  ProfScope prof(prof_name, st);
+  hipLaunchKernelGGL(k_gemm<EPI>, dim3((unsigned)a.tilesN * a.tilesT), dim3(GEMM_THREADS), GEMM_SMEM_BYTES, st, a);
+  CONVDR_CHECK_LAUNCH("k_gemm");
+  return 0;
+}
+
+static int check_config(const convdr_encoder_config* c) {
+  CONVDR_REQUIRE(c->hidden % 128 == 0 && c->hidden <= 1024, "encoder: hidden must be a multiple of 128, <= 1024 (got %d)",
+                 c->hidden);
+  CONVDR_REQUIRE(c->heads * 64 == c->hidden, "encoder: head_dim must be 64 (hidden=%d heads=%d)", c->hidden, c->heads);
+  CONVDR_REQUIRE(c->intermediate % 64 == 0, "encoder: intermediate %% 64 != 0 (%d)", c->intermediate);
+  CONVDR_REQUIRE(c->out_dim == 0 || (c->out_dim % 4 == 0 && c->out_dim <= 1024), "encoder: bad out_dim %d", c->out_dim);
+  return 0;
+}
+
+// One transformer layer on packed rows; buffers may be shared across layers (inference).
+int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_weights* w, const EncBufs& p,
+                          const int32_t* cu, const int32_t* lens, int64_t rows, int B, int max_len, float* lse,
+                          hipStream_t st) {
+  const int H = c->hidden, I = c->intermediate;
+  GemmArgs g{};
+  g.rows = rows;
+  // fused QKV projection: Q, K token-major, V feature-major
+  g.W = (const bf16_t*)w->wqkv; g.X = p.X; g.N = 3 * H; g.K = H; g.bias = w->bqkv;
+  g.Qo = p.Q; g.Ko = p.K; g.Vt = p.Vt; g.H = H; g.ldt = p.ldt;
+  if (int e = launch_gemm<EPI_QKV>(g, st, "gemm_qkv")) return e;
+  {
+    AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, p.ctx, lse, 0.125f};
+    ProfScope prof("attention", st);
+    hipLaunchKernelGGL(k_attention_fwd, dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
+    CONVDR_CHECK_LAUNCH("k_attention_fwd");
+  }
+  // attention output dense + residual -> Y (fp32) -> LayerNorm -> X
+  g = GemmArgs{};
+  g.rows = rows; g.W = (const bf16_t*)w->wo; g.X = p.ctx; g.N = H; g.K = H; g.bias = w->bo; g.Cf = p.Y; g.R = p.X;
+  if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_attn_out")) return e;
+  {
+    ProfScope prof("layernorm", st);
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.Y, rows, H, w->ln1_g,
+                       w->ln1_b, c->ln_eps, p.X, (float*)nullptr);
+    CONVDR_CHECK_LAUNCH("k_layernorm");
+  }
+  // FFN
+  g = GemmArgs{};
+  g.rows = rows; g.W = (const bf16_t*)w->w1; g.X = p.X; g.N = I; g.K = H; g.bias = w->b1; g.Cb = p.Hm;
+  if (int e = launch_gemm<EPI_GELU_BF16>(g, st, "gemm_ffn1")) return e;
+  g = GemmArgs{};
+  g.rows = rows; g.W = (const bf16_t*)w->w2; g.X = p.Hm; g.N = H; g.K = I; g.bias = w->b2; g.Cf = p.Y; g.R = p.X;
+  if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_ffn2")) return e;
+  return 0;
+}
+
+}  // namespace convdr
+
+using namespace convdr;
+
+extern "C" size_t convdr_encoder_workspace_bytes(const convdr_encoder_config* cfg, int64_t rows, int B) {
+  return enc_plan(cfg, rows, B, nullptr).total;
+}
+
+extern "C" int convdr_cast_f32_bf16(const float* x, void* y, int64_t n, convdr_stream_t stream) {
+  CONVDR_REQUIRE(n % 4 == 0, "convdr_cast_f32_bf16: n %% 4 != 0 (%lld)", (long long)n);
+  if (n == 0) return 0;
+  const int64_t n4 = n / 4;
+  const unsigned grid = (unsigned)(ceil_div64(n4, 256) < 4096 ? ceil_div64(n4, 256) : 4096);
+  hipLaunchKernelGGL(k_cast_f32_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n4);
+  CONVDR_CHECK_LAUNCH("k_cast_f32_bf16");
+  return 0;
+}
+
+extern "C" int convdr_encoder_forward(const convdr_encoder_config* cfg, const convdr_encoder_weights* w,
+                                      const int64_t* input_ids, const int64_t* attention_mask, int B, int L,
+                                      const int32_t* cu_seqlens, const int32_t* seq_lens, int64_t rows, int max_len,
+                                      void* workspace, size_t workspace_bytes, float* out, convdr_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = check_config(cfg)) return e;
+  CONVDR_REQUIRE(B > 0 && L > 0 && rows > 0 && rows % 8 == 0 && max_len > 0 && max_len <= L,
+                 "convdr_encoder_forward: bad sizes B=%d L=%d rows=%lld max_len=%d", B, L, (long long)rows, max_len);
+  const EncBufs p = enc_plan(cfg, rows, B, (char*)workspace);
+  CONVDR_REQUIRE(workspace_bytes >= p.total, "convdr_encoder_forward: workspace too small (%zu < %zu)", workspace_bytes,
+                 p.total);
+  const int H = cfg->hidden;
+  // V^T columns past the last row are read (never used) by the last key tile: keep them finite
+  CONVDR_CHECK_HIP(hipMemset2DAsync(p.Vt + rows, p.ldt * 2, 0, (p.ldt - rows) * 2, H, st));
+  hipLaunchKernelGGL(k_seq_pack, dim3((B + 3) / 4), dim3(256), 0, st, input_ids, attention_mask, B, L, cu_seqlens,
+                     cfg->kind, cfg->pad_idx, cfg->max_pos, p.tok_id, p.tok_pos);
+  CONVDR_CHECK_LAUNCH("k_seq_pack");
+  {
+    ProfScope prof("embed_ln", st);
+    hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.tok_id, p.tok_pos, rows, H,
+                       w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, cfg->ln_eps, p.X);
+    CONVDR_CHECK_LAUNCH("k_embed_ln");
+  }
+  for (int l = 0; l < cfg->layers; ++l) {
+    const convdr_layer_weights* lw = &w->layers[l];
+    if (int e = encoder_layer_forward(cfg, lw, p, cu_seqlens, seq_lens, rows, B, max_len, nullptr, st)) return e;
+    if (l + 1 < cfg->layers) {
+      ProfScope prof("layernorm", st);
+      hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.Y, rows, H, lw->ln2_g,
+                         lw->ln2_b, cfg->ln_eps, p.X, (float*)nullptr);
+      CONVDR_CHECK_LAUNCH("k_layernorm");
+    } else {
+      // only the CLS rows of the last layer are live (models.py:43): gather their pre-LN sums, LayerNorm B rows
+      hipLaunchKernelGGL(k_gather_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, (const bf16_t*)nullptr,
+                         p.Y, (bf16_t*)nullptr, p.cls_y);
+      CONVDR_CHECK_LAUNCH("k_gather_cls");
+      float* cls_out = cfg->out_dim > 0 ? p.cls_f : out;
+      hipLaunchKernelGGL(k_layernorm, dim3((B + 3) / 4), dim3(256), 0, st, p.cls_y, (int64_t)B, H, lw->ln2_g, lw->ln2_b,
+                         cfg->ln_eps, p.cls_b, cls_out);
+      CONVDR_CHECK_LAUNCH("k_layernorm(cls)");
+    }
+  }
+  if (cfg->out_dim > 0) {  // rdot_nll head: LayerNorm(Linear(H, out_dim)(cls))   models.py:144
+    GemmArgs g{};
+    g.rows = B; g.W = (const bf16_t*)w->head_w; g.X = p.cls_b; g.N = cfg->out_dim; g.K = H; g.bias = w->head_b;
+    g.Cf = p.head_y;
+    if (int e = launch_gemm<EPI_F32>(g, st, "gemm_head")) return e;
+    hipLaunchKernelGGL(k_layernorm, dim3((B + 3) / 4), dim3(256), 0, st, p.head_y, (int64_t)B, cfg->out_dim,
+                       w->head_ln_g, w->head_ln_b, cfg->head_ln_eps, (bf16_t*)nullptr, out);
+    CONVDR_CHECK_LAUNCH("k_layernorm(head)");
+  }
+  return 0;
+}

@@ -1,0 +1,442 @@
+// Device kernels of the BERT/RoBERTa dual-encoder forward on gfx950 (shared by encoder.hip and train.hip).
+//
+// Replaces the third-party arithmetic behind  self.roberta(input_ids, attention_mask)
+// (/root/reference/model/models.py:141-142) and BertModel.forward (:208-209): HF transformers==2.3.0
+// embeddings + 12 x [self-attention, output dense + residual + LayerNorm, FFN + residual + LayerNorm].
+//
+// Data layout in HBM ("packed rows"): only tokens with attention_mask == 1 are computed.  Sequence b owns
+// rows [cu[b], cu[b] + len[b]) of every [rows, *] activation matrix; cu[b] is a multiple of 8 so that 16-byte
+// accesses along the token axis stay aligned.  CLS-only pooling (models.py:43, use_mean = False for every
+// registered config) makes this identical to the reference's padded computation (SURVEY.md §7 hard part 7).
+//   X    [rows, H]  bf16   layer input / LayerNorm output (MFMA operand and residual)
+//   Y    [rows, H]  f32    pre-LayerNorm sums (GEMM epilogue output, LayerNorm input)
+//   Q, K [rows, H]  bf16   row-major, head h = columns [64 h, 64 h + 64)
+//   Vt   [H, ldt]   bf16   V transposed (feature-major, token-contiguous): the P.V contraction runs over keys,
+//                          and MFMA wants the contraction index contiguous per lane, so the QKV GEMM epilogue
+//                          writes V already transposed instead of transposing it inside the attention kernel
+//   ctx  [rows, H]  bf16   attention output
+//   Hm   [rows, I]  bf16   gelu(FFN1)
+#pragma once
+#include "gemm_nt.hpp"
+
+namespace convdr {
+
+// ---------------------------------------------------------------------------------------------
+// pack: one wave per sequence.  Compacts the mask == 1 tokens of ids[b, :] to rows cu[b]..; position ids:
+//   RoBERTa: cumsum(ids != pad_idx) * (ids != pad_idx) + pad_idx over the FULL row (masked positions count,
+//            the reference pads with id 0 which is not RoBERTa's pad id 1 -- utils/util.py:146-185);
+//   BERT:    the column index.
+// Alignment rows [cu[b] + len, cu[b+1]) get token id -1 (embedding kernel writes zeros).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_seq_pack(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
+                                                  int B, int L, const int32_t* __restrict__ cu, int kind, int pad_idx,
+                                                  int max_pos, int32_t* __restrict__ tok_id,
+                                                  int32_t* __restrict__ tok_pos) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int base = cu[b], end = cu[b + 1];
+  int kept = 0, nonpad = 0;
+  for (int l0 = 0; l0 < L; l0 += 64) {
+    const int l = l0 + lane;
+    const bool valid = l < L;
+    const int64_t id = valid ? ids[(int64_t)b * L + l] : (int64_t)pad_idx;
+    const bool m = valid && mask[(int64_t)b * L + l] != 0;
+    const bool np = valid && id != pad_idx;
+    const unsigned long long bm = __ballot(m), bnp = __ballot(np);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (m) {
+      const int row = base + kept + __popcll(bm & lt);
+      if (row < end) {
+        int p = kind == 0 ? (np ? nonpad + __popcll(bnp & (lt | (1ull << lane))) + pad_idx : pad_idx) : l;
+        p = p < max_pos ? p : max_pos - 1;
+        tok_id[row] = (int)id;
+        tok_pos[row] = p;
+      }
+    }
+    kept += __popcll(bm);
+    nonpad += __popcll(bnp);
+  }
+  for (int r = base + kept + lane; r < end; r += 64) {
+    tok_id[r] = -1;
+    tok_pos[r] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm helpers: one wave per row, H <= 1024, H % 4 == 0; lane owns elements 256 j + 4 lane + c.
+// Biased variance, eps inside the sqrt (torch.nn.LayerNorm).
+// ---------------------------------------------------------------------------------------------
+struct LnRow {
+  float4 v[4];
+};
+
+__device__ __forceinline__ void ln_normalize(LnRow& x, int H, int lane, float eps, const float* __restrict__ g,
+                                             const float* __restrict__ b) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (256 * j + 4 * lane < H) s += x.v[j].x + x.v[j].y + x.v[j].z + x.v[j].w;
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (256 * j + 4 * lane < H) {
+      const float a = x.v[j].x - mean, c = x.v[j].y - mean, d = x.v[j].z - mean, e = x.v[j].w - mean;
+      q += a * a + c * c + d * d + e * e;
+    }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e0 = 256 * j + 4 * lane;
+    if (e0 < H) {
+      const float4 gg = *(const float4*)(g + e0), bb = *(const float4*)(b + e0);
+      x.v[j].x = (x.v[j].x - mean) * rstd * gg.x + bb.x;
+      x.v[j].y = (x.v[j].y - mean) * rstd * gg.y + bb.y;
+      x.v[j].z = (x.v[j].z - mean) * rstd * gg.z + bb.z;
+      x.v[j].w = (x.v[j].w - mean) * rstd * gg.w + bb.w;
+    }
+  }
+}
+
+__device__ __forceinline__ void ln_store(const LnRow& x, int H, int lane, bf16_t* __restrict__ xb,
+                                         float* __restrict__ xf) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e0 = 256 * j + 4 * lane;
+    if (e0 < H) {
+      if (xb) {
+        uint2 o;
+        o.x = pack_bf16x2(x.v[j].x, x.v[j].y);
+        o.y = pack_bf16x2(x.v[j].z, x.v[j].w);
+        *(uint2*)(xb + e0) = o;
+      }
+      if (xf) *(float4*)(xf + e0) = x.v[j];
+    }
+  }
+}
+
+// embeddings: LayerNorm(word[id] + pos[p] + type[0]) -> bf16 X
+__global__ void __launch_bounds__(256) k_embed_ln(const int32_t* __restrict__ tok_id,
+                                                  const int32_t* __restrict__ tok_pos, int64_t rows, int H,
+                                                  const float* __restrict__ word, const float* __restrict__ pos,
+                                                  const float* __restrict__ type0, const float* __restrict__ g,
+                                                  const float* __restrict__ b, float eps, bf16_t* __restrict__ X) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int id = tok_id[row];
+  LnRow x;
+  if (id < 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ln_store(x, H, lane, X + row * H, nullptr);
+    return;
+  }
+  const float* w = word + (int64_t)id * H;
+  const float* p = pos + (int64_t)tok_pos[row] * H;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e0 = 256 * j + 4 * lane;
+    if (e0 < H) {
+      const float4 a = *(const float4*)(w + e0), c = *(const float4*)(p + e0), t = *(const float4*)(type0 + e0);
+      x.v[j] = make_float4(a.x + c.x + t.x, a.y + c.y + t.y, a.z + c.z + t.z, a.w + c.w + t.w);
+    }
+  }
+  ln_normalize(x, H, lane, eps, g, b);
+  ln_store(x, H, lane, X + row * H, nullptr);
+}
+
+// rows of fp32 Y -> LayerNorm -> bf16 Xb (and/or fp32 Xf).  `gather` (optional) maps output row -> input row.
+__global__ void __launch_bounds__(256) k_layernorm(const float* __restrict__ Y, int64_t rows, int H,
+                                                   const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                   bf16_t* __restrict__ Xb, float* __restrict__ Xf) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  LnRow x;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e0 = 256 * j + 4 * lane;
+    if (e0 < H) x.v[j] = *(const float4*)(Y + row * H + e0);
+  }
+  ln_normalize(x, H, lane, eps, g, b);
+  ln_store(x, H, lane, Xb ? Xb + row * H : nullptr, Xf ? Xf + row * H : nullptr);
+}
+
+// out[b, :] = in[cu[b], :]  (CLS rows), bf16 and/or fp32
+__global__ void __launch_bounds__(256) k_gather_cls(const int32_t* __restrict__ cu, int B, int H,
+                                                    const bf16_t* __restrict__ Xb, const float* __restrict__ Xf,
+                                                    bf16_t* __restrict__ Ob, float* __restrict__ Of) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int64_t row = cu[b];
+  for (int e0 = 4 * lane; e0 < H; e0 += 256) {
+    if (Ob) *(uint2*)(Ob + (int64_t)b * H + e0) = *(const uint2*)(Xb + row * H + e0);
+    if (Of) *(float4*)(Of + (int64_t)b * H + e0) = *(const float4*)(Xf + row * H + e0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM with fused epilogues.  The engine computes a 128 x 128 tile  acc[r][l] = sum_k Rm[r0+r][k] Lm[l0+l][k]
+// where the "R" operand's index lands on accumulator REGISTERS (4 consecutive r per register quad) and the
+// "L" operand's index on LANES.  Every output below is stored at  out[l * ld + r]  (r contiguous), i.e. 8-byte
+// (bf16) / 16-byte (fp32) pieces per lane, so:
+//    token-major outputs  C[token][feature]:  R = weight rows (features), L = activation rows (tokens)
+//    V^T                  Vt[feature][token]: R = tokens,                 L = features   (roles swapped)
+// ---------------------------------------------------------------------------------------------
+enum { EPI_BF16 = 0, EPI_GELU_BF16 = 1, EPI_RESID_F32 = 2, EPI_QKV = 3, EPI_F32 = 4 };
+
+struct GemmArgs {
+  const bf16_t* W;    // [N, K] weights (features)
+  const bf16_t* X;    // [rows, K] activations (tokens)
+  int64_t rows;       // tokens
+  int N, K;
+  const float* bias;  // [N]
+  bf16_t* Cb;         // EPI_BF16 / EPI_GELU_BF16: [rows, N]
+  float* Cf;          // EPI_RESID_F32 / EPI_F32:  [rows, N]
+  const bf16_t* R;    // EPI_RESID_F32: residual [rows, N]
+  bf16_t *Qo, *Ko, *Vt;  // EPI_QKV (N = 3H): Q [rows, H], K [rows, H], Vt [H, ldt]
+  int H;
+  int64_t ldt;
+  int tilesN, tilesT;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+template <int EPI>
+__global__ void __launch_bounds__(GEMM_THREADS, 2) k_gemm(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // consecutive logical tiles sweep the feature tiles of one token tile: the activation tile stays in L2
+  const uint32_t logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int tt = logical / a.tilesN, tn = logical - tt * a.tilesN;
+  const int64_t t0 = (int64_t)tt * 128;
+  const int n0 = tn * 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1, hi = lane >> 5;
+
+  GemmAcc acc;
+  gemm_acc_zero(acc);
+  bool tokens_on_regs = false;
+  if constexpr (EPI == EPI_QKV) tokens_on_regs = n0 >= 2 * a.H;
+  if (tokens_on_regs)
+    gemm_nt_mainloop(a.X, a.K, a.rows, a.W, a.K, a.N, a.K, t0, n0, smem, acc);
+  else
+    gemm_nt_mainloop(a.W, a.K, a.N, a.X, a.K, a.rows, a.K, n0, t0, smem, acc);
+
+  if (tokens_on_regs) {  // V third of the fused QKV projection -> Vt[feature][token]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int f = n0 + gemm_acc_col(wn, nt, lane);  // feature on the lane
+      if (f >= a.N) continue;
+      const float bv = a.bias[f];
+      bf16_t* dst = a.Vt + (int64_t)(f - 2 * a.H) * a.ldt;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int64_t t = t0 + wm * 64 + mt * 32 + 8 * g + 4 * hi;  // 4 consecutive tokens (rows % 4 == 0)
+          if (t < a.rows) {
+            const f32x16& v = acc.c[mt][nt];
+            uint2 o;
+            o.x = pack_bf16x2(v[4 * g + 0] + bv, v[4 * g + 1] + bv);
+            o.y = pack_bf16x2(v[4 * g + 2] + bv, v[4 * g + 3] + bv);
+            *(uint2*)(dst + t) = o;
+          }
+        }
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int64_t t = t0 + gemm_acc_col(wn, nt, lane);  // token on the lane
+    if (t >= a.rows) continue;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int f = n0 + wm * 64 + mt * 32 + 8 * g + 4 * hi;  // 4 consecutive features (N % 4 == 0)
+        if (f >= a.N) continue;
+        const f32x16& v = acc.c[mt][nt];
+        const float4 bv = *(const float4*)(a.bias + f);
+        float y0 = v[4 * g + 0] + bv.x, y1 = v[4 * g + 1] + bv.y, y2 = v[4 * g + 2] + bv.z, y3 = v[4 * g + 3] + bv.w;
+        if constexpr (EPI == EPI_GELU_BF16) {
+          y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3);
+        }
+        if constexpr (EPI == EPI_RESID_F32) {
+          const uint2 r = *(const uint2*)(a.R + t * a.N + f);
+          y0 += __uint_as_float(r.x << 16); y1 += __uint_as_float(r.x & 0xffff0000u);
+          y2 += __uint_as_float(r.y << 16); y3 += __uint_as_float(r.y & 0xffff0000u);
+        }
+        if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_F32) {
+          *(float4*)(a.Cf + t * a.N + f) = make_float4(y0, y1, y2, y3);
+        } else {
+          uint2 o;
+          o.x = pack_bf16x2(y0, y1);
+          o.y = pack_bf16x2(y2, y3);
+          if constexpr (EPI == EPI_QKV) {
+            bf16_t* dst = f < a.H ? a.Qo + t * a.H + f : a.Ko + t * a.H + (f - a.H);
+            *(uint2*)dst = o;
+          } else {
+            *(uint2*)(a.Cb + t * a.N + f) = o;
+          }
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Self-attention, head_dim 64, varlen (one sequence per blockIdx.z, no padding keys exist).
+// Workgroup = 4 waves = 128 queries of one (sequence, head); K and V^T tiles of 64 keys staged in LDS by
+// LDS-DMA and shared by the 4 waves; each wave owns 32 queries.  Everything per query is LANE-LOCAL:
+//   S^T = K Q^T   (A = K rows, B = Q)  -> lane = query, registers = keys
+//   O^T = V^T P^T (A = V^T rows, B = P straight from the S^T registers) -> lane = query, registers = head dims
+// The K rows feeding MFMA row i are permuted (bits 2 and 3 of i swapped) so that the 8 S^T registers
+// 8s..8s+7 of a lane hold exactly the keys 16 s + 8 (lane >> 5) + 0..7 that MFMA expects as the lane's
+// B-operand k-slots in the P.V step: no cross-lane shuffles, no LDS round trip for P.
+// Online softmax over key tiles; lanes q and q+32 hold the two halves of a query's keys / head dims and
+// exchange only the running max and the final row sum.  Writes LSE (natural log) when lse != nullptr.
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const bf16_t *Q, *K, *Vt;
+  int64_t ldt;
+  const int32_t *cu, *lens;
+  int H;
+  bf16_t* ctx;
+  float* lse;       // [heads, ldt] or nullptr
+  float scale;      // 1 / sqrt(head_dim)
+};
+
+constexpr int ATT_SMEM_BYTES = 2 * 64 * 128;  // K tile + V^T tile, 8 KB each
+
+__global__ void __launch_bounds__(256) k_attention_fwd(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + 64 * 128;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int len = a.lens[b];
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= len) return;
+  const int64_t base = a.cu[b];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  const int q = q0 + wave * 32 + li;
+  const int qc = q < len ? q : len - 1;
+  const int H = a.H;
+
+  bf16x8 qf[4];
+  {
+    const bf16_t* qp = a.Q + (base + qc) * H + h * 64 + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+  }
+  const float c = a.scale * 1.44269504088896341f;  // exp(x * scale) = exp2(x * c)
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+
+  const int sw = (lane >> 1) & 7;
+  const int krow = (li & ~12) | ((li & 4) << 1) | ((li & 8) >> 1);  // bits 2 <-> 3
+  const int ksw = (krow >> 1) & 7;
+
+  for (int kv0 = 0; kv0 < len; kv0 += 64) {
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // 64 rows x 128 B per tile = 2 LDS-DMA rounds of 256 lanes x 16 B
+      const int r0 = (i * 4 + wave) * 8;
+      const int row = r0 + (lane >> 3);
+      const int gch = (lane & 7) ^ ((row >> 1) & 7);
+      glds16((const char*)(a.K + (base + kv0 + row) * H + h * 64) + gch * 16, sK + r0 * 128);
+      glds16((const char*)(a.Vt + (int64_t)(h * 64 + row) * a.ldt + base + kv0) + gch * 16, sV + r0 * 128);
+    }
+    __syncthreads();  // (vmcnt(0) is drained by the compiler before the barrier)
+
+    // ---- S^T = K Q^T for the 64 keys of this tile ----
+    f32x16 st[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+      const char* kp = sK + (kt * 32 + krow) * 128;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *(const bf16x8*)(kp + (((2 * s + hi) ^ ksw) * 16));
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kt], 0, 0, 0);
+      }
+    }
+    // register r of tile kt <-> key kv0 + 32 kt + 16 (r >> 3) + 8 hi + (r & 7)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
+        if (key >= len) st[kt][r] = -INFINITY;
+        mx = fmaxf(mx, st[kt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);               // finite: every tile has >= 1 valid key
+    const float alpha = exp2f((m - mn) * c);     // m = -inf on the first tile -> 0
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f((st[kt][r] - mn) * c);
+        st[kt][r] = p;
+        ps += p;
+      }
+    l = l * alpha + ps;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {  // 16 keys per step
+      const int kt = s4 >> 1, r0 = (s4 & 1) * 8;
+      union { bf16x8 v; uint32_t u[4]; } pb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pb.u[j] = pack_bf16x2(st[kt][r0 + 2 * j], st[kt][r0 + 2 * j + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8 vf = *(const bf16x8*)(sV + (dt * 32 + li) * 128 + (((2 * s4 + hi) ^ sw) * 16));
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb.v, o[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  l += __shfl_xor(l, 32, 64);
+  const int plen = a.cu[b + 1] - (int)base;  // len rounded up to the row alignment
+  if (q < plen) {
+    // alignment rows [len, plen) get zeros: they feed later GEMMs / V^T columns and must stay finite
+    const float inv = q < len ? 1.f / l : 0.f;
+    bf16_t* dst = a.ctx + (base + q) * H + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 ov;
+        ov.x = pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        ov.y = pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *(uint2*)(dst + dt * 32 + 8 * g + 4 * hi) = ov;
+      }
+    if (a.lse && hi == 0) a.lse[(int64_t)h * a.ldt + base + q] = q < len ? m * a.scale + logf(l) : 0.f;
+  }
+}
+
+// fp32 rows -> bf16 rows (weight packing at load / after each optimizer step)
+__global__ void __launch_bounds__(256) k_cast_f32_bf16(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = *(const float4*)(x + 4 * i);
+    uint2 o;
+    o.x = pack_bf16x2(v.x, v.y);
+    o.y = pack_bf16x2(v.z, v.w);
+    *(uint2*)(y + 4 * i) = o;
+  }
+}
+
+}  // namespace convdr

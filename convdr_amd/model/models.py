@@ -1,0 +1,488 @@
+"""Operator surface of the reference's ``model/models.py`` on MI355X.
+
+Same names, same call contract, same parameter (state_dict) names as
+/root/reference/model/models.py, so the reference drivers' call sites
+(`MSMarcoConfigDict[name].model_class.from_pretrained(...)`, `model(ids, mask)`,
+`model(ids, mask, is_query=False)`, `.query_emb`, `.body_emb`, `.named_parameters()`,
+`.save_pretrained`, `.resize_token_embeddings`) work unchanged -- but every forward runs the
+hand-written gfx950 kernels of libconvdr_hip.so (csrc/encoder*.hip) instead of HuggingFace
+``transformers`` modules.  torch.nn here only names and owns the fp32 master parameters.
+
+  EmbeddingMixin            models.py:13-49
+  NLL                       models.py:52-75
+  RobertaDot_NLL_LN         models.py:129-148   RoBERTa -> CLS -> Linear(H,768) -> LayerNorm(768)
+  RobertaDot_NLL_LN_Inference models.py:151-156
+  HFBertEncoder / BiEncoder models.py:191-262   two BERT towers, raw CLS
+  MSMarcoConfig / MSMarcoConfigDict models.py:275-311
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib
+
+
+# --------------------------------------------------------------------------------------------
+# configuration (stand-in for transformers.RobertaConfig / BertConfig: only the fields the path reads)
+# --------------------------------------------------------------------------------------------
+class EncoderConfig:
+    model_type = "roberta"
+    _defaults = dict(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                     intermediate_size=3072, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1,
+                     layer_norm_eps=1e-5, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                     hidden_act="gelu", num_labels=2, finetuning_task=None)
+
+    def __init__(self, **kw):
+        for k, v in self._defaults.items():
+            setattr(self, k, kw.pop(k, v))
+        self.extra = kw
+        if self.hidden_act != "gelu":
+            raise NotImplementedError("only exact-erf gelu is implemented (hidden_act=%r)" % self.hidden_act)
+
+    @classmethod
+    def from_pretrained(cls, path, **kw):
+        kw.pop("cache_dir", None)
+        with open(os.path.join(path, "config.json")) as f:
+            d = json.load(f)
+        d.pop("model_type", None)
+        d.update(kw)
+        return cls(**d)
+
+    def to_dict(self):
+        d = {k: getattr(self, k) for k in self._defaults}
+        d.update(self.extra)
+        d["model_type"] = self.model_type
+        return d
+
+    def save_pretrained(self, path):
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.to_dict(), f, indent=2, sort_keys=True, default=str)
+
+
+class RobertaConfig(EncoderConfig):
+    model_type = "roberta"
+
+
+class BertConfig(EncoderConfig):
+    model_type = "bert"
+    _defaults = dict(EncoderConfig._defaults, vocab_size=30522, max_position_embeddings=512, type_vocab_size=2,
+                     pad_token_id=0, layer_norm_eps=1e-12)
+
+
+class _TokenizerPlaceholder:
+    """The tokenizers stay HuggingFace's (host-side text processing is out of scope);
+    resolved lazily so that importing this module never needs vocab files."""
+
+    def __init__(self, hf_name):
+        self.hf_name = hf_name
+
+    def from_pretrained(self, *a, **kw):
+        import transformers
+        return getattr(transformers, self.hf_name).from_pretrained(*a, **kw)
+
+
+RobertaTokenizer = _TokenizerPlaceholder("RobertaTokenizer")
+BertTokenizer = _TokenizerPlaceholder("BertTokenizer")
+
+
+# --------------------------------------------------------------------------------------------
+# parameter containers with HuggingFace's names
+# --------------------------------------------------------------------------------------------
+class _Embeddings(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
+        self.position_embeddings = nn.Embedding(cfg.max_position_embeddings, cfg.hidden_size)
+        self.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, cfg.hidden_size)
+        self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        H = cfg.hidden_size
+        self.query, self.key, self.value = nn.Linear(H, H), nn.Linear(H, H), nn.Linear(H, H)
+
+
+class _DenseLN(nn.Module):
+    def __init__(self, n_in, n_out, eps):
+        super().__init__()
+        self.dense = nn.Linear(n_in, n_out)
+        self.LayerNorm = nn.LayerNorm(n_out, eps=eps)
+
+
+class _Dense(nn.Module):
+    def __init__(self, n_in, n_out):
+        super().__init__()
+        self.dense = nn.Linear(n_in, n_out)
+
+
+class _Attention(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.self = _SelfAttention(cfg)
+        self.output = _DenseLN(cfg.hidden_size, cfg.hidden_size, cfg.layer_norm_eps)
+
+
+class _Layer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.attention = _Attention(cfg)
+        self.intermediate = _Dense(cfg.hidden_size, cfg.intermediate_size)
+        self.output = _DenseLN(cfg.intermediate_size, cfg.hidden_size, cfg.layer_norm_eps)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer = nn.ModuleList([_Layer(cfg) for _ in range(cfg.num_hidden_layers)])
+
+
+class EncoderTower(nn.Module):
+    """Parameters of one BERT/RoBERTa tower under HF's names (embeddings.*, encoder.layer.N.*, pooler.dense.*)
+    plus the packed bf16 device copies the kernels read."""
+
+    def __init__(self, cfg, kind, out_dim=0):
+        super().__init__()
+        self.config = cfg
+        self.kind = kind  # "roberta" | "bert"
+        self.embeddings = _Embeddings(cfg)
+        self.encoder = _Encoder(cfg)
+        self.pooler = _Dense(cfg.hidden_size, cfg.hidden_size)  # present in transformers==2.3.0 checkpoints; unused
+        self._packed = None
+        self._packed_key = None
+        self._ws = None
+
+    # ---- packed weights ---------------------------------------------------------------------
+    def _version_key(self, extra):
+        ps = list(self.parameters()) + list(extra)
+        return tuple((p.data_ptr(), p._version) for p in ps)
+
+    @staticmethod
+    def _bf16(t):
+        t = t.detach().float().contiguous()
+        out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+        _lib.check(_lib.lib().convdr_cast_f32_bf16(_lib.ptr(t), _lib.ptr(out), t.numel(), _lib.stream_ptr()),
+                   "convdr_cast_f32_bf16")
+        return out
+
+    def packed(self, head=None):
+        """(cfg struct, weights struct, keepalive) for the C ABI; rebuilt when any parameter changed."""
+        extra = [] if head is None else [head[0].weight, head[0].bias, head[1].weight, head[1].bias]
+        key = self._version_key(extra)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        cfg = self.config
+        dev = self.embeddings.word_embeddings.weight.device
+        if dev.type != "cuda":
+            raise _lib.ConvdrError("the encoder runs on the GPU only (parameters are on %s); call .to('cuda')" % dev)
+        keep = []
+
+        def f32(t):
+            t = t.detach().float().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def b16(t):
+            o = self._bf16(t)
+            keep.append(o)
+            return o.data_ptr()
+
+        with torch.cuda.device(dev):
+            layers = (_lib.LayerWeights * cfg.num_hidden_layers)()
+            for i, ly in enumerate(self.encoder.layer):
+                s = ly.attention.self
+                lw = layers[i]
+                lw.wqkv = b16(torch.cat([s.query.weight, s.key.weight, s.value.weight], 0))
+                lw.bqkv = f32(torch.cat([s.query.bias, s.key.bias, s.value.bias], 0))
+                lw.wo, lw.bo = b16(ly.attention.output.dense.weight), f32(ly.attention.output.dense.bias)
+                lw.ln1_g, lw.ln1_b = f32(ly.attention.output.LayerNorm.weight), f32(ly.attention.output.LayerNorm.bias)
+                lw.w1, lw.b1 = b16(ly.intermediate.dense.weight), f32(ly.intermediate.dense.bias)
+                lw.w2, lw.b2 = b16(ly.output.dense.weight), f32(ly.output.dense.bias)
+                lw.ln2_g, lw.ln2_b = f32(ly.output.LayerNorm.weight), f32(ly.output.LayerNorm.bias)
+            w = _lib.EncoderWeights()
+            e = self.embeddings
+            w.word_emb, w.pos_emb = f32(e.word_embeddings.weight), f32(e.position_embeddings.weight)
+            w.type_emb = f32(e.token_type_embeddings.weight)
+            w.emb_ln_g, w.emb_ln_b = f32(e.LayerNorm.weight), f32(e.LayerNorm.bias)
+            w.layers = C.cast(layers, C.POINTER(_lib.LayerWeights))
+            out_dim, head_eps = 0, 1e-5
+            if head is not None:
+                lin, ln = head
+                w.head_w, w.head_b = b16(lin.weight), f32(lin.bias)
+                w.head_ln_g, w.head_ln_b = f32(ln.weight), f32(ln.bias)
+                out_dim, head_eps = lin.out_features, ln.eps
+        c = _lib.EncoderConfig(kind=0 if self.kind == "roberta" else 1, hidden=cfg.hidden_size,
+                               heads=cfg.num_attention_heads, layers=cfg.num_hidden_layers,
+                               intermediate=cfg.intermediate_size, vocab=e.word_embeddings.num_embeddings,
+                               max_pos=cfg.max_position_embeddings, pad_idx=cfg.pad_token_id if self.kind == "roberta" else 0,
+                               out_dim=out_dim, ln_eps=cfg.layer_norm_eps, head_ln_eps=head_eps)
+        keep.append(layers)
+        self._packed, self._packed_key = (c, w, keep), key
+        return self._packed
+
+    # ---- forward ------------------------------------------------------------------------------
+    def embed(self, input_ids, attention_mask, head=None, seq_lens=None):
+        """-> fp32 [B, out_dim or H] embeddings (CLS pooling, models.py:43)."""
+        L_ = _lib.lib()
+        if input_ids.device.type != "cuda":
+            raise _lib.ConvdrError("encoder inputs must be CUDA tensors (no CPU fallback)")
+        ids = input_ids.long().contiguous()
+        mask = attention_mask.long().contiguous()
+        B, L = ids.shape
+        dev = ids.device
+        if seq_lens is None:
+            seq_lens = mask.sum(1).to(torch.int32)
+            lens_host = seq_lens.cpu().numpy()          # one small D2H sync per batch
+            if not bool(mask[:, 0].all()):
+                raise ValueError("attention_mask[:, 0] must be 1 (CLS position); the reference right-pads")
+        else:
+            lens_host = np.asarray(seq_lens, np.int32)
+            seq_lens = torch.as_tensor(lens_host, device=dev)
+        if lens_host.min() < 1:
+            raise ValueError("every sequence needs at least one unmasked token")
+        cu_host = np.zeros(B + 1, np.int32)
+        np.cumsum((lens_host + 7) // 8 * 8, out=cu_host[1:])
+        rows, max_len = int(cu_host[-1]), int(lens_host.max())
+        cu = torch.as_tensor(cu_host, device=dev)
+        with torch.cuda.device(dev):
+            c, w, _keep = self.packed(head)
+            out = torch.empty((B, c.out_dim or c.hidden), dtype=torch.float32, device=dev)
+            need = L_.convdr_encoder_workspace_bytes(C.byref(c), rows, B)
+            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                self._ws = torch.empty(int(need * 1.25), dtype=torch.uint8, device=dev)
+            _lib.check(L_.convdr_encoder_forward(C.byref(c), C.byref(w), _lib.ptr(ids), _lib.ptr(mask), B, L,
+                                                 _lib.ptr(cu), _lib.ptr(seq_lens), rows, max_len, _lib.ptr(self._ws),
+                                                 self._ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
+                       "convdr_encoder_forward")
+        return out
+
+
+# --------------------------------------------------------------------------------------------
+# checkpoint I/O shared by the model classes (HF directory layout: config.json + pytorch_model.bin)
+# --------------------------------------------------------------------------------------------
+def _load_state_dict_file(path):
+    st = os.path.join(path, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        return load_file(st)
+    return torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
+
+
+class _PretrainedMixin:
+    @classmethod
+    def from_pretrained(cls, path, config=None, from_tf=False, cache_dir=None, **kw):
+        if from_tf:
+            raise NotImplementedError("TensorFlow checkpoints are not supported")
+        if config is None:
+            config = cls.config_class.from_pretrained(path)
+        model = cls(config, **kw)
+        sd = _load_state_dict_file(path)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        real_missing = [k for k in missing if "pooler" not in k and not k.startswith("classifier")]
+        if real_missing:
+            raise KeyError("checkpoint %s lacks parameters: %s" % (path, real_missing[:8]))
+        return model
+
+    def save_pretrained(self, path):
+        os.makedirs(path, exist_ok=True)
+        self.config.save_pretrained(path)
+        torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()}, os.path.join(path, "pytorch_model.bin"))
+
+
+# --------------------------------------------------------------------------------------------
+# the reference's classes
+# --------------------------------------------------------------------------------------------
+class EmbeddingMixin:
+    """models.py:13-49."""
+
+    def __init__(self, model_argobj):
+        if model_argobj is None:
+            self.use_mean = False
+        else:
+            self.use_mean = model_argobj.use_mean
+        print("Using mean:", self.use_mean)
+
+    def _init_weights(self, module):
+        if isinstance(module, (nn.Linear, nn.Embedding, nn.Conv1d)):
+            module.weight.data.normal_(mean=0.0, std=0.02)
+
+    def masked_mean(self, t, mask):
+        s = torch.sum(t * mask.unsqueeze(-1).float(), axis=1)
+        d = mask.sum(axis=1, keepdim=True).float()
+        return s / d
+
+    def masked_mean_or_first(self, emb_all, mask):
+        assert isinstance(emb_all, tuple)
+        if self.use_mean:
+            return self.masked_mean(emb_all[0], mask)
+        return emb_all[0][:, 0]
+
+    def query_emb(self, input_ids, attention_mask):
+        raise NotImplementedError("Please Implement this method")
+
+    def body_emb(self, input_ids, attention_mask):
+        raise NotImplementedError("Please Implement this method")
+
+
+def _pairwise_nll(q_embs, a_embs, b_embs):
+    logit_matrix = torch.cat([(q_embs * a_embs).sum(-1).unsqueeze(1), (q_embs * b_embs).sum(-1).unsqueeze(1)], dim=1)
+    lsm = torch.nn.functional.log_softmax(logit_matrix, dim=1)
+    return (-1.0 * lsm[:, 0]).mean()
+
+
+class NLL(EmbeddingMixin):
+    """models.py:52-75."""
+
+    def forward(self, query_ids, attention_mask_q, input_ids_a=None, attention_mask_a=None, input_ids_b=None,
+                attention_mask_b=None, is_query=True):
+        if input_ids_b is None and is_query:
+            return self.query_emb(query_ids, attention_mask_q)
+        elif input_ids_b is None:
+            return self.body_emb(query_ids, attention_mask_q)
+        q_embs = self.query_emb(query_ids, attention_mask_q)
+        a_embs = self.body_emb(input_ids_a, attention_mask_a)
+        b_embs = self.body_emb(input_ids_b, attention_mask_b)
+        return (_pairwise_nll(q_embs, a_embs, b_embs), )
+
+
+class _Classifier(nn.Module):
+    """RobertaForSequenceClassification's head: present in checkpoints, never used on this path
+    (hence find_unused_parameters=True at gen_passage_embeddings.py:68)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.out_proj = nn.Linear(cfg.hidden_size, cfg.num_labels)
+
+
+class RobertaDot_NLL_LN(NLL, _PretrainedMixin, nn.Module):
+    """models.py:129-148: RoBERTa -> CLS -> embeddingHead Linear(H, 768) -> norm LayerNorm(768)."""
+    config_class = RobertaConfig
+
+    def __init__(self, config, model_argobj=None):
+        nn.Module.__init__(self)
+        NLL.__init__(self, model_argobj)
+        self.config = config
+        self.roberta = EncoderTower(config, "roberta")
+        self.classifier = _Classifier(config)
+        self.embeddingHead = nn.Linear(config.hidden_size, 768)
+        self.norm = nn.LayerNorm(768)
+        self.apply(self._init_weights)
+
+    def query_emb(self, input_ids, attention_mask):
+        if self.use_mean:
+            raise NotImplementedError("use_mean=True is not registered by any reference config (models.py:295-307)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from ..train import encoder_autograd
+            return encoder_autograd(self, self.roberta, (self.embeddingHead, self.norm), input_ids, attention_mask)
+        return self.roberta.embed(input_ids, attention_mask, head=(self.embeddingHead, self.norm))
+
+    def body_emb(self, input_ids, attention_mask):
+        return self.query_emb(input_ids, attention_mask)
+
+    def resize_token_embeddings(self, new_num_tokens):
+        """run_convdr_train.py:474: grow the word-embedding table, new rows N(0, 0.02) like HF's _init_weights."""
+        old = self.roberta.embeddings.word_embeddings
+        if new_num_tokens is None or new_num_tokens == old.num_embeddings:
+            return old
+        new = nn.Embedding(new_num_tokens, old.embedding_dim).to(old.weight.device)
+        new.weight.data.normal_(mean=0.0, std=0.02)
+        n = min(old.num_embeddings, new_num_tokens)
+        new.weight.data[:n] = old.weight.data[:n]
+        self.roberta.embeddings.word_embeddings = new
+        self.config.vocab_size = new_num_tokens
+        return new
+
+
+class RobertaDot_NLL_LN_Inference(RobertaDot_NLL_LN):
+    """models.py:151-156."""
+
+    def forward(self, input_ids, attention_mask):
+        return self.query_emb(input_ids, attention_mask)
+
+
+class HFBertEncoder(EncoderTower):
+    """models.py:191-216: a BERT tower whose forward returns (sequence_output, pooled = CLS, None).
+    Only the CLS row is materialised on this path (nothing in the reference reads the rest)."""
+
+    def __init__(self, config):
+        super().__init__(config, "bert")
+        assert config.hidden_size > 0, "Encoder hidden_size can't be zero"
+
+    @classmethod
+    def init_encoder(cls, args, dropout: float = 0.1):
+        cfg = getattr(args, "bert_config", None) or BertConfig()
+        if dropout != 0:
+            cfg.attention_probs_dropout_prob = dropout
+            cfg.hidden_dropout_prob = dropout
+        enc = cls(cfg)
+        path = getattr(args, "bert_path", None)     # the reference downloads "bert-base-uncased"; no network here
+        if path:
+            enc.load_state_dict({k[5:] if k.startswith("bert.") else k: v
+                                 for k, v in _load_state_dict_file(path).items()}, strict=False)
+        return enc
+
+    def forward(self, input_ids, attention_mask):
+        pooled = self.embed(input_ids, attention_mask)
+        return None, pooled, None
+
+    def get_out_size(self):
+        return self.config.hidden_size
+
+
+class BiEncoder(nn.Module):
+    """models.py:219-262."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.question_model = HFBertEncoder.init_encoder(args)
+        self.ctx_model = HFBertEncoder.init_encoder(args)
+
+    def query_emb(self, input_ids, attention_mask):
+        return self.question_model(input_ids, attention_mask)[1]
+
+    def body_emb(self, input_ids, attention_mask):
+        return self.ctx_model(input_ids, attention_mask)[1]
+
+    def forward(self, query_ids, attention_mask_q, input_ids_a=None, attention_mask_a=None, input_ids_b=None,
+                attention_mask_b=None, is_query=True):
+        if input_ids_b is None:
+            if input_ids_a is None:
+                return self.query_emb(query_ids, attention_mask_q) if is_query else self.body_emb(
+                    query_ids, attention_mask_q)
+            return (self.query_emb(query_ids, attention_mask_q), self.body_emb(input_ids_a, attention_mask_a))
+        q_embs = self.query_emb(query_ids, attention_mask_q)
+        a_embs = self.body_emb(input_ids_a, attention_mask_a)
+        b_embs = self.body_emb(input_ids_b, attention_mask_b)
+        return (_pairwise_nll(q_embs, a_embs, b_embs), )
+
+
+# --------------------------------------------------------------------------------------------
+ALL_MODELS = ()
+default_process_fn = None   # data/process_fn.py is dead code on this path
+
+
+class MSMarcoConfig:
+    """models.py:275-288."""
+
+    def __init__(self, name, model, process_fn=default_process_fn, use_mean=True, tokenizer_class=RobertaTokenizer,
+                 config_class=RobertaConfig):
+        self.name = name
+        self.process_fn = process_fn
+        self.model_class = model
+        self.use_mean = use_mean
+        self.tokenizer_class = tokenizer_class
+        self.config_class = config_class
+
+
+configs = [
+    MSMarcoConfig(name="rdot_nll", model=RobertaDot_NLL_LN, use_mean=False),
+    MSMarcoConfig(name="dpr", model=BiEncoder, tokenizer_class=BertTokenizer, config_class=BertConfig, use_mean=False),
+]
+
+MSMarcoConfigDict = {cfg.name: cfg for cfg in configs}

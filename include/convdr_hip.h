@@ -80,6 +80,56 @@ int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, const void*
 const uint32_t* convdr_ip_debug_counts(const void* workspace, int nq, int64_t n, int d, int k, int cap);
 const uint32_t* convdr_ip_debug_band(const void* workspace, int nq, int64_t n, int d, int k, int cap);
 
+/* ------------------------------------------------------------------------------------------
+ * Dual-encoder forward: replaces the HuggingFace RobertaModel / BertModel forward + pooling + head
+ * behind  /root/reference/model/models.py:140-148 (RobertaDot_NLL_LN.query_emb / body_emb) and
+ * :205-211, :227-235 (HFBertEncoder.forward, BiEncoder.query_emb / body_emb).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t kind;        /* 0 = RoBERTa position ids (cumsum(ids != pad_idx) * (ids != pad_idx) + pad_idx), 1 = BERT (0..L-1) */
+  int32_t hidden, heads, layers, intermediate;   /* head_dim = hidden / heads must be 64 */
+  int32_t vocab, max_pos, pad_idx;
+  int32_t out_dim;     /* 768 for rdot_nll (embeddingHead + norm, models.py:136-137); 0 = raw CLS (dpr, models.py:210) */
+  float ln_eps;        /* encoder LayerNorms (1e-5 RoBERTa, 1e-12 BERT) */
+  float head_ln_eps;   /* nn.LayerNorm(768) default 1e-5 */
+} convdr_encoder_config;
+
+typedef struct {       /* device pointers; w* are bf16 [out, in] row-major (nn.Linear layout), the rest fp32 */
+  const void* wqkv;    /* [3H, H] = rows of attention.self.{query,key,value}.weight stacked */
+  const float* bqkv;   /* [3H] */
+  const void* wo;      /* attention.output.dense.weight [H, H] */
+  const float* bo;
+  const float *ln1_g, *ln1_b; /* attention.output.LayerNorm */
+  const void* w1;      /* intermediate.dense.weight [I, H] */
+  const float* b1;
+  const void* w2;      /* output.dense.weight [H, I] */
+  const float* b2;
+  const float *ln2_g, *ln2_b; /* output.LayerNorm */
+} convdr_layer_weights;
+
+typedef struct {
+  const float *word_emb, *pos_emb, *type_emb; /* fp32 [vocab, H], [max_pos, H], [>=1, H] (row 0 used) */
+  const float *emb_ln_g, *emb_ln_b;
+  const convdr_layer_weights* layers;         /* HOST array of `layers` entries */
+  const void* head_w;                         /* bf16 [out_dim, H] (out_dim > 0) */
+  const float *head_b, *head_ln_g, *head_ln_b;
+} convdr_encoder_weights;
+
+/* fp32 -> bf16 (round to nearest even); n % 4 == 0.  Used to pack weights at load time / after an optimizer step. */
+int convdr_cast_f32_bf16(const float* x, void* y, int64_t n, convdr_stream_t stream);
+
+size_t convdr_encoder_workspace_bytes(const convdr_encoder_config* cfg, int64_t rows, int B);
+
+/* out[b, :] = embedding of sequence b.  input_ids / attention_mask: device int64 [B, L] exactly as the reference
+ * drivers pass them (gen_passage_embeddings.py:105-112).  Only mask == 1 tokens are computed ("packed rows"):
+ * cu_seqlens (device int32 [B+1]) gives each sequence's first row, multiples of 8, cu[B] == rows;
+ * seq_lens (device int32 [B]) = mask.sum(1) >= 1; mask[b, 0] must be 1 (the CLS position).  max_len = max(seq_lens).
+ * out: device fp32 [B, out_dim or hidden]. */
+int convdr_encoder_forward(const convdr_encoder_config* cfg, const convdr_encoder_weights* w,
+                           const int64_t* input_ids, const int64_t* attention_mask, int B, int L,
+                           const int32_t* cu_seqlens, const int32_t* seq_lens, int64_t rows, int max_len,
+                           void* workspace, size_t workspace_bytes, float* out, convdr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,8 +99,8 @@ def HFAdamW230():
 
 
 # ----------------------------------------------------------------------------
-TINY = dict(vocab_size=200, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
-            intermediate_size=128, max_position_embeddings=514)
+TINY = dict(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+            intermediate_size=256, max_position_embeddings=514)
 
 
 def tiny_roberta_config(dropout=0.0):

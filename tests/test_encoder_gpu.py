@@ -1,0 +1,103 @@
+"""Parity of the HIP dual-encoder forward (through the C ABI / the model.models surface) with the
+reference-run fixtures and with the fp32 CPU oracle.  Tolerance: the north star's "embedding cosine
+within 1e-3 of fp32" (bf16 MFMA operands, fp32 accumulate / LayerNorm / softmax statistics)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder as OE
+from tests.helpers import cosine
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-3
+
+
+def _sd(z):
+    return {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}
+
+
+def _tiny_rdot(z):
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    cfg = json.loads(str(z["config"]))
+    model = MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig(**cfg))
+    missing, unexpected = model.load_state_dict(_sd(z), strict=False)
+    assert not unexpected and all("pooler" in k for k in missing), (missing, unexpected)
+    return model.cuda().eval()
+
+
+def _check(emb, ref, what):
+    emb = emb.detach().cpu().numpy()
+    cs = cosine(emb, ref)
+    assert cs.min() > 1 - COS_TOL, "%s: cosine %s" % (what, cs)
+    assert np.abs(emb - ref).max() < 0.08, "%s: max abs err %g" % (what, np.abs(emb - ref).max())
+
+
+def test_rdot_nll_matches_reference_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "encoder_rdot_nll.npz"))
+    model = _tiny_rdot(z)
+    with torch.no_grad():
+        for case in ("L16", "L64", "L510"):
+            ids, mask = torch.from_numpy(z[case + "/ids"]).cuda(), torch.from_numpy(z[case + "/mask"]).cuda()
+            _check(model(ids, mask), z[case + "/emb"], case + " query_emb")
+            _check(model(ids, mask, is_query=False), z[case + "/emb"], case + " body_emb")
+            _check(model.body_emb(ids, mask), z[case + "/emb"], case)
+        t = lambda k: torch.from_numpy(z["triple/" + k]).cuda()
+        loss = model(t("ids_q"), t("m_q"), t("ids_a"), t("m_a"), t("ids_b"), t("m_b"))[0].item()
+    assert abs(loss - float(z["triple/loss"])) < 2e-2 * max(1.0, abs(float(z["triple/loss"])))
+
+
+def test_dpr_matches_reference_fixture(golden_dir):
+    from convdr_amd.model.models import MSMarcoConfigDict, BertConfig
+    z = np.load(os.path.join(golden_dir, "encoder_dpr.npz"))
+    cfg = json.loads(str(z["config"]))
+    args = type("A", (), {"bert_config": BertConfig(**cfg)})()
+    model = MSMarcoConfigDict["dpr"].model_class(args)
+    missing, unexpected = model.load_state_dict(_sd(z), strict=False)
+    assert not unexpected, unexpected
+    model = model.cuda().eval()
+    ids, mask = torch.from_numpy(z["ids"]).cuda(), torch.from_numpy(z["mask"]).cuda()
+    with torch.no_grad():
+        _check(model(ids, mask), z["q_emb"], "dpr query")
+        _check(model(ids, mask, is_query=False), z["b_emb"], "dpr body")
+        q, a = model(ids, mask, ids, mask)
+        _check(a, z["b_emb"], "dpr pair")
+
+
+def test_roberta_base_shape_matches_oracle():
+    """Full-size architecture (12 x 768, 12 heads, I = 3072), random N(0, 0.02) weights (models.py:25-30),
+    ragged right-padded batch stored at L = 128."""
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    torch.manual_seed(0)
+    model = MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig())
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.02)
+            elif "LayerNorm.weight" in n or n == "norm.weight":
+                p.add_(torch.randn_like(p) * 0.05)
+    rs = np.random.RandomState(0)
+    B, L = 12, 128
+    lens = [128, 100, 65, 64, 63, 33, 32, 31, 17, 8, 2, 1]
+    ids = rs.randint(3, 50000, size=(B, L)).astype(np.int64)
+    ids[:, 0] = 0
+    mask = np.zeros((B, L), np.int64)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+        ids[b, n:] = 0
+    ids[1, 7] = 1  # RoBERTa's pad id inside a sequence: position id stays 1 and does not advance the count
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = OE.rdot_nll_emb(sd, torch.from_numpy(ids), torch.from_numpy(mask), num_layers=12, num_heads=12).numpy()
+    model = model.cuda().eval()
+    with torch.no_grad():
+        emb = model.body_emb(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda())
+    _check(emb, ref, "roberta-base shape")
+    # a second call with other shapes reuses/extends the workspace
+    with torch.no_grad():
+        emb2 = model.body_emb(torch.from_numpy(ids[:5, :70]).cuda(), torch.from_numpy(np.minimum(mask[:5, :70], 1)).cuda())
+    ref2 = OE.rdot_nll_emb(sd, torch.from_numpy(ids[:5, :70]), torch.from_numpy(mask[:5, :70]), num_layers=12,
+                           num_heads=12).numpy()
+    _check(emb2, ref2, "second call")

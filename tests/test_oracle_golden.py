@@ -27,7 +27,7 @@ def test_rdot_nll_embeddings_match_reference(golden_dir):
         np.testing.assert_allclose(emb, z[case + "/emb"], atol=2e-5, rtol=0)
         assert cosine(emb, z[case + "/emb"]).min() > 1 - 1e-6
     hs = OE.encoder_hidden(sd, "roberta.", torch.from_numpy(z["L16/ids"]), torch.from_numpy(z["L16/mask"]),
-                           kind="roberta", num_layers=2, num_heads=4, eps=1e-5, return_all=True)
+                           kind="roberta", num_layers=2, num_heads=2, eps=1e-5, return_all=True)
     ref = z["L16/hidden_states"]
     m = z["L16/mask"].astype(bool)
     for l in range(3):  # padded query rows are don't-care (mask constant differs: -1e4 vs dtype-min)
@@ -38,7 +38,7 @@ def test_rdot_nll_triple_loss_matches_reference(golden_dir):
     z = np.load(os.path.join(golden_dir, "encoder_rdot_nll.npz"))
     sd = _sd(z)
     e = lambda i, m: OE.rdot_nll_emb(sd, torch.from_numpy(z["triple/" + i]), torch.from_numpy(z["triple/" + m]),
-                                     num_layers=2, num_heads=4)
+                                     num_layers=2, num_heads=2)
     loss = OE.pairwise_nll(e("ids_q", "m_q"), e("ids_a", "m_a"), e("ids_b", "m_b"))
     assert abs(loss.item() - float(z["triple/loss"])) < 1e-4 * max(1, abs(float(z["triple/loss"])))
 
@@ -47,8 +47,8 @@ def test_dpr_embeddings_match_reference(golden_dir):
     z = np.load(os.path.join(golden_dir, "encoder_dpr.npz"))
     sd = _sd(z)
     ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
-    q = OE.dpr_emb(sd, ids, mask, tower="question_model", num_layers=2, num_heads=4)
-    b = OE.dpr_emb(sd, ids, mask, tower="ctx_model", num_layers=2, num_heads=4)
+    q = OE.dpr_emb(sd, ids, mask, tower="question_model", num_layers=2, num_heads=2)
+    b = OE.dpr_emb(sd, ids, mask, tower="ctx_model", num_layers=2, num_heads=2)
     np.testing.assert_allclose(q.numpy(), z["q_emb"], atol=2e-5, rtol=0)
     np.testing.assert_allclose(b.numpy(), z["b_emb"], atol=2e-5, rtol=0)
     loss = OE.pairwise_nll(q, b, torch.flip(b, [0]))
