@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- ConvDR hot path on MI355X.  One JSON line on rank 0 (see the driver contract).
 
-Workload (BASELINE.json configs[1]): 1M synthetic passages x 768-d, 1k queries, brute-force
-inner-product top-100; per step the engine (i) encodes a batch of synthetic 128-token passages
-into embeddings (when the encoder kernels are built) and (ii) runs the full 1k x 1M exact top-100
-search over the resident block.  With N > 1 every rank owns its own 1M-passage shard (weak scaling;
-the corpus partitions by block = rank) and the query set is replicated, so there is
-no data-path collective inside the timed region except the barrier.
+Workload = BASELINE.json configs[1]: "1 MI355X: 1M synthetic passages x 768-d encode + 1k-query brute-force IP
+top-100, bf16 MFMA".  One step = one pass of the hot path over one batch:
+  (i)   encode a batch of synthetic 128-token passages with the roberta-base-shaped rdot_nll encoder
+        (random N(0, 0.02) weights, models.py:25-30) -> fp32 [batch, 768] embeddings,
+  (ii)  append them to the block under construction (fp32 rows + bf16 scan copy + norm),
+  (iii) run the exact 1k-query x 1M-passage inner-product top-100 search over the resident block.
+`value` = passages encoded per second of whole-step time (search and fold included); the search rate is
+reported beside it.  With N > 1 every rank owns a model replica and its own 1M-passage shard (weak scaling: the
+corpus and the passage stream partition by rank); no collective inside the timed region.
 """
 import argparse
 import json
@@ -17,33 +20,64 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA
+H, I, LAYERS, HEADS, D_OUT = 768, 3072, 12, 12, 768
+LINEAR_FLOP_PER_TOKEN = LAYERS * 2 * (4 * H * H + 2 * H * I)   # 169,869,312
 
 
-def cpu_baseline_ip(nq, d, k, seconds_budget=20.0):
-    """FAISS-CPU IndexFlatIP restated (SGEMM + per-query partial sort), timed on the host cores on a
-    bounded sample of the same workload: all nq queries against as many passages as fit the budget."""
-    import numpy as np
+def flop_per_passage(L):
+    return LINEAR_FLOP_PER_TOKEN * L + 36864 * L * L + 2 * H * D_OUT
+
+
+def random_rdot_model(seed=0):
     import torch
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    torch.manual_seed(seed)
+    return MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig())
+
+
+def synthetic_tokens(n, L, seed, device):
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+    ids = torch.randint(3, 50000, (n, L), generator=g, device=device, dtype=torch.int32)
+    ids[:, 0] = 0
+    return ids
+
+
+def cpu_baseline(nq, d, k, L, budget_s=12.0):
+    """The reference's CPU path restated and timed on the host cores (bounded samples of the same workload):
+    encode = the fp32 oracle forward (HF-free restatement of RobertaDot_NLL_LN.body_emb), search = exact fp32
+    Q @ P.T + top-k (what FAISS-CPU IndexFlatIP computes; FAISS is not installed anywhere)."""
+    import torch
+    from oracle import encoder as OE
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    model = random_rdot_model()
+    sd = {k_: v.detach() for k_, v in model.state_dict().items()}
+    B = 16
+    ids = synthetic_tokens(B, L, 0, "cpu").long()
+    mask = torch.ones_like(ids)
+    with torch.no_grad():
+        OE.rdot_nll_emb(sd, ids[:2], mask[:2], num_layers=LAYERS, num_heads=HEADS)
+        t0, reps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s and reps < 20:
+            OE.rdot_nll_emb(sd, ids, mask, num_layers=LAYERS, num_heads=HEADS)
+            reps += 1
+        enc_rate = B * reps / (time.perf_counter() - t0)
     n = 50_000
     g = torch.Generator().manual_seed(0)
-    P = torch.randn(n, d, generator=g)
-    Q = torch.randn(nq, d, generator=g)
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        S = Q @ P.T
-        torch.topk(S, k, dim=1)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or reps >= 40:
-            break
-    return {"value": nq * n * reps / el, "unit": "query x passage pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d queries x %d passages x %d reps, torch fp32 SGEMM + topk(%d) (FAISS-CPU IndexFlatIP restated; "
-                      "FAISS itself is not installed)" % (nq, n, reps, k)}
+    P, Q = torch.randn(n, d, generator=g), torch.randn(nq, d, generator=g)
+    t0, r2 = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s and r2 < 40:
+        torch.topk(Q @ P.T, k, dim=1)
+        r2 += 1
+    ip_rate = nq * n * r2 / (time.perf_counter() - t0)
+    return {"value": enc_rate, "unit": "passages/s", "cores": cores, "threads": threads, "kind": "port",
+            "ip_pairs_per_s": ip_rate,
+            "sample": "encode: %d x %d-token passages x %d reps, fp32 torch oracle of RobertaDot_NLL_LN (12 x 768); "
+                      "search: %d queries x %d passages x %d reps, fp32 SGEMM + topk(%d)" % (B, L, reps, nq, n, r2, k)}
 
 
 def main():
@@ -54,87 +88,125 @@ def main():
     ap.add_argument("--passages", type=int, default=1_000_000)
     ap.add_argument("--queries", type=int, default=1000)
     ap.add_argument("--topk", type=int, default=100)
+    ap.add_argument("--enc-batch", type=int, default=2048)
+    ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=dev)
     from convdr_amd import _lib
     from convdr_amd.search import FlatIPIndex
-    L = _lib.lib()
+    L_ = _lib.lib()
 
-    n, nq, k, d = args.passages, args.queries, args.topk, 768
-    g = torch.Generator(device="cuda").manual_seed(rank)
-    P = torch.randn(n, d, device="cuda", generator=g)
-    Q = torch.randn(nq, d, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1234))
-    index = FlatIPIndex(d)
+    n, nq, k, d, EB, SL = args.passages, args.queries, args.topk, D_OUT, args.enc_batch, args.seq_len
+    model = random_rdot_model().to(dev).eval()
+    tower, head = model.roberta, (model.embeddingHead, model.norm)
+    pool = [synthetic_tokens(EB, SL, 100 * rank + i, dev) for i in range(4)]
+    lens = np.full(EB, SL, np.int32)
+
+    g = torch.Generator(device=dev).manual_seed(rank)
+    P = torch.randn(n, d, device=dev, generator=g)
+    Q = torch.randn(nq, d, device=dev, generator=torch.Generator(device=dev).manual_seed(1234))
+    index = FlatIPIndex(d, device=dev)
     index.add(P)
     del P
+    # freshly encoded embeddings go to the block under construction (searched once complete, like the reference's
+    # encode-all-then-search flow); a ring of 32 batches stands in for it
+    slots = 32
+    building = FlatIPIndex(d, device=dev)
+    building.add(torch.zeros(slots * EB, d, device=dev))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
 
-    def step():
-        return index.search_device(Q, k)
+    def step(i, timers=None):
+        with torch.no_grad():
+            if timers:
+                timers[0].record()
+            emb = tower.embed(pool[i % len(pool)], None, head=head, seq_lens=lens)
+            if timers:
+                timers[1].record()
+            building.update_rows((i % slots) * EB, emb)
+            out = index.search_device(Q, k)
+            if timers:
+                timers[2].record()
+        return out
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
+    for i in range(args.warmup):
+        out = step(i)
     sync_all()
-    if int(out[2].abs().sum().item()) != 0:
-        print("warning: %d uncertified queries in warmup" % int((out[2] != 0).sum().item()), file=sys.stderr)
-    L.convdr_prof_enable(1)
+    L_.convdr_prof_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    for i in range(args.steps):
+        out = step(i, ev[i])
     sync_all()
     el = time.perf_counter() - t0
     status_bad = int((out[2] != 0).sum().item())
     emitted, band = (t.float().mean().item() for t in index.last_counts(nq, k))
-    scan_ms, scan_n = _lib.prof_collect("ip_scan_emit")
-    samp_ms, _ = _lib.prof_collect("ip_scan_sample")
-    resc_ms, _ = _lib.prof_collect("ip_rescore")
-    L.convdr_prof_enable(0)
+    enc_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / args.steps
+    ip_ms = sum(b.elapsed_time(c) for _, b, c in ev) / args.steps
+    spans = {}
+    for name in ("gemm_qkv", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2", "attention", "layernorm", "embed_ln", "gemm_head",
+                 "ip_scan_emit", "ip_scan_sample", "ip_rescore"):
+        ms, cnt = _lib.prof_collect(name)
+        if cnt:
+            spans[name] = (ms / cnt, cnt, ms / args.steps)
+    L_.convdr_prof_enable(0)
     if world > 1:
-        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
+        dist.destroy_process_group()
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
         return
-    pairs_per_s = world * nq * n * args.steps / el
-    scan_s = scan_ms / 1e3 / max(1, scan_n)
-    flops = 2.0 * nq * n * d
+    rows = EB * SL
+    gemm_flop = {"gemm_qkv": 2.0 * rows * H * 3 * H, "gemm_attn_out": 2.0 * rows * H * H,
+                 "gemm_ffn1": 2.0 * rows * H * I, "gemm_ffn2": 2.0 * rows * I * H,
+                 "attention": 36864.0 / LAYERS * SL * SL * EB, "ip_scan_emit": 2.0 * nq * n * d}
+    kern = {name: {"avg_ms": v[0], "launches": v[1], "ms_per_step": v[2],
+                   **({"TFLOPs": gemm_flop[name] / v[0] / 1e9} if name in gemm_flop else {})}
+            for name, v in spans.items()}
+    dom = "gemm_ffn1"
+    dom_tf = gemm_flop[dom] / spans[dom][0] / 1e9
+    enc_rate = EB / (enc_ms / 1e3)
     line = {
         "metric": "passages encoded/sec + query x passage IP-scored/sec, 768-d",
-        "value": pairs_per_s, "unit": "query x passage pairs/s (exact top-%d, whole job)" % k,
+        "value": world * EB * args.steps / el, "unit": "passages/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 scan + f64 rescore",
-        "data": "synthetic N(0,1) embeddings, seed=rank; queries seed 1234",
-        "config": {"workload": "configs[1]: %d passages x 768-d per GPU, %d-query brute-force IP top-%d "
-                               "(encode leg not built yet)" % (n, nq, k),
-                   "passages_per_gpu": n, "queries": nq, "topk": k, "parallelism": "corpus-sharded x%d" % world},
-        "uncertified_queries": status_bad, "candidates_per_query": {"emitted": emitted, "rescored_band": band},
-        "kernel_ms": {"ip_scan_emit": scan_s * 1e3, "ip_scan_sample": samp_ms / max(1, scan_n),
-                      "ip_rescore": resc_ms / max(1, scan_n)},
-        "roofline": {"kernel": "k_ip_scan<EMIT>", "bound": "mfma", "achieved": flops / scan_s / 1e12,
-                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": flops / scan_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                     "hbm_GBps_algorithmic": n * d * 2 / scan_s / 1e9},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic: uniform token ids in [3, 50000) with id[0] = 0, %d real tokens/passage; N(0,1) corpus/query "
+                "embeddings (seed = rank / 1234); random-init roberta-base-shaped weights" % SL,
+        "config": {"workload": "configs[1]: encode %d x %d-token passages per step into a resident %d x 768 block + "
+                               "%d-query exact IP top-%d over the block" % (EB, SL, n, nq, k),
+                   "passages_per_gpu": n, "queries": nq, "topk": k, "encode_batch": EB, "seq_len": SL,
+                   "parallelism": "replica + corpus shard per GPU x%d" % world},
+        "encode": {"passages_per_s_per_gpu": enc_rate, "ms_per_batch": enc_ms,
+                   "TFLOPs_dense_count": enc_rate * flop_per_passage(SL) / 1e12,
+                   "frac_of_bf16_mfma_peak": enc_rate * flop_per_passage(SL) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
+        "ip_search": {"pairs_per_s_per_gpu": nq * n / (ip_ms / 1e3), "ms_per_search_incl_fold": ip_ms,
+                      "uncertified_queries": status_bad,
+                      "candidates_per_query": {"emitted": emitted, "rescored_band": band}},
+        "kernels": kern,
+        "roofline": {"kernel": "k_gemm<EPI_GELU_BF16> (FFN1 [%d x 768] x [768 x 3072])" % rows, "bound": "mfma",
+                     "achieved": dom_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": dom_tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None},
     }
     if not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline_ip(nq, d, k)
+        line["cpu_baseline"] = cpu_baseline(nq, d, k, SL)
     print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

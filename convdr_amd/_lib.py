@@ -46,6 +46,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ConvdrError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "or `make -C convdr_amd/csrc`" % LIB_PATH)
+        # torch first: libconvdr_hip.so must bind to the HIP runtime (libamdhip64) that torch has loaded, not a
+        # second copy -- two runtimes in one process do not share devices, streams or allocations
+        import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in _SIGNATURES.items():
             f = getattr(_lib, name)
@@ -95,5 +98,5 @@ class EncoderWeights(C.Structure):
 
 register("convdr_cast_f32_bf16", C.c_int, [_p, _p, C.c_int64, _p])
 register("convdr_encoder_workspace_bytes", C.c_size_t, [C.POINTER(EncoderConfig), C.c_int64, C.c_int])
-register("convdr_encoder_forward", C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), _p, _p, C.c_int,
+register("convdr_encoder_forward", C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), _p, C.c_int, _p, C.c_int,
                                              C.c_int, _p, _p, C.c_int64, C.c_int, _p, C.c_size_t, _p, _p])

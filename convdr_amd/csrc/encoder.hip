@@ -123,7 +123,7 @@ extern "C" int convdr_cast_f32_bf16(const float* x, void* y, int64_t n, convdr_s
 }
 
 extern "C" int convdr_encoder_forward(const convdr_encoder_config* cfg, const convdr_encoder_weights* w,
-                                      const int64_t* input_ids, const int64_t* attention_mask, int B, int L,
+                                      const void* input_ids, int ids_are_int32, const int64_t* attention_mask, int B, int L,
                                       const int32_t* cu_seqlens, const int32_t* seq_lens, int64_t rows, int max_len,
                                       void* workspace, size_t workspace_bytes, float* out, convdr_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -136,7 +136,7 @@ extern "C" int convdr_encoder_forward(const convdr_encoder_config* cfg, const co
   const int H = cfg->hidden;
   // V^T columns past the last row are read (never used) by the last key tile: keep them finite
   CONVDR_CHECK_HIP(hipMemset2DAsync(p.Vt + rows, p.ldt * 2, 0, (p.ldt - rows) * 2, H, st));
-  hipLaunchKernelGGL(k_seq_pack, dim3((B + 3) / 4), dim3(256), 0, st, input_ids, attention_mask, B, L, cu_seqlens,
+  hipLaunchKernelGGL(k_seq_pack, dim3((B + 3) / 4), dim3(256), 0, st, input_ids, ids_are_int32, attention_mask, seq_lens, B, L, cu_seqlens,
                      cfg->kind, cfg->pad_idx, cfg->max_pos, p.tok_id, p.tok_pos);
   CONVDR_CHECK_LAUNCH("k_seq_pack");
   {

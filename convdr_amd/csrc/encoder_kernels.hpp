@@ -28,7 +28,10 @@ namespace convdr {
 //   BERT:    the column index.
 // Alignment rows [cu[b] + len, cu[b+1]) get token id -1 (embedding kernel writes zeros).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_seq_pack(const int64_t* __restrict__ ids, const int64_t* __restrict__ mask,
+// ids: int64 [B, L] (the drivers' .long() tensors) or int32 [B, L] (token-cache records, ids32 != 0);
+// mask == nullptr means "prefix mask": position l is kept iff l < lens[b] (right padding).
+__global__ void __launch_bounds__(256) k_seq_pack(const void* __restrict__ ids_v, int ids32,
+                                                  const int64_t* __restrict__ mask, const int32_t* __restrict__ lens,
                                                   int B, int L, const int32_t* __restrict__ cu, int kind, int pad_idx,
                                                   int max_pos, int32_t* __restrict__ tok_id,
                                                   int32_t* __restrict__ tok_pos) {
@@ -36,12 +39,15 @@ __global__ void __launch_bounds__(256) k_seq_pack(const int64_t* __restrict__ id
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const int base = cu[b], end = cu[b + 1];
+  const int64_t* ids = (const int64_t*)ids_v;
+  const int32_t* ids_i = (const int32_t*)ids_v;
+  const int len_b = lens[b];
   int kept = 0, nonpad = 0;
   for (int l0 = 0; l0 < L; l0 += 64) {
     const int l = l0 + lane;
     const bool valid = l < L;
-    const int64_t id = valid ? ids[(int64_t)b * L + l] : (int64_t)pad_idx;
-    const bool m = valid && mask[(int64_t)b * L + l] != 0;
+    const int64_t id = valid ? (ids32 ? (int64_t)ids_i[(int64_t)b * L + l] : ids[(int64_t)b * L + l]) : (int64_t)pad_idx;
+    const bool m = valid && (mask ? mask[(int64_t)b * L + l] != 0 : l < len_b);
     const bool np = valid && id != pad_idx;
     const unsigned long long bm = __ballot(m), bnp = __ballot(np);
     const unsigned long long lt = (1ull << lane) - 1ull;

@@ -227,12 +227,16 @@ class EncoderTower(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------
     def embed(self, input_ids, attention_mask, head=None, seq_lens=None):
-        """-> fp32 [B, out_dim or H] embeddings (CLS pooling, models.py:43)."""
+        """-> fp32 [B, out_dim or H] embeddings (CLS pooling, models.py:43).
+        Fast path for the corpus loop: int32 ids, attention_mask=None and host `seq_lens` (right padding)."""
         L_ = _lib.lib()
         if input_ids.device.type != "cuda":
             raise _lib.ConvdrError("encoder inputs must be CUDA tensors (no CPU fallback)")
-        ids = input_ids.long().contiguous()
-        mask = attention_mask.long().contiguous()
+        ids32 = input_ids.dtype == torch.int32
+        ids = input_ids.contiguous() if ids32 else input_ids.long().contiguous()
+        mask = None if attention_mask is None else attention_mask.long().contiguous()
+        if mask is None and seq_lens is None:
+            raise ValueError("attention_mask=None needs seq_lens")
         B, L = ids.shape
         dev = ids.device
         if seq_lens is None:
@@ -255,7 +259,7 @@ class EncoderTower(nn.Module):
             need = L_.convdr_encoder_workspace_bytes(C.byref(c), rows, B)
             if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
                 self._ws = torch.empty(int(need * 1.25), dtype=torch.uint8, device=dev)
-            _lib.check(L_.convdr_encoder_forward(C.byref(c), C.byref(w), _lib.ptr(ids), _lib.ptr(mask), B, L,
+            _lib.check(L_.convdr_encoder_forward(C.byref(c), C.byref(w), _lib.ptr(ids), int(ids32), _lib.ptr(mask), B, L,
                                                  _lib.ptr(cu), _lib.ptr(seq_lens), rows, max_len, _lib.ptr(self._ws),
                                                  self._ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
                        "convdr_encoder_forward")

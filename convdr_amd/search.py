@@ -71,6 +71,19 @@ class FlatIPIndex:
             self._p32 = torch.cat([self._p32, t], 0)
             self._pbf = torch.cat([self._pbf, pbf], 0)
 
+    def update_rows(self, row0, emb):
+        """Overwrite rows [row0, row0 + len(emb)) of the resident block with freshly encoded embeddings
+        (device fp32 [m, d]) and refresh their bf16 scan copy / the block's max norm.  No sync."""
+        import torch
+        m = int(emb.shape[0])
+        assert emb.dtype == torch.float32 and emb.is_contiguous() and row0 + m <= self.ntotal
+        dst32, dstbf = self._p32[row0:row0 + m], self._pbf[row0:row0 + m]
+        dst32.copy_(emb)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().convdr_ip_prepare_block(_lib.ptr(dst32), m, self.d, _lib.ptr(dstbf),
+                                                         _lib.ptr(self._max_norm), _lib.stream_ptr()),
+                       "convdr_ip_prepare_block")
+
     def _workspace(self, nbytes):
         import torch
         if self._ws is None or self._ws.numel() < nbytes:

@@ -121,12 +121,14 @@ int convdr_cast_f32_bf16(const float* x, void* y, int64_t n, convdr_stream_t str
 size_t convdr_encoder_workspace_bytes(const convdr_encoder_config* cfg, int64_t rows, int B);
 
 /* out[b, :] = embedding of sequence b.  input_ids / attention_mask: device int64 [B, L] exactly as the reference
- * drivers pass them (gen_passage_embeddings.py:105-112).  Only mask == 1 tokens are computed ("packed rows"):
+ * drivers pass them (gen_passage_embeddings.py:105-112); with ids_are_int32 != 0 input_ids is int32 [B, L] (token-cache
+ * records, data/tokenizing.py:116) and attention_mask may be NULL = "l < seq_lens[b]" (what GetProcessingFn builds,
+ * data/tokenizing.py:138-140).  Only mask == 1 tokens are computed ("packed rows"):
  * cu_seqlens (device int32 [B+1]) gives each sequence's first row, multiples of 8, cu[B] == rows;
  * seq_lens (device int32 [B]) = mask.sum(1) >= 1; mask[b, 0] must be 1 (the CLS position).  max_len = max(seq_lens).
  * out: device fp32 [B, out_dim or hidden]. */
 int convdr_encoder_forward(const convdr_encoder_config* cfg, const convdr_encoder_weights* w,
-                           const int64_t* input_ids, const int64_t* attention_mask, int B, int L,
+                           const void* input_ids, int ids_are_int32, const int64_t* attention_mask, int B, int L,
                            const int32_t* cu_seqlens, const int32_t* seq_lens, int64_t rows, int max_len,
                            void* workspace, size_t workspace_bytes, float* out, convdr_stream_t stream);
 

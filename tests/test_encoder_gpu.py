@@ -101,3 +101,37 @@ def test_roberta_base_shape_matches_oracle():
     ref2 = OE.rdot_nll_emb(sd, torch.from_numpy(ids[:5, :70]), torch.from_numpy(mask[:5, :70]), num_layers=12,
                            num_heads=12).numpy()
     _check(emb2, ref2, "second call")
+
+
+def test_corpus_encode_loop_matches_reference_blocks(golden_dir, tmp_path):
+    """Token cache -> blocks, against the files the reference's own StreamInferenceDoc wrote."""
+    import json
+    import pickle
+    from types import SimpleNamespace
+    from convdr_amd import blocks, encode
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    z = np.load(os.path.join(golden_dir, "encode_loop.npz"))
+    N, L = int(z["N"]), int(z["L"])
+    (tmp_path / "data").mkdir()
+    open(tmp_path / "data" / "passages", "wb").write(z["token_cache"].tobytes())
+    json.dump({"type": "int32", "total_number": N, "embedding_size": L}, open(tmp_path / "data" / "passages_meta", "w"))
+    cfg = RobertaConfig(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                        intermediate_size=256, max_position_embeddings=514)
+    model = MSMarcoConfigDict["rdot_nll"].model_class(cfg)
+    model.load_state_dict(_sd(z), strict=False)
+    model = model.cuda().eval()
+    args = SimpleNamespace(data_dir=str(tmp_path / "data"), output_dir=str(tmp_path / "out"),
+                           per_gpu_eval_batch_size=8, max_seq_length=L)
+    encode.generate_new_ann(args, model)
+    emb = pickle.load(open(tmp_path / "out" / "passage__emb_p__data_obj_0.pb", "rb"))      # the reference's reader
+    embid = pickle.load(open(tmp_path / "out" / "passage__embid_p__data_obj_0.pb", "rb"))
+    assert emb.dtype == np.float32 and emb.shape == z["emb"].shape and emb.flags.c_contiguous
+    assert embid.dtype == np.int64
+    np.testing.assert_array_equal(embid, z["embid"])
+    _check(torch.from_numpy(emb), z["emb"], "encode loop")
+    # sharding rule: 2 ranks -> records i % 2 == rank, same embeddings
+    with blocks.TokenCache(str(tmp_path / "data" / "passages")) as cache:
+        for r in range(2):
+            e, i = encode.encode_shard(model, cache, rank=r, world=2, batch_size=5)
+            assert i.tolist() == list(range(r, N, 2))
+            np.testing.assert_allclose(e, emb[r::2], atol=1e-5)
