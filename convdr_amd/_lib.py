@@ -100,3 +100,4 @@ register("convdr_cast_f32_bf16", C.c_int, [_p, _p, C.c_int64, _p])
 register("convdr_encoder_workspace_bytes", C.c_size_t, [C.POINTER(EncoderConfig), C.c_int64, C.c_int])
 register("convdr_encoder_forward", C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), _p, C.c_int, _p, C.c_int,
                                              C.c_int, _p, _p, C.c_int64, C.c_int, _p, C.c_size_t, _p, _p])
+register("convdr_encoder_debug_layout", C.c_int, [C.POINTER(EncoderConfig), C.c_int64, C.c_int, C.POINTER(C.c_int64)])

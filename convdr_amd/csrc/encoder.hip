@@ -40,22 +40,34 @@ static EncBufs enc_plan(const convdr_encoder_config* c, int64_t rows, int B, cha
   return p;
 }
 
-template <int EPI>
-int launch_gemm(GemmArgs a, hipStream_t st, const char* prof_name) {
+template <int EPI, class T>
+int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
+  static_assert(T::TR == T::TL, "square tiles: the QKV kernel swaps operand roles per tile");
   static bool attr_done = false;
   if (!attr_done) {
     CONVDR_CHECK_HIP(
-        hipFuncSetAttribute((const void*)k_gemm<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_SMEM_BYTES));
+        hipFuncSetAttribute((const void*)k_gemm<EPI, T>, hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM_BYTES));
     attr_done = true;
   }
-  CONVDR_REQUIRE(a.K % GEMM_BK == 0 && a.N % 4 == 0, "gemm: need K %% 64 == 0 and N %% 4 == 0 (K=%d N=%d)", a.K, a.N);
-  a.tilesN = (a.N + 127) / 128;
-  a.tilesT = (int)ceil_div64(a.rows, 128);
+  a.tilesN = (a.N + T::TR - 1) / T::TR;
+  a.tilesT = (int)ceil_div64(a.rows, T::TL);
   if (a.tilesT == 0) return 0;
   ProfScope prof(prof_name, st);
-  hipLaunchKernelGGL(k_gemm<EPI>, dim3((unsigned)a.tilesN * a.tilesT), dim3(GEMM_THREADS), GEMM_SMEM_BYTES, st, a);
+  hipLaunchKernelGGL((k_gemm<EPI, T>), dim3((unsigned)a.tilesN * a.tilesT), dim3(T::THREADS), T::SMEM_BYTES, st, a);
   CONVDR_CHECK_LAUNCH("k_gemm");
   return 0;
+}
+
+// 256 x 256 tiles when the problem fills them (N % 256 == 0, for QKV also H % 256 == 0, and enough token rows
+// to occupy the 256 CUs), else 128 x 128.
+template <int EPI>
+int launch_gemm(GemmArgs a, hipStream_t st, const char* prof_name) {
+  CONVDR_REQUIRE(a.K % GEMM_BK == 0 && a.N % 4 == 0, "gemm: need K %% 64 == 0 and N %% 4 == 0 (K=%d N=%d)", a.K, a.N);
+  if (EPI == EPI_QKV) CONVDR_REQUIRE(a.H % 128 == 0, "gemm: fused QKV needs hidden %% 128 == 0 (%d)", a.H);
+  const bool fits = a.N % 256 == 0 && (EPI != EPI_QKV || a.H % 256 == 0);
+  const int64_t tiles256 = (int64_t)(a.N / 256) * ceil_div64(a.rows, 256);
+  if (fits && tiles256 >= 192) return launch_gemm_t<EPI, Tile256>(a, st, prof_name);
+  return launch_gemm_t<EPI, Tile128>(a, st, prof_name);
 }
 
 static int check_config(const convdr_encoder_config* c) {
@@ -173,5 +185,15 @@ extern "C" int convdr_encoder_forward(const convdr_encoder_config* cfg, const co
                        w->head_ln_g, w->head_ln_b, cfg->head_ln_eps, (bf16_t*)nullptr, out);
     CONVDR_CHECK_LAUNCH("k_layernorm(head)");
   }
+  return 0;
+}
+
+// Debug / test aid: byte offsets of the activation buffers inside the workspace, in the order
+// tok_id, tok_pos, X, Q, K, Vt, ctx, Hm, Y, cls_b, cls_y, cls_f, head_y; out[13] = ldt.
+extern "C" int convdr_encoder_debug_layout(const convdr_encoder_config* cfg, int64_t rows, int B, int64_t* out) {
+  const EncBufs p = enc_plan(cfg, rows, B, nullptr);
+  const void* v[13] = {p.tok_id, p.tok_pos, p.X, p.Q, p.K, p.Vt, p.ctx, p.Hm, p.Y, p.cls_b, p.cls_y, p.cls_f, p.head_y};
+  for (int i = 0; i < 13; ++i) out[i] = (int64_t)(size_t)v[i];
+  out[13] = p.ldt;
   return 0;
 }

@@ -211,37 +211,33 @@ struct GemmArgs {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-template <int EPI>
-__global__ void __launch_bounds__(GEMM_THREADS, 2) k_gemm(const GemmArgs a) {
+template <int EPI, class T>
+__global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // consecutive logical tiles sweep the feature tiles of one token tile: the activation tile stays in L2
   const uint32_t logical = xcd_remap(blockIdx.x, gridDim.x);
   const int tt = logical / a.tilesN, tn = logical - tt * a.tilesN;
-  const int64_t t0 = (int64_t)tt * 128;
-  const int n0 = tn * 128;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1, hi = lane >> 5;
-
-  GemmAcc acc;
-  gemm_acc_zero(acc);
+  const WavePos<T> w;
+  GemmAcc<T> acc;
+  acc.zero();
   bool tokens_on_regs = false;
-  if constexpr (EPI == EPI_QKV) tokens_on_regs = n0 >= 2 * a.H;
-  if (tokens_on_regs)
-    gemm_nt_mainloop(a.X, a.K, a.rows, a.W, a.K, a.N, a.K, t0, n0, smem, acc);
-  else
-    gemm_nt_mainloop(a.W, a.K, a.N, a.X, a.K, a.rows, a.K, n0, t0, smem, acc);
+  if constexpr (EPI == EPI_QKV) tokens_on_regs = tn * T::TR >= 2 * a.H;   // H % TR == 0 (checked by the launcher)
 
-  if (tokens_on_regs) {  // V third of the fused QKV projection -> Vt[feature][token]
+  if (tokens_on_regs) {  // V third of the fused QKV projection -> Vt[feature][token]: roles swapped
+    const int64_t t0 = (int64_t)tt * T::TL;      // the launcher lays tiles out as [tilesT][tilesN] with TR == TL
+    const int n0 = tn * T::TR;
+    gemm_nt_mainloop<T>(a.X, a.K, a.rows, a.W, a.K, a.N, a.K, t0, n0, smem, acc, w);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int f = n0 + gemm_acc_col(wn, nt, lane);  // feature on the lane
+    for (int nt = 0; nt < T::NT; ++nt) {
+      const int f = n0 + w.l_index(nt);  // feature on the lane
       if (f >= a.N) continue;
       const float bv = a.bias[f];
       bf16_t* dst = a.Vt + (int64_t)(f - 2 * a.H) * a.ldt;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int64_t t = t0 + wm * 64 + mt * 32 + 8 * g + 4 * hi;  // 4 consecutive tokens (rows % 4 == 0)
+          const int64_t t = t0 + w.r_base(mt, g);  // 4 consecutive tokens (rows % 4 == 0)
           if (t < a.rows) {
             const f32x16& v = acc.c[mt][nt];
             uint2 o;
@@ -254,15 +250,18 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) k_gemm(const GemmArgs a) {
     return;
   }
 
+  const int64_t t0 = (int64_t)tt * T::TL;
+  const int n0 = tn * T::TR;
+  gemm_nt_mainloop<T>(a.W, a.K, a.N, a.X, a.K, a.rows, a.K, n0, t0, smem, acc, w);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int64_t t = t0 + gemm_acc_col(wn, nt, lane);  // token on the lane
+  for (int nt = 0; nt < T::NT; ++nt) {
+    const int64_t t = t0 + w.l_index(nt);  // token on the lane
     if (t >= a.rows) continue;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int f = n0 + wm * 64 + mt * 32 + 8 * g + 4 * hi;  // 4 consecutive features (N % 4 == 0)
+        const int f = n0 + w.r_base(mt, g);  // 4 consecutive features (N % 4 == 0)
         if (f >= a.N) continue;
         const f32x16& v = acc.c[mt][nt];
         const float4 bv = *(const float4*)(a.bias + f);
@@ -358,7 +357,8 @@ __global__ void __launch_bounds__(256) k_attention_fwd(const AttnArgs a) {
       glds16((const char*)(a.K + (base + kv0 + row) * H + h * 64) + gch * 16, sK + r0 * 128);
       glds16((const char*)(a.Vt + (int64_t)(h * 64 + row) * a.ldt + base + kv0) + gch * 16, sV + r0 * 128);
     }
-    __syncthreads();  // (vmcnt(0) is drained by the compiler before the barrier)
+    lds_dma_wait_all();  // explicit: hipcc's automatic vmcnt wait for LDS-DMA is not reliable (gemm_nt.hpp)
+    __syncthreads();
 
     // ---- S^T = K Q^T for the 64 keys of this tile ----
     f32x16 st[2];

@@ -89,28 +89,26 @@ struct ScanArgs {
   float* T;          // FULL: [nPt*128, nq_pad]; TOP2: [nPt*8, nq_pad]
 };
 
-template <int MODE>
-__global__ void __launch_bounds__(GEMM_THREADS, 2) k_ip_scan(const ScanArgs a) {
+template <int MODE, class T>
+__global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan(const ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t logical = xcd_remap(blockIdx.x, gridDim.x);
   const int ts = logical / a.nQt, qt = logical - ts * a.nQt;
-  const int64_t m0 = (int64_t)ts * a.pt_stride * GEMM_BM;
-  const int64_t n0 = (int64_t)qt * GEMM_BN;
+  const int64_t m0 = (int64_t)ts * a.pt_stride * T::TR;
+  const int64_t n0 = (int64_t)qt * T::TL;
 
-  GemmAcc acc;
-  gemm_acc_zero(acc);
-  gemm_nt_mainloop(a.P, a.d, a.n, a.Qb, a.d, a.nq_pad, a.d, m0, n0, smem, acc);
-
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1, hi = lane >> 5;
+  const WavePos<T> w;
+  GemmAcc<T> acc;
+  acc.zero();
+  gemm_nt_mainloop<T>(a.P, a.d, a.n, a.Qb, a.d, a.nq_pad, a.d, m0, n0, smem, acc, w);
 
   if constexpr (MODE == IP_MODE_EMIT) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int q = (int)n0 + gemm_acc_col(wn, nt, lane);
+    for (int nt = 0; nt < T::NT; ++nt) {
+      const int q = (int)n0 + w.l_index(nt);
       const float tau = q < a.nq ? a.tau[q] : INFINITY;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < T::MT; ++mt) {
         const f32x16 v = acc.c[mt][nt];
         float mx = v[0];
 #pragma unroll
@@ -118,7 +116,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) k_ip_scan(const ScanArgs a) {
         if (mx >= tau) {  // rare: ~rank_target hits per query in the whole block
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int64_t row = m0 + gemm_acc_row(wm, mt, r, lane);
+            const int64_t row = m0 + w.r_index(mt, r);
             if (v[r] >= tau && row < a.n) {
               const uint32_t slot = atomicAdd(&a.counts[q], 1u);
               if (slot < (uint32_t)a.cap) {
@@ -132,32 +130,32 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) k_ip_scan(const ScanArgs a) {
     }
   } else if constexpr (MODE == IP_MODE_FULL) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int q = (int)n0 + gemm_acc_col(wn, nt, lane);
+    for (int nt = 0; nt < T::NT; ++nt) {
+      const int q = (int)n0 + w.l_index(nt);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t row = m0 + gemm_acc_row(wm, mt, r, lane);
+          const int64_t row = m0 + w.r_index(mt, r);
           a.T[row * a.nq_pad + q] = row < a.n ? acc.c[mt][nt][r] : -INFINITY;
         }
     }
-  } else {  // TOP2: best two of this lane's 32 scores (one query, 32 of the tile's passages)
+  } else {  // TOP2: best two of this lane's MT*16 scores (one query, MT*16 of the tile's passages)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int q = (int)n0 + gemm_acc_col(wn, nt, lane);
+    for (int nt = 0; nt < T::NT; ++nt) {
+      const int q = (int)n0 + w.l_index(nt);
       float b0 = -INFINITY, b1 = -INFINITY;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t row = m0 + gemm_acc_row(wm, mt, r, lane);
+          const int64_t row = m0 + w.r_index(mt, r);
           const float s = row < a.n ? acc.c[mt][nt][r] : -INFINITY;
           const float lo = fminf(b0, s);
           b0 = fmaxf(b0, s);
           b1 = fmaxf(b1, lo);
         }
-      const int64_t slot = (((int64_t)ts * 2 + wm) * 2 + hi) * 2;
+      const int64_t slot = (((int64_t)ts * T::WR + w.wr) * 2 + w.hi) * 2;
       a.T[slot * a.nq_pad + q] = b0;
       a.T[(slot + 1) * a.nq_pad + q] = b1;
     }
@@ -354,6 +352,8 @@ __global__ void __launch_bounds__(256) k_ip_select(int k, int cap, const uint32_
 // host-side plan shared by workspace sizing and the search call
 // ------------------------------------------------------------------------------------------
 struct IpPlan {
+  bool big;          // 256 x 256 scan tiles (more than 128 queries), else 128 x 128
+  int tr, tl;        // tile extent over passages / queries
   int nq_pad, nQt, nPt;
   int mode;          // -1: no threshold pass (n <= cap), else IP_MODE_FULL / IP_MODE_TOP2
   int nSt, stride;   // sampled passage tiles / tile stride
@@ -364,9 +364,12 @@ struct IpPlan {
 
 static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
   IpPlan p;
-  p.nq_pad = (nq + GEMM_BN - 1) / GEMM_BN * GEMM_BN;
-  p.nQt = p.nq_pad / GEMM_BN;
-  p.nPt = (int)ceil_div64(n, GEMM_BM);
+  p.big = nq > 128;
+  p.tr = p.big ? Tile256::TR : Tile128::TR;
+  p.tl = p.big ? Tile256::TL : Tile128::TL;
+  p.nq_pad = (nq + p.tl - 1) / p.tl * p.tl;
+  p.nQt = p.nq_pad / p.tl;
+  p.nPt = (int)ceil_div64(n, p.tr);
   p.nSt = 0; p.stride = 1; p.nvals = 0; p.npow2 = 2;
   if (n <= cap) {
     p.mode = -1;
@@ -377,10 +380,10 @@ static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
     int64_t S = n / 32;
     if (S < IP_SAMPLE_MIN) S = IP_SAMPLE_MIN;
     if (S > IP_SAMPLE_MAX) S = IP_SAMPLE_MAX;
-    p.nSt = (int)(S / GEMM_BM);
+    p.nSt = (int)(S / p.tr);
     if (p.nSt > p.nPt) p.nSt = p.nPt;
     p.stride = p.nPt / p.nSt;
-    p.nvals = (int64_t)p.nSt * 8;
+    p.nvals = (int64_t)p.nSt * 8;   // WR * 2 halves * 2 values per tile, WR = 2 for both tile shapes
   }
   while (p.npow2 < p.nvals) p.npow2 <<= 1;
   size_t o = 0;
@@ -390,7 +393,7 @@ static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
   p.o_tau = take((size_t)p.nq_pad * 4);
   p.o_counts = take((size_t)p.nq_pad * 4);
   p.o_m = take((size_t)p.nq_pad * 4);
-  const size_t t_rows = p.mode == IP_MODE_FULL ? (size_t)p.nPt * GEMM_BM : (size_t)p.nvals;
+  const size_t t_rows = p.mode == IP_MODE_FULL ? (size_t)p.nPt * p.tr : (size_t)p.nvals;
   p.o_T = take(t_rows * p.nq_pad * 4);
   p.o_id = take((size_t)nq * cap * 4);
   p.o_s = take((size_t)nq * cap * 4);
@@ -400,19 +403,24 @@ static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
   return p;
 }
 
-template <int MODE>
-static int launch_scan(const ScanArgs& a, hipStream_t st) {
-  static bool attr_done = false;  // 64 KB dynamic LDS needs the opt-in once per kernel
+template <int MODE, class T>
+static int launch_scan_t(const ScanArgs& a, hipStream_t st) {
+  static bool attr_done = false;  // > 48 KB dynamic LDS needs the opt-in once per kernel
   if (!attr_done) {
-    CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_scan<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         GEMM_SMEM_BYTES));
+    CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_scan<MODE, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         T::SMEM_BYTES));
     attr_done = true;
   }
   const unsigned grid = (unsigned)a.nPt * (unsigned)a.nQt;
   ProfScope prof(MODE == IP_MODE_EMIT ? "ip_scan_emit" : "ip_scan_sample", st);
-  hipLaunchKernelGGL(k_ip_scan<MODE>, dim3(grid), dim3(GEMM_THREADS), GEMM_SMEM_BYTES, st, a);
+  hipLaunchKernelGGL((k_ip_scan<MODE, T>), dim3(grid), dim3(T::THREADS), T::SMEM_BYTES, st, a);
   CONVDR_CHECK_LAUNCH("k_ip_scan");
   return 0;
+}
+
+template <int MODE>
+static int launch_scan(const ScanArgs& a, bool big, hipStream_t st) {
+  return big ? launch_scan_t<MODE, Tile256>(a, st) : launch_scan_t<MODE, Tile128>(a, st);
 }
 
 }  // namespace convdr
@@ -496,12 +504,12 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
       a.nPt = p.nSt; a.pt_stride = p.stride;
       if (p.mode == IP_MODE_FULL) {
         r = (int64_t)R < n ? R : (int)n;
-        if (int e = launch_scan<IP_MODE_FULL>(a, st)) return e;
+        if (int e = launch_scan<IP_MODE_FULL>(a, p.big, st)) return e;
       } else {
-        const double frac = (double)p.nSt * GEMM_BM / (double)n;
+        const double frac = (double)p.nSt * p.tr / (double)n;
         r = (int)lrint(R * frac);
         if (r < 8) r = 8;
-        if (int e = launch_scan<IP_MODE_TOP2>(a, st)) return e;
+        if (int e = launch_scan<IP_MODE_TOP2>(a, p.big, st)) return e;
       }
       static bool attr_done = false;
       if (!attr_done) {
@@ -514,7 +522,7 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
       CONVDR_CHECK_LAUNCH("k_tau_select");
     }
     a.nPt = p.nPt; a.pt_stride = 1;
-    if (int e = launch_scan<IP_MODE_EMIT>(a, st)) return e;
+    if (int e = launch_scan<IP_MODE_EMIT>(a, p.big, st)) return e;
   }
   static bool attr_done2 = false;
   if (!attr_done2) {

@@ -132,6 +132,10 @@ int convdr_encoder_forward(const convdr_encoder_config* cfg, const convdr_encode
                            const int32_t* cu_seqlens, const int32_t* seq_lens, int64_t rows, int max_len,
                            void* workspace, size_t workspace_bytes, float* out, convdr_stream_t stream);
 
+/* Test aid: byte offsets of the activation buffers inside the encoder workspace, in the order tok_id, tok_pos, X, Q, K,
+ * Vt, ctx, Hm, Y, cls_b, cls_y, cls_f, head_y; out[13] = leading dimension of Vt. */
+int convdr_encoder_debug_layout(const convdr_encoder_config* cfg, int64_t rows, int B, int64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

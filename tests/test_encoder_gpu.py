@@ -135,3 +135,23 @@ def test_corpus_encode_loop_matches_reference_blocks(golden_dir, tmp_path):
             e, i = encode.encode_shard(model, cache, rank=r, world=2, batch_size=5)
             assert i.tolist() == list(range(r, N, 2))
             np.testing.assert_allclose(e, emb[r::2], atol=1e-5)
+
+
+def test_forward_is_bitwise_deterministic():
+    """Regression for a real bug: hipcc does not reliably wait for LDS-DMA (global_load_lds) before a barrier;
+    without the explicit vmcnt drain in gemm_nt.hpp rare stale operand rows made repeated forwards differ."""
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    torch.manual_seed(0)
+    model = MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig(vocab_size=1000, num_hidden_layers=4)).cuda().eval()
+    rs = np.random.RandomState(0)
+    lens = [128, 100, 65, 64, 63, 33, 32, 31, 17, 8, 2, 1] * 8
+    ids = rs.randint(3, 1000, size=(len(lens), 128)).astype(np.int64)
+    mask = np.zeros_like(ids)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+    ids, mask = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    with torch.no_grad():
+        outs = [model.body_emb(ids, mask) for _ in range(6)]
+    assert not torch.isnan(outs[0]).any()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
