@@ -3,6 +3,8 @@
 // :205-211 + :227-235 (HFBertEncoder / BiEncoder.query_emb/body_emb).
 #include "encoder_kernels.hpp"
 
+#include <stdlib.h>
+
 #include "../../include/convdr_hip.h"
 
 namespace convdr {
@@ -49,6 +51,8 @@ int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
         hipFuncSetAttribute((const void*)k_gemm<EPI, T>, hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM_BYTES));
     attr_done = true;
   }
+  static const int dbg = getenv("CONVDR_DBG_SAME_TILE") ? atoi(getenv("CONVDR_DBG_SAME_TILE")) : 0;
+  a.dbg_same_tile = dbg;
   a.tilesN = (a.N + T::TR - 1) / T::TR;
   a.tilesT = (int)ceil_div64(a.rows, T::TL);
   if (a.tilesT == 0) return 0;

@@ -207,16 +207,29 @@ struct GemmArgs {
   int H;
   int64_t ldt;
   int tilesN, tilesT;
+  int dbg_same_tile;  // experiment: every workgroup reads tile (0, 0) (all-L2-hit upper bound); results are garbage
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (HF "gelu": x * 0.5 * (1 + erf(x / sqrt(2)))).  erf by Abramowitz & Stegun 7.1.26
+// (|abs error| <= 1.5e-7, far below the bf16 output rounding) instead of libm's erff: 1 rcp + 1 exp + 7 FMA.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.f - p * t * __expf(-z * z);   // erf(|x| / sqrt 2)
+  return 0.5f * x + 0.5f * fabsf(x) * e;          // 0.5 x (1 + sign(x) e)
+}
 
 template <int EPI, class T>
 __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // consecutive logical tiles sweep the feature tiles of one token tile: the activation tile stays in L2
   const uint32_t logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int tt = logical / a.tilesN, tn = logical - tt * a.tilesN;
+  int tt = logical / a.tilesN, tn = logical - tt * a.tilesN;
+  if (a.dbg_same_tile) { tt = 0; tn = 0; }
   const WavePos<T> w;
   GemmAcc<T> acc;
   acc.zero();
@@ -253,38 +266,60 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a) {
   const int64_t t0 = (int64_t)tt * T::TL;
   const int n0 = tn * T::TR;
   gemm_nt_mainloop<T>(a.W, a.K, a.N, a.X, a.K, a.rows, a.K, n0, t0, smem, acc, w);
+
+  // ---- epilogue.  The operand buffers are dead: park the tile's bias slice in LDS (no vmcnt round trip per
+  // register quad), issue all residual loads of a 32-token column block up front, then convert and store. ----
+  __syncthreads();
+  float* sbias = (float*)smem;
+  for (int i = threadIdx.x; i < T::TR; i += T::THREADS) sbias[i] = n0 + i < a.N ? a.bias[n0 + i] : 0.f;
+  __syncthreads();
+  const bool full_n = n0 + T::TR <= a.N;  // workgroup-uniform: no per-quad feature bound checks on the fast path
 #pragma unroll
   for (int nt = 0; nt < T::NT; ++nt) {
     const int64_t t = t0 + w.l_index(nt);  // token on the lane
-    if (t >= a.rows) continue;
+    const bool t_ok = t < a.rows;
+    const int64_t tc = t_ok ? t : a.rows - 1;
+    uint2 res[T::MT][4];
+    if constexpr (EPI == EPI_RESID_F32) {
+#pragma unroll
+      for (int mt = 0; mt < T::MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          int f = n0 + w.r_base(mt, g);
+          f = (full_n || f < a.N) ? f : a.N - 4;
+          res[mt][g] = *(const uint2*)(a.R + tc * a.N + f);
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int f = n0 + w.r_base(mt, g);  // 4 consecutive features (N % 4 == 0)
-        if (f >= a.N) continue;
+        const int fl = w.r_base(mt, g);      // 4 consecutive features (N % 4 == 0)
+        const int f = n0 + fl;
         const f32x16& v = acc.c[mt][nt];
-        const float4 bv = *(const float4*)(a.bias + f);
+        const float4 bv = *(const float4*)(sbias + fl);
         float y0 = v[4 * g + 0] + bv.x, y1 = v[4 * g + 1] + bv.y, y2 = v[4 * g + 2] + bv.z, y3 = v[4 * g + 3] + bv.w;
         if constexpr (EPI == EPI_GELU_BF16) {
           y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3);
         }
         if constexpr (EPI == EPI_RESID_F32) {
-          const uint2 r = *(const uint2*)(a.R + t * a.N + f);
+          const uint2 r = res[mt][g];
           y0 += __uint_as_float(r.x << 16); y1 += __uint_as_float(r.x & 0xffff0000u);
           y2 += __uint_as_float(r.y << 16); y3 += __uint_as_float(r.y & 0xffff0000u);
         }
-        if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_F32) {
-          *(float4*)(a.Cf + t * a.N + f) = make_float4(y0, y1, y2, y3);
-        } else {
-          uint2 o;
-          o.x = pack_bf16x2(y0, y1);
-          o.y = pack_bf16x2(y2, y3);
-          if constexpr (EPI == EPI_QKV) {
-            bf16_t* dst = f < a.H ? a.Qo + t * a.H + f : a.Ko + t * a.H + (f - a.H);
-            *(uint2*)dst = o;
+        if (t_ok && (full_n || f < a.N)) {
+          if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_F32) {
+            *(float4*)(a.Cf + t * a.N + f) = make_float4(y0, y1, y2, y3);
           } else {
-            *(uint2*)(a.Cb + t * a.N + f) = o;
+            uint2 o;
+            o.x = pack_bf16x2(y0, y1);
+            o.y = pack_bf16x2(y2, y3);
+            if constexpr (EPI == EPI_QKV) {
+              bf16_t* dst = f < a.H ? a.Qo + t * a.H + f : a.Ko + t * a.H + (f - a.H);
+              *(uint2*)dst = o;
+            } else {
+              *(uint2*)(a.Cb + t * a.N + f) = o;
+            }
           }
         }
       }
