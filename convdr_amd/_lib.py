@@ -101,3 +101,33 @@ register("convdr_encoder_workspace_bytes", C.c_size_t, [C.POINTER(EncoderConfig)
 register("convdr_encoder_forward", C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), _p, C.c_int, _p, C.c_int,
                                              C.c_int, _p, _p, C.c_int64, C.c_int, _p, C.c_size_t, _p, _p])
 register("convdr_encoder_debug_layout", C.c_int, [C.POINTER(EncoderConfig), C.c_int64, C.c_int, C.POINTER(C.c_int64)])
+
+
+class LayerWeightsT(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv_t", "wo_t", "w1_t", "w2_t")]
+
+
+class LayerGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2",
+                                          "ln2_g", "ln2_b")]
+
+
+class EncoderGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b")] + \
+               [("layers", C.POINTER(LayerGrads))] + \
+               [(n, C.c_void_p) for n in ("head_w", "head_b", "head_ln_g", "head_ln_b")]
+
+
+register("convdr_encoder_train_workspace_bytes", C.c_size_t, [C.POINTER(EncoderConfig), C.c_int64, C.c_int])
+register("convdr_encoder_train_forward", C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), _p, C.c_int, _p,
+                                                   C.c_int, C.c_int, _p, _p, C.c_int64, C.c_int, _p, C.c_size_t, _p, _p])
+register("convdr_encoder_backward", C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), C.POINTER(LayerWeightsT),
+                                              _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, C.c_size_t, _p,
+                                              C.POINTER(EncoderGrads), _p])
+register("convdr_transpose_f32_bf16", C.c_int, [_p, C.c_int, C.c_int, _p, _p])
+register("convdr_mse_fwd_bwd", C.c_int, [_p, _p, C.c_int64, C.c_float, _p, _p, _p])
+register("convdr_rank_ce_fwd_bwd", C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, C.c_int, _p])
+register("convdr_grad_norm_clip", C.c_int, [_p, C.c_int64, C.c_float, _p, _p, C.c_int, _p])
+register("convdr_scale_f32", C.c_int, [_p, C.c_int64, _p, _p])
+register("convdr_adamw_step", C.c_int, [_p, _p, _p, _p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                        C.c_double, C.c_int, C.c_int, _p, _p])

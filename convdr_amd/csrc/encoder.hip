@@ -1,9 +1,7 @@
 // Host orchestration + C ABI of the dual-encoder forward (inference path).
 // Reference call sites replaced:  model/models.py:140-148 (RobertaDot_NLL_LN.query_emb/body_emb),
 // :205-211 + :227-235 (HFBertEncoder / BiEncoder.query_emb/body_emb).
-#include "encoder_kernels.hpp"
-
-#include <stdlib.h>
+#include "gemm_launch.hpp"
 
 #include "../../include/convdr_hip.h"
 
@@ -42,38 +40,6 @@ static EncBufs enc_plan(const convdr_encoder_config* c, int64_t rows, int B, cha
   return p;
 }
 
-template <int EPI, class T>
-int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
-  static_assert(T::TR == T::TL, "square tiles: the QKV kernel swaps operand roles per tile");
-  static bool attr_done = false;
-  if (!attr_done) {
-    CONVDR_CHECK_HIP(
-        hipFuncSetAttribute((const void*)k_gemm<EPI, T>, hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM_BYTES));
-    attr_done = true;
-  }
-  static const int dbg = getenv("CONVDR_DBG_SAME_TILE") ? atoi(getenv("CONVDR_DBG_SAME_TILE")) : 0;
-  a.dbg_same_tile = dbg;
-  a.tilesN = (a.N + T::TR - 1) / T::TR;
-  a.tilesT = (int)ceil_div64(a.rows, T::TL);
-  if (a.tilesT == 0) return 0;
-  ProfScope prof(prof_name, st);
-  hipLaunchKernelGGL((k_gemm<EPI, T>), dim3((unsigned)a.tilesN * a.tilesT), dim3(T::THREADS), T::SMEM_BYTES, st, a);
-  CONVDR_CHECK_LAUNCH("k_gemm");
-  return 0;
-}
-
-// 256 x 256 tiles when the problem fills them (N % 256 == 0, for QKV also H % 256 == 0, and enough token rows
-// to occupy the 256 CUs), else 128 x 128.
-template <int EPI>
-int launch_gemm(GemmArgs a, hipStream_t st, const char* prof_name) {
-  CONVDR_REQUIRE(a.K % GEMM_BK == 0 && a.N % 4 == 0, "gemm: need K %% 64 == 0 and N %% 4 == 0 (K=%d N=%d)", a.K, a.N);
-  if (EPI == EPI_QKV) CONVDR_REQUIRE(a.H % 128 == 0, "gemm: fused QKV needs hidden %% 128 == 0 (%d)", a.H);
-  const bool fits = a.N % 256 == 0 && (EPI != EPI_QKV || a.H % 256 == 0);
-  const int64_t tiles256 = (int64_t)(a.N / 256) * ceil_div64(a.rows, 256);
-  if (fits && tiles256 >= 192) return launch_gemm_t<EPI, Tile256>(a, st, prof_name);
-  return launch_gemm_t<EPI, Tile128>(a, st, prof_name);
-}
-
 static int check_config(const convdr_encoder_config* c) {
   CONVDR_REQUIRE(c->hidden % 128 == 0 && c->hidden <= 1024, "encoder: hidden must be a multiple of 128, <= 1024 (got %d)",
                  c->hidden);
@@ -95,7 +61,7 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
   g.Qo = p.Q; g.Ko = p.K; g.Vt = p.Vt; g.H = H; g.ldt = p.ldt;
   if (int e = launch_gemm<EPI_QKV>(g, st, "gemm_qkv")) return e;
   {
-    AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, p.ctx, lse, 0.125f};
+    AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, (int64_t)H, p.ctx, lse, 0.125f};
     ProfScope prof("attention", st);
     hipLaunchKernelGGL(k_attention_fwd, dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
     CONVDR_CHECK_LAUNCH("k_attention_fwd");

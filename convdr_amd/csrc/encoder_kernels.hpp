@@ -30,7 +30,7 @@ namespace convdr {
 // ---------------------------------------------------------------------------------------------
 // ids: int64 [B, L] (the drivers' .long() tensors) or int32 [B, L] (token-cache records, ids32 != 0);
 // mask == nullptr means "prefix mask": position l is kept iff l < lens[b] (right padding).
-__global__ void __launch_bounds__(256) k_seq_pack(const void* __restrict__ ids_v, int ids32,
+static __global__ void __launch_bounds__(256) k_seq_pack(const void* __restrict__ ids_v, int ids32,
                                                   const int64_t* __restrict__ mask, const int32_t* __restrict__ lens,
                                                   int B, int L, const int32_t* __restrict__ cu, int kind, int pad_idx,
                                                   int max_pos, int32_t* __restrict__ tok_id,
@@ -123,7 +123,7 @@ __device__ __forceinline__ void ln_store(const LnRow& x, int H, int lane, bf16_t
 }
 
 // embeddings: LayerNorm(word[id] + pos[p] + type[0]) -> bf16 X
-__global__ void __launch_bounds__(256) k_embed_ln(const int32_t* __restrict__ tok_id,
+static __global__ void __launch_bounds__(256) k_embed_ln(const int32_t* __restrict__ tok_id,
                                                   const int32_t* __restrict__ tok_pos, int64_t rows, int H,
                                                   const float* __restrict__ word, const float* __restrict__ pos,
                                                   const float* __restrict__ type0, const float* __restrict__ g,
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) k_embed_ln(const int32_t* __restrict__ to
 }
 
 // rows of fp32 Y -> LayerNorm -> bf16 Xb (and/or fp32 Xf).  `gather` (optional) maps output row -> input row.
-__global__ void __launch_bounds__(256) k_layernorm(const float* __restrict__ Y, int64_t rows, int H,
+static __global__ void __launch_bounds__(256) k_layernorm(const float* __restrict__ Y, int64_t rows, int H,
                                                    const float* __restrict__ g, const float* __restrict__ b, float eps,
                                                    bf16_t* __restrict__ Xb, float* __restrict__ Xf) {
   const int lane = threadIdx.x & 63;
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) k_layernorm(const float* __restrict__ Y, 
 }
 
 // out[b, :] = in[cu[b], :]  (CLS rows), bf16 and/or fp32
-__global__ void __launch_bounds__(256) k_gather_cls(const int32_t* __restrict__ cu, int B, int H,
+static __global__ void __launch_bounds__(256) k_gather_cls(const int32_t* __restrict__ cu, int B, int H,
                                                     const bf16_t* __restrict__ Xb, const float* __restrict__ Xf,
                                                     bf16_t* __restrict__ Ob, float* __restrict__ Of) {
   const int lane = threadIdx.x & 63;
@@ -192,17 +192,24 @@ __global__ void __launch_bounds__(256) k_gather_cls(const int32_t* __restrict__ 
 //    token-major outputs  C[token][feature]:  R = weight rows (features), L = activation rows (tokens)
 //    V^T                  Vt[feature][token]: R = tokens,                 L = features   (roles swapped)
 // ---------------------------------------------------------------------------------------------
-enum { EPI_BF16 = 0, EPI_GELU_BF16 = 1, EPI_RESID_F32 = 2, EPI_QKV = 3, EPI_F32 = 4 };
+enum { EPI_BF16 = 0, EPI_GELU_BF16 = 1, EPI_RESID_F32 = 2, EPI_QKV = 3, EPI_F32 = 4,
+       EPI_GELU_SAVE = 5,   // training FFN1: Cb = gelu(y) and Cb2 = y (pre-activation, for the backward)
+       EPI_DGELU_BF16 = 6,  // backward of FFN1's activation: Cb = acc * gelu'(R[t, f])
+       EPI_SLAB_F32 = 7 };  // wgrad partial: Cf[split][rows][N] = acc (no bias)
 
 struct GemmArgs {
   const bf16_t* W;    // [N, K] weights (features)
   const bf16_t* X;    // [rows, K] activations (tokens)
   int64_t rows;       // tokens
   int N, K;
-  const float* bias;  // [N]
+  int64_t ldw, ldx;   // leading dimensions of W / X in elements (0 -> K)
+  int k_split_len;    // EPI_SLAB_F32: contraction slice per blockIdx.y (0 -> whole K)
+  const float* bias;  // [N] or nullptr (zeros)
   bf16_t* Cb;         // EPI_BF16 / EPI_GELU_BF16: [rows, N]
+  bf16_t* Cb2;        // EPI_GELU_SAVE: pre-activation [rows, N]
   float* Cf;          // EPI_RESID_F32 / EPI_F32:  [rows, N]
-  const bf16_t* R;    // EPI_RESID_F32: residual [rows, N]
+  const bf16_t* R;    // EPI_RESID_F32: residual [rows, N] bf16 (EPI_DGELU_BF16: the pre-activation)
+  const float* Rf;    // EPI_RESID_F32: fp32 residual instead of R when non-null (gradient residual stream)
   bf16_t *Qo, *Ko, *Vt;  // EPI_QKV (N = 3H): Q [rows, H], K [rows, H], Vt [H, ldt]
   int H;
   int64_t ldt;
@@ -223,8 +230,22 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x + 0.5f * fabsf(x) * e;          // 0.5 x (1 + sign(x) e)
 }
 
+// d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_grad(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float ex = __expf(-z * z);
+  const float e = 1.f - p * t * ex;                       // erf(|x| / sqrt 2)
+  const float cdf = 0.5f + (x < 0.f ? -0.5f : 0.5f) * e;  // Phi(x)
+  return cdf + x * 0.3989422804014327f * ex;              // exp(-x^2 / 2) == ex
+}
+
 template <int EPI, class T>
-__global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a) {
+static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // consecutive logical tiles sweep the feature tiles of one token tile: the activation tile stays in L2
   const uint32_t logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -235,11 +256,16 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a) {
   acc.zero();
   bool tokens_on_regs = false;
   if constexpr (EPI == EPI_QKV) tokens_on_regs = tn * T::TR >= 2 * a.H;   // H % TR == 0 (checked by the launcher)
+  const int64_t ldw = a.ldw ? a.ldw : a.K, ldx = a.ldx ? a.ldx : a.K;
+  int kbeg = 0, klen = a.K;
+  if constexpr (EPI == EPI_SLAB_F32) {
+    if (a.k_split_len) { kbeg = blockIdx.y * a.k_split_len; klen = a.k_split_len; }
+  }
 
   if (tokens_on_regs) {  // V third of the fused QKV projection -> Vt[feature][token]: roles swapped
     const int64_t t0 = (int64_t)tt * T::TL;      // the launcher lays tiles out as [tilesT][tilesN] with TR == TL
     const int n0 = tn * T::TR;
-    gemm_nt_mainloop<T>(a.X, a.K, a.rows, a.W, a.K, a.N, a.K, t0, n0, smem, acc, w);
+    gemm_nt_mainloop<T>(a.X, ldx, a.rows, a.W, ldw, a.N, a.K, t0, n0, smem, acc, w);
 #pragma unroll
     for (int nt = 0; nt < T::NT; ++nt) {
       const int f = n0 + w.l_index(nt);  // feature on the lane
@@ -265,13 +291,13 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a) {
 
   const int64_t t0 = (int64_t)tt * T::TL;
   const int n0 = tn * T::TR;
-  gemm_nt_mainloop<T>(a.W, a.K, a.N, a.X, a.K, a.rows, a.K, n0, t0, smem, acc, w);
+  gemm_nt_mainloop<T>(a.W, ldw, a.N, a.X, ldx, a.rows, klen, n0, t0, smem, acc, w, kbeg);
 
   // ---- epilogue.  The operand buffers are dead: park the tile's bias slice in LDS (no vmcnt round trip per
   // register quad), issue all residual loads of a 32-token column block up front, then convert and store. ----
   __syncthreads();
   float* sbias = (float*)smem;
-  for (int i = threadIdx.x; i < T::TR; i += T::THREADS) sbias[i] = n0 + i < a.N ? a.bias[n0 + i] : 0.f;
+  for (int i = threadIdx.x; i < T::TR; i += T::THREADS) sbias[i] = (a.bias && n0 + i < a.N) ? a.bias[n0 + i] : 0.f;
   __syncthreads();
   const bool full_n = n0 + T::TR <= a.N;  // workgroup-uniform: no per-quad feature bound checks on the fast path
 #pragma unroll
@@ -280,15 +306,17 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a) {
     const bool t_ok = t < a.rows;
     const int64_t tc = t_ok ? t : a.rows - 1;
     uint2 res[T::MT][4];
-    if constexpr (EPI == EPI_RESID_F32) {
+    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_DGELU_BF16) {
+      if (EPI == EPI_DGELU_BF16 || a.Rf == nullptr) {
 #pragma unroll
-      for (int mt = 0; mt < T::MT; ++mt)
+        for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          int f = n0 + w.r_base(mt, g);
-          f = (full_n || f < a.N) ? f : a.N - 4;
-          res[mt][g] = *(const uint2*)(a.R + tc * a.N + f);
-        }
+          for (int g = 0; g < 4; ++g) {
+            int f = n0 + w.r_base(mt, g);
+            f = (full_n || f < a.N) ? f : a.N - 4;
+            res[mt][g] = *(const uint2*)(a.R + tc * a.N + f);
+          }
+      }
     }
 #pragma unroll
     for (int mt = 0; mt < T::MT; ++mt)
@@ -299,16 +327,30 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a) {
         const f32x16& v = acc.c[mt][nt];
         const float4 bv = *(const float4*)(sbias + fl);
         float y0 = v[4 * g + 0] + bv.x, y1 = v[4 * g + 1] + bv.y, y2 = v[4 * g + 2] + bv.z, y3 = v[4 * g + 3] + bv.w;
-        if constexpr (EPI == EPI_GELU_BF16) {
+        float p0 = y0, p1 = y1, p2 = y2, p3 = y3;  // pre-activation
+        if constexpr (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_SAVE) {
           y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3);
         }
-        if constexpr (EPI == EPI_RESID_F32) {
+        if constexpr (EPI == EPI_DGELU_BF16) {
           const uint2 r = res[mt][g];
-          y0 += __uint_as_float(r.x << 16); y1 += __uint_as_float(r.x & 0xffff0000u);
-          y2 += __uint_as_float(r.y << 16); y3 += __uint_as_float(r.y & 0xffff0000u);
+          y0 *= gelu_grad(__uint_as_float(r.x << 16)); y1 *= gelu_grad(__uint_as_float(r.x & 0xffff0000u));
+          y2 *= gelu_grad(__uint_as_float(r.y << 16)); y3 *= gelu_grad(__uint_as_float(r.y & 0xffff0000u));
+        }
+        if constexpr (EPI == EPI_RESID_F32) {
+          if (a.Rf) {
+            const int fc = (full_n || f < a.N) ? f : a.N - 4;
+            const float4 r = *(const float4*)(a.Rf + tc * a.N + fc);
+            y0 += r.x; y1 += r.y; y2 += r.z; y3 += r.w;
+          } else {
+            const uint2 r = res[mt][g];
+            y0 += __uint_as_float(r.x << 16); y1 += __uint_as_float(r.x & 0xffff0000u);
+            y2 += __uint_as_float(r.y << 16); y3 += __uint_as_float(r.y & 0xffff0000u);
+          }
         }
         if (t_ok && (full_n || f < a.N)) {
-          if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_F32) {
+          if constexpr (EPI == EPI_SLAB_F32) {
+            *(float4*)(a.Cf + ((int64_t)blockIdx.y * a.rows + t) * a.N + f) = make_float4(y0, y1, y2, y3);
+          } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_F32) {
             *(float4*)(a.Cf + t * a.N + f) = make_float4(y0, y1, y2, y3);
           } else {
             uint2 o;
@@ -319,6 +361,12 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a) {
               *(uint2*)dst = o;
             } else {
               *(uint2*)(a.Cb + t * a.N + f) = o;
+              if constexpr (EPI == EPI_GELU_SAVE) {
+                uint2 o2;
+                o2.x = pack_bf16x2(p0, p1);
+                o2.y = pack_bf16x2(p2, p3);
+                *(uint2*)(a.Cb2 + t * a.N + f) = o2;
+              }
             }
           }
         }
@@ -343,6 +391,7 @@ struct AttnArgs {
   int64_t ldt;
   const int32_t *cu, *lens;
   int H;
+  int64_t ldq;      // row stride of Q and K in elements (H, or 3H when they live in a fused [rows, 3H] buffer)
   bf16_t* ctx;
   float* lse;       // [heads, ldt] or nullptr
   float scale;      // 1 / sqrt(head_dim)
@@ -350,7 +399,7 @@ struct AttnArgs {
 
 constexpr int ATT_SMEM_BYTES = 2 * 64 * 128;  // K tile + V^T tile, 8 KB each
 
-__global__ void __launch_bounds__(256) k_attention_fwd(const AttnArgs a) {
+static __global__ void __launch_bounds__(256) k_attention_fwd(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sV = smem + 64 * 128;
@@ -368,7 +417,7 @@ __global__ void __launch_bounds__(256) k_attention_fwd(const AttnArgs a) {
 
   bf16x8 qf[4];
   {
-    const bf16_t* qp = a.Q + (base + qc) * H + h * 64 + 8 * hi;
+    const bf16_t* qp = a.Q + (base + qc) * a.ldq + h * 64 + 8 * hi;
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
   }
@@ -389,7 +438,7 @@ __global__ void __launch_bounds__(256) k_attention_fwd(const AttnArgs a) {
       const int r0 = (i * 4 + wave) * 8;
       const int row = r0 + (lane >> 3);
       const int gch = (lane & 7) ^ ((row >> 1) & 7);
-      glds16((const char*)(a.K + (base + kv0 + row) * H + h * 64) + gch * 16, sK + r0 * 128);
+      glds16((const char*)(a.K + (base + kv0 + row) * a.ldq + h * 64) + gch * 16, sK + r0 * 128);
       glds16((const char*)(a.Vt + (int64_t)(h * 64 + row) * a.ldt + base + kv0) + gch * 16, sV + r0 * 128);
     }
     lds_dma_wait_all();  // explicit: hipcc's automatic vmcnt wait for LDS-DMA is not reliable (gemm_nt.hpp)
@@ -470,7 +519,7 @@ __global__ void __launch_bounds__(256) k_attention_fwd(const AttnArgs a) {
 }
 
 // fp32 rows -> bf16 rows (weight packing at load / after each optimizer step)
-__global__ void __launch_bounds__(256) k_cast_f32_bf16(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n4) {
+static __global__ void __launch_bounds__(256) k_cast_f32_bf16(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 v = *(const float4*)(x + 4 * i);
     uint2 o;

@@ -105,7 +105,10 @@ template <class T>
 __device__ __forceinline__ void gemm_nt_mainloop(const bf16_t* __restrict__ R, int64_t ldr, int64_t nR,
                                                  const bf16_t* __restrict__ L, int64_t ldl, int64_t nL, int K,
                                                  int64_t r0, int64_t l0, char* smem, GemmAcc<T>& acc,
-                                                 const WavePos<T>& w) {
+                                                 const WavePos<T>& w, int k_begin = 0) {
+  // contraction range [k_begin, k_begin + K): split-K callers pass a slice
+  R += k_begin;
+  L += k_begin;
   char* sR = smem;
   char* sL = smem + 2 * T::R_BYTES;
   const int nk = K / GEMM_BK;

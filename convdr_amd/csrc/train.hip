@@ -1,0 +1,437 @@
+// Training path of the dual encoder: forward that keeps activations, full backward, losses, grad-norm clip and
+// HF-AdamW.  Replaces, for the student model, what
+//   embs = model(concat_ids, concat_id_mask) ... loss.backward() ... clip_grad_norm_ ... optimizer.step()
+// (/root/reference/drivers/run_convdr_train.py:109-191) execute through torch autograd + HF AdamW.
+#include "gemm_launch.hpp"
+#include "train_kernels.hpp"
+
+#include "../../include/convdr_hip.h"
+
+namespace convdr {
+
+struct LayerSave {
+  bf16_t *Xin, *QKV, *QKVt, *ctx, *X1, *Hpre, *Hm;
+  float *LSE, *Y1, *Y2;
+};
+
+struct TrainBufs {
+  int32_t *tok_id, *tok_pos;
+  LayerSave* L;  // host array (inside the plan object)
+  bf16_t *Xout, *cls_b;
+  float *cls_y, *cls_f, *head_y;
+  // backward scratch
+  float *G0, *G1, *Drow, *slab, *part, *dcls_y, *dcls_f, *dhead_y;
+  bf16_t *dYb, *dYt, *dHpre, *dHpre_t, *dctx, *dctx_t, *dQKV, *dQKVt, *actT, *dhead_yb, *dhead_yt, *cls_bt, *dclsb;
+  int64_t ldt, Tp;
+  size_t slab_elems;
+  size_t total;
+};
+
+constexpr int TRAIN_MAX_LAYERS = 48;
+constexpr int LN_BWD_BLOCKS = 256;
+constexpr size_t SLAB_ELEMS = (size_t)16 * 3072 * 768;  // >= splits * N * K for every weight of a base-size model
+
+struct TrainPlan {
+  TrainBufs b;
+  LayerSave layers[TRAIN_MAX_LAYERS];
+};
+
+static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char* base, TrainPlan& P) {
+  TrainBufs& p = P.b;
+  p.L = P.layers;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return base + at; };
+  const int H = c->hidden, I = c->intermediate;
+  const int64_t rs = rows + 128;
+  p.Tp = (int64_t)align_up((size_t)rows, 64);
+  p.ldt = p.Tp + 64;
+  p.tok_id = (int32_t*)take(rs * 4);
+  p.tok_pos = (int32_t*)take(rs * 4);
+  for (int l = 0; l < c->layers; ++l) {
+    LayerSave& s = P.layers[l];
+    s.Xin = (bf16_t*)take(rs * H * 2);
+    s.QKV = (bf16_t*)take(rs * 3 * H * 2);
+    s.QKVt = (bf16_t*)take((size_t)3 * H * p.ldt * 2);
+    s.ctx = (bf16_t*)take(rs * H * 2);
+    s.X1 = (bf16_t*)take(rs * H * 2);
+    s.Hpre = (bf16_t*)take(rs * I * 2);
+    s.Hm = (bf16_t*)take(rs * I * 2);
+    s.LSE = (float*)take((size_t)c->heads * p.ldt * 4);
+    s.Y1 = (float*)take(rs * H * 4);
+    s.Y2 = (float*)take(rs * H * 4);
+  }
+  const int64_t Bp = B + 128;
+  const int64_t Bt = (int64_t)align_up((size_t)B, 64) + 64;
+  const int E = c->out_dim > 0 ? c->out_dim : 4;
+  p.Xout = (bf16_t*)take(rs * H * 2);
+  p.cls_b = (bf16_t*)take(Bp * H * 2);
+  p.cls_y = (float*)take(Bp * H * 4);
+  p.cls_f = (float*)take(Bp * H * 4);
+  p.head_y = (float*)take(Bp * E * 4);
+  p.G0 = (float*)take(rs * H * 4);
+  p.G1 = (float*)take(rs * H * 4);
+  p.Drow = (float*)take((size_t)c->heads * p.ldt * 4);
+  p.slab_elems = SLAB_ELEMS;
+  p.slab = (float*)take(p.slab_elems * 4);
+  p.part = (float*)take((size_t)LN_BWD_BLOCKS * 3 * 3072 * 4 + (size_t)16 * 3 * 3072 * 4);
+  p.dcls_y = (float*)take(Bp * H * 4);
+  p.dcls_f = (float*)take(Bp * H * 4);
+  p.dhead_y = (float*)take(Bp * E * 4);
+  p.dYb = (bf16_t*)take(rs * H * 2);
+  p.dYt = (bf16_t*)take((size_t)H * p.ldt * 2);
+  p.dHpre = (bf16_t*)take(rs * I * 2);
+  p.dHpre_t = (bf16_t*)take((size_t)I * p.ldt * 2);
+  p.dctx = (bf16_t*)take(rs * H * 2);
+  p.dctx_t = (bf16_t*)take((size_t)H * p.ldt * 2);
+  p.dQKV = (bf16_t*)take(rs * 3 * H * 2);
+  p.dQKVt = (bf16_t*)take((size_t)3 * H * p.ldt * 2);
+  p.actT = (bf16_t*)take((size_t)I * p.ldt * 2);
+  p.dhead_yb = (bf16_t*)take(Bp * E * 2);
+  p.dhead_yt = (bf16_t*)take((size_t)E * Bt * 2);
+  p.cls_bt = (bf16_t*)take((size_t)H * Bt * 2);
+  p.dclsb = (bf16_t*)take(Bp * H * 2);
+  p.total = o;
+}
+
+static int check_train_config(const convdr_encoder_config* c) {
+  CONVDR_REQUIRE(c->hidden % 128 == 0 && c->hidden <= 1024 && c->heads * 64 == c->hidden,
+                 "train: hidden must be a multiple of 128 (<= 1024) with head_dim 64 (hidden=%d heads=%d)", c->hidden,
+                 c->heads);
+  CONVDR_REQUIRE(c->intermediate % 64 == 0 && c->intermediate <= 3072 * 2 && c->layers <= TRAIN_MAX_LAYERS,
+                 "train: unsupported intermediate/layers (%d, %d)", c->intermediate, c->layers);
+  CONVDR_REQUIRE(c->out_dim == 0 || (c->out_dim % 64 == 0 && c->out_dim <= 1024), "train: out_dim %% 64 != 0 (%d)",
+                 c->out_dim);
+  return 0;
+}
+
+static int transpose(const bf16_t* in, int64_t rows, int C, int64_t ld_in, bf16_t* out, int64_t ldt, hipStream_t st) {
+  ProfScope prof("transpose", st);
+  hipLaunchKernelGGL(k_transpose_bf16, dim3((C + 63) / 64, (unsigned)(ldt / 64)), dim3(256), 0, st, in, rows, C, ld_in, out,
+                     ldt, ldt);
+  CONVDR_CHECK_LAUNCH("k_transpose_bf16");
+  return 0;
+}
+
+// dW[n, k] (+)= sum_t dY[t, n] X[t, k] from the transposed operands dYt [N, ldt], Xt [K, ldt] (zero beyond the rows)
+static int wgrad(const bf16_t* dYt, int N, const bf16_t* Xt, int K, int64_t Tp, int64_t ldt, const TrainBufs& p, float* dW,
+                 hipStream_t st) {
+  const int64_t tiles = (int64_t)((N + 255) / 256) * ((K + 255) / 256);
+  int splits = (int)(Tp / 64);  // number of 64-wide contraction chunks
+  int want = (int)((320 + tiles - 1) / tiles);
+  int chunks = (splits + want - 1) / want;  // chunks of 64 per split
+  if (chunks < 1) chunks = 1;
+  while (splits % chunks) ++chunks;
+  int nsplit = splits / chunks;
+  while ((size_t)nsplit * N * K > p.slab_elems && nsplit > 1) {  // stay inside the slab arena
+    ++chunks;
+    while (splits % chunks) ++chunks;
+    nsplit = splits / chunks;
+  }
+  CONVDR_REQUIRE((size_t)nsplit * N * K <= p.slab_elems, "wgrad: slab arena too small for %d x %d", N, K);
+  GemmArgs g{};
+  g.W = Xt; g.ldw = ldt; g.N = K;          // R operand: k index -> contiguous output index
+  g.X = dYt; g.ldx = ldt; g.rows = N;      // L operand: n index -> output row
+  g.K = (int)Tp; g.k_split_len = chunks * 64;
+  g.Cf = p.slab;
+  if (int e = launch_gemm<EPI_SLAB_F32>(g, st, "gemm_wgrad")) return e;
+  const int64_t n = (int64_t)N * K;
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)(ceil_div64(n, 256) < 2048 ? ceil_div64(n, 256) : 2048)), dim3(256), 0,
+                     st, p.slab, nsplit, n, n, dW, 1);
+  CONVDR_CHECK_LAUNCH("k_reduce_partials");
+  return 0;
+}
+
+static int bias_grad(const bf16_t* dY, int64_t rows, int C, const TrainBufs& p, float* db, hipStream_t st) {
+  float* part = p.part + (size_t)LN_BWD_BLOCKS * 3 * 3072;
+  hipLaunchKernelGGL(k_colsum_bf16, dim3((C + 255) / 256, 16), dim3(256), 0, st, dY, rows, C, part);
+  CONVDR_CHECK_LAUNCH("k_colsum_bf16");
+  hipLaunchKernelGGL(k_reduce_partials, dim3((C + 255) / 256), dim3(256), 0, st, part, 16, (int64_t)C, (int64_t)C, db, 1);
+  CONVDR_CHECK_LAUNCH("k_reduce_partials(bias)");
+  return 0;
+}
+
+static int ln_bwd(const float* dY, const float* Yin, int64_t rows, int H, const float* g, float eps, float* dXf, bf16_t* dXb,
+                  const TrainBufs& p, float* dgamma, float* dbeta, hipStream_t st) {
+  const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
+  ProfScope prof("layernorm_bwd", st);
+  hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, Yin, rows, H, g, eps, dXf, dXb, p.part);
+  CONVDR_CHECK_LAUNCH("k_layernorm_bwd");
+  hipLaunchKernelGGL(k_reduce_partials, dim3((H + 255) / 256), dim3(256), 0, st, p.part, blocks, (int64_t)2 * H, (int64_t)H,
+                     dgamma, 1);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((H + 255) / 256), dim3(256), 0, st, p.part + H, blocks, (int64_t)2 * H,
+                     (int64_t)H, dbeta, 1);
+  CONVDR_CHECK_LAUNCH("k_reduce_partials(ln)");
+  return 0;
+}
+
+}  // namespace convdr
+
+using namespace convdr;
+
+extern "C" size_t convdr_encoder_train_workspace_bytes(const convdr_encoder_config* cfg, int64_t rows, int B) {
+  if (cfg->layers > TRAIN_MAX_LAYERS) return 0;
+  TrainPlan P;
+  train_plan(cfg, rows, B, nullptr, P);
+  return P.b.total;
+}
+
+extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, const convdr_encoder_weights* w,
+                                            const void* input_ids, int ids_are_int32, const int64_t* attention_mask, int B,
+                                            int L, const int32_t* cu_seqlens, const int32_t* seq_lens, int64_t rows,
+                                            int max_len, void* workspace, size_t workspace_bytes, float* out,
+                                            convdr_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = check_train_config(cfg)) return e;
+  CONVDR_REQUIRE(B > 0 && L > 0 && rows > 0 && rows % 8 == 0 && max_len > 0 && max_len <= L,
+                 "convdr_encoder_train_forward: bad sizes B=%d L=%d rows=%lld max_len=%d", B, L, (long long)rows, max_len);
+  TrainPlan P;
+  train_plan(cfg, rows, B, (char*)workspace, P);
+  const TrainBufs& p = P.b;
+  CONVDR_REQUIRE(workspace_bytes >= p.total, "convdr_encoder_train_forward: workspace too small (%zu < %zu)",
+                 workspace_bytes, p.total);
+  const int H = cfg->hidden, I = cfg->intermediate;
+  hipLaunchKernelGGL(k_seq_pack, dim3((B + 3) / 4), dim3(256), 0, st, input_ids, ids_are_int32, attention_mask, seq_lens, B, L,
+                     cu_seqlens, cfg->kind, cfg->pad_idx, cfg->max_pos, p.tok_id, p.tok_pos);
+  CONVDR_CHECK_LAUNCH("k_seq_pack");
+  hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.tok_id, p.tok_pos, rows, H,
+                     w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, cfg->ln_eps, P.layers[0].Xin);
+  CONVDR_CHECK_LAUNCH("k_embed_ln");
+  for (int l = 0; l < cfg->layers; ++l) {
+    const convdr_layer_weights* lw = &w->layers[l];
+    const LayerSave& s = P.layers[l];
+    GemmArgs g{};
+    g.rows = rows; g.W = (const bf16_t*)lw->wqkv; g.X = s.Xin; g.N = 3 * H; g.K = H; g.bias = lw->bqkv; g.Cb = s.QKV;
+    if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_qkv")) return e;
+    if (int e = transpose(s.QKV, rows, 3 * H, 3 * H, s.QKVt, p.ldt, st)) return e;
+    {
+      AttnArgs a{s.QKV, s.QKV + H, s.QKVt + (size_t)2 * H * p.ldt, p.ldt, cu_seqlens, seq_lens, H, (int64_t)3 * H, s.ctx,
+                 s.LSE, 0.125f};
+      ProfScope prof("attention", st);
+      hipLaunchKernelGGL(k_attention_fwd, dim3((max_len + 127) / 128, cfg->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
+      CONVDR_CHECK_LAUNCH("k_attention_fwd");
+    }
+    g = GemmArgs{};
+    g.rows = rows; g.W = (const bf16_t*)lw->wo; g.X = s.ctx; g.N = H; g.K = H; g.bias = lw->bo; g.Cf = s.Y1; g.R = s.Xin;
+    if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_attn_out")) return e;
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, s.Y1, rows, H, lw->ln1_g, lw->ln1_b,
+                       cfg->ln_eps, s.X1, (float*)nullptr);
+    CONVDR_CHECK_LAUNCH("k_layernorm");
+    g = GemmArgs{};
+    g.rows = rows; g.W = (const bf16_t*)lw->w1; g.X = s.X1; g.N = I; g.K = H; g.bias = lw->b1; g.Cb = s.Hm; g.Cb2 = s.Hpre;
+    if (int e = launch_gemm<EPI_GELU_SAVE>(g, st, "gemm_ffn1")) return e;
+    g = GemmArgs{};
+    g.rows = rows; g.W = (const bf16_t*)lw->w2; g.X = s.Hm; g.N = H; g.K = I; g.bias = lw->b2; g.Cf = s.Y2; g.R = s.X1;
+    if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_ffn2")) return e;
+    if (l + 1 < cfg->layers) {
+      hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, s.Y2, rows, H, lw->ln2_g, lw->ln2_b,
+                         cfg->ln_eps, P.layers[l + 1].Xin, (float*)nullptr);
+      CONVDR_CHECK_LAUNCH("k_layernorm");
+    } else {
+      hipLaunchKernelGGL(k_gather_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, (const bf16_t*)nullptr, s.Y2,
+                         (bf16_t*)nullptr, p.cls_y);
+      float* cls_out = cfg->out_dim > 0 ? p.cls_f : out;
+      hipLaunchKernelGGL(k_layernorm, dim3((B + 3) / 4), dim3(256), 0, st, p.cls_y, (int64_t)B, H, lw->ln2_g, lw->ln2_b,
+                         cfg->ln_eps, p.cls_b, cls_out);
+      CONVDR_CHECK_LAUNCH("k_layernorm(cls)");
+    }
+  }
+  if (cfg->out_dim > 0) {
+    GemmArgs g{};
+    g.rows = B; g.W = (const bf16_t*)w->head_w; g.X = p.cls_b; g.N = cfg->out_dim; g.K = H; g.bias = w->head_b; g.Cf = p.head_y;
+    if (int e = launch_gemm<EPI_F32>(g, st, "gemm_head")) return e;
+    hipLaunchKernelGGL(k_layernorm, dim3((B + 3) / 4), dim3(256), 0, st, p.head_y, (int64_t)B, cfg->out_dim, w->head_ln_g,
+                       w->head_ln_b, cfg->head_ln_eps, (bf16_t*)nullptr, out);
+    CONVDR_CHECK_LAUNCH("k_layernorm(head)");
+  }
+  return 0;
+}
+
+extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const convdr_encoder_weights* w,
+                                       const convdr_layer_weights_t* wt, const int32_t* cu_seqlens, const int32_t* seq_lens,
+                                       const void* head_w_t, int B, int64_t rows, int max_len, void* workspace,
+                                       size_t workspace_bytes, const float* d_out, const convdr_encoder_grads* gr,
+                                       convdr_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = check_train_config(cfg)) return e;
+  TrainPlan P;
+  train_plan(cfg, rows, B, (char*)workspace, P);
+  const TrainBufs& p = P.b;
+  CONVDR_REQUIRE(workspace_bytes >= p.total, "convdr_encoder_backward: workspace too small (%zu < %zu)", workspace_bytes,
+                 p.total);
+  const int H = cfg->hidden, I = cfg->intermediate, NL = cfg->layers;
+  const int64_t Bt = (int64_t)align_up((size_t)B, 64) + 64;
+  const convdr_layer_grads* lg_last = &gr->layers[NL - 1];
+  const float* dcls = d_out;  // gradient w.r.t. LayerNorm2(cls rows) of the last layer
+
+  // ---- head: out = LayerNorm(head_y), head_y = cls_b . head_w^T + head_b ----
+  if (cfg->out_dim > 0) {
+    const int E = cfg->out_dim;
+    if (int e = ln_bwd(d_out, p.head_y, B, E, w->head_ln_g, cfg->head_ln_eps, p.dhead_y, p.dhead_yb, p, gr->head_ln_g,
+                       gr->head_ln_b, st))
+      return e;
+    if (int e = bias_grad(p.dhead_yb, B, E, p, gr->head_b, st)) return e;
+    // d cls = d head_y . head_w : dgrad with the transposed head weight [H, E]
+    GemmArgs g{};
+    g.rows = B; g.W = (const bf16_t*)head_w_t; g.X = p.dhead_yb; g.N = H; g.K = E; g.Cf = p.dcls_f;
+    if (int e = launch_gemm<EPI_F32>(g, st, "gemm_dgrad")) return e;
+    // d head_w [E, H] = d head_y^T . cls_b
+    if (int e = transpose(p.dhead_yb, B, E, E, p.dhead_yt, Bt, st)) return e;
+    if (int e = transpose(p.cls_b, B, H, H, p.cls_bt, Bt, st)) return e;
+    if (int e = wgrad(p.dhead_yt, E, p.cls_bt, H, Bt - 64, Bt, p, gr->head_w, st)) return e;
+    dcls = p.dcls_f;
+  }
+  // ---- last layer's LayerNorm2 on the CLS rows only, scattered into a zero [rows, H] gradient ----
+  if (int e = ln_bwd(dcls, p.cls_y, B, H, w->layers[NL - 1].ln2_g, cfg->ln_eps, p.dcls_y, (bf16_t*)nullptr, p, lg_last->ln2_g,
+                     lg_last->ln2_b, st))
+    return e;
+  CONVDR_CHECK_HIP(hipMemsetAsync(p.G0, 0, (size_t)rows * H * 4, st));
+  hipLaunchKernelGGL(k_scatter_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, p.dcls_y, p.G0);
+  CONVDR_CHECK_LAUNCH("k_scatter_cls");
+
+  float* A = p.G0;   // holds the gradient flowing down the residual stream
+  float* Bf = p.G1;  // scratch
+  for (int l = NL - 1; l >= 0; --l) {
+    const convdr_layer_weights* lw = &w->layers[l];
+    const convdr_layer_weights_t* lt = &wt[l];
+    const convdr_layer_grads* lg = &gr->layers[l];
+    const LayerSave& s = P.layers[l];
+    const bool last = l == NL - 1;
+    // A = d(pre-LN2 sum Y2) for the last layer (CLS rows only), d(layer output) otherwise
+    float *dY2, *dX1, *dY1, *dXin;
+    if (!last) {
+      if (int e = ln_bwd(A, s.Y2, rows, H, lw->ln2_g, cfg->ln_eps, Bf, p.dYb, p, lg->ln2_g, lg->ln2_b, st)) return e;
+      dY2 = Bf; dX1 = A; dY1 = Bf; dXin = A;
+    } else {
+      hipLaunchKernelGGL(k_cast_f32_bf16, dim3(1024), dim3(256), 0, st, A, p.dYb, (int64_t)rows * H / 4);
+      CONVDR_CHECK_LAUNCH("k_cast_f32_bf16");
+      dY2 = A; dX1 = Bf; dY1 = A; dXin = Bf;
+    }
+    // ---- FFN2: Y2 = Hm W2^T + b2 + X1 ----
+    if (int e = bias_grad(p.dYb, rows, H, p, lg->b2, st)) return e;
+    if (int e = transpose(p.dYb, rows, H, H, p.dYt, p.ldt, st)) return e;
+    if (int e = transpose(s.Hm, rows, I, I, p.actT, p.ldt, st)) return e;
+    if (int e = wgrad(p.dYt, H, p.actT, I, p.Tp, p.ldt, p, lg->w2, st)) return e;
+    GemmArgs g{};
+    g.rows = rows; g.W = (const bf16_t*)lt->w2_t; g.X = p.dYb; g.N = I; g.K = H; g.Cb = p.dHpre; g.R = s.Hpre;
+    if (int e = launch_gemm<EPI_DGELU_BF16>(g, st, "gemm_dgrad")) return e;   // dHpre = (dY2 W2) * gelu'(Hpre)
+    // ---- FFN1: Hpre = X1 W1^T + b1;  dX1 = dHpre W1 + dY2 (residual branch, fp32) ----
+    if (int e = bias_grad(p.dHpre, rows, I, p, lg->b1, st)) return e;
+    if (int e = transpose(p.dHpre, rows, I, I, p.dHpre_t, p.ldt, st)) return e;
+    if (int e = transpose(s.X1, rows, H, H, p.actT, p.ldt, st)) return e;
+    if (int e = wgrad(p.dHpre_t, I, p.actT, H, p.Tp, p.ldt, p, lg->w1, st)) return e;
+    g = GemmArgs{};
+    g.rows = rows; g.W = (const bf16_t*)lt->w1_t; g.X = p.dHpre; g.N = H; g.K = I; g.Cf = dX1; g.Rf = dY2;
+    if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_dgrad")) return e;
+    // ---- LayerNorm1 ----
+    if (int e = ln_bwd(dX1, s.Y1, rows, H, lw->ln1_g, cfg->ln_eps, dY1, p.dYb, p, lg->ln1_g, lg->ln1_b, st)) return e;
+    // ---- attention output projection: Y1 = ctx Wo^T + bo + Xin ----
+    if (int e = bias_grad(p.dYb, rows, H, p, lg->bo, st)) return e;
+    if (int e = transpose(p.dYb, rows, H, H, p.dYt, p.ldt, st)) return e;
+    if (int e = transpose(s.ctx, rows, H, H, p.actT, p.ldt, st)) return e;
+    if (int e = wgrad(p.dYt, H, p.actT, H, p.Tp, p.ldt, p, lg->wo, st)) return e;
+    g = GemmArgs{};
+    g.rows = rows; g.W = (const bf16_t*)lt->wo_t; g.X = p.dYb; g.N = H; g.K = H; g.Cb = p.dctx;
+    if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
+    // ---- attention ----
+    if (int e = transpose(p.dctx, rows, H, H, p.dctx_t, p.ldt, st)) return e;
+    hipLaunchKernelGGL(k_attn_rowdot, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.dctx, s.ctx, rows, H, p.Drow,
+                       p.ldt);
+    CONVDR_CHECK_LAUNCH("k_attn_rowdot");
+    {
+      AttnBwdArgs a{s.QKV, s.QKVt, p.dctx, p.dctx_t, s.LSE, p.Drow, p.ldt, cu_seqlens, seq_lens, H, p.dQKV, 0.125f};
+      static bool attr_done = false;
+      if (!attr_done) {
+        CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_attention_bwd_dkv, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             4 * ATTB_TILE + 512));
+        attr_done = true;
+      }
+      ProfScope prof("attention_bwd", st);
+      const dim3 grid((max_len + 127) / 128, cfg->heads, B);
+      hipLaunchKernelGGL(k_attention_bwd_dq, grid, dim3(256), 3 * ATTB_TILE, st, a);
+      hipLaunchKernelGGL(k_attention_bwd_dkv, grid, dim3(256), 4 * ATTB_TILE + 512, st, a);
+      CONVDR_CHECK_LAUNCH("k_attention_bwd");
+    }
+    // ---- QKV projection: QKV = Xin Wqkv^T + bqkv;  dXin = dQKV Wqkv + dY1 (residual branch, fp32) ----
+    if (int e = bias_grad(p.dQKV, rows, 3 * H, p, lg->bqkv, st)) return e;
+    if (int e = transpose(p.dQKV, rows, 3 * H, 3 * H, p.dQKVt, p.ldt, st)) return e;
+    if (int e = transpose(s.Xin, rows, H, H, p.actT, p.ldt, st)) return e;
+    if (int e = wgrad(p.dQKVt, 3 * H, p.actT, H, p.Tp, p.ldt, p, lg->wqkv, st)) return e;
+    g = GemmArgs{};
+    g.rows = rows; g.W = (const bf16_t*)lt->wqkv_t; g.X = p.dQKV; g.N = H; g.K = 3 * H; g.Cf = dXin; g.Rf = dY1;
+    if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_dgrad")) return e;
+    if (dXin != A) { float* t = A; A = Bf; Bf = t; }   // A again holds the stream gradient (now d Xin = d output of layer l-1)
+  }
+  // ---- embeddings ----
+  {
+    const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
+    hipLaunchKernelGGL(k_embed_bwd, dim3(blocks), dim3(256), 0, st, A, p.tok_id, p.tok_pos, rows, H, w->word_emb, w->pos_emb,
+                       w->type_emb, w->emb_ln_g, cfg->ln_eps, gr->word_emb, gr->pos_emb, p.part);
+    CONVDR_CHECK_LAUNCH("k_embed_bwd");
+    float* outs[3] = {gr->emb_ln_g, gr->emb_ln_b, gr->type_emb};
+    for (int k = 0; k < 3; ++k) {
+      hipLaunchKernelGGL(k_reduce_partials, dim3((H + 255) / 256), dim3(256), 0, st, p.part + (size_t)k * H, blocks,
+                         (int64_t)3 * H, (int64_t)H, outs[k], 1);
+    }
+    CONVDR_CHECK_LAUNCH("k_reduce_partials(embed)");
+  }
+  return 0;
+}
+
+// fp32 [n, k] row-major -> bf16 [k, n]
+extern "C" int convdr_transpose_f32_bf16(const float* x, int n, int k, void* y, convdr_stream_t stream) {
+  hipLaunchKernelGGL(k_transpose_f32_bf16, dim3((k + 63) / 64, (n + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, n, k,
+                     (bf16_t*)y);
+  CONVDR_CHECK_LAUNCH("k_transpose_f32_bf16");
+  return 0;
+}
+
+extern "C" int convdr_mse_fwd_bwd(const float* s, const float* t, int64_t n, float grad_scale, float* loss, float* ds,
+                                  convdr_stream_t stream) {
+  CONVDR_REQUIRE(n > 0, "convdr_mse_fwd_bwd: n = %lld", (long long)n);
+  hipLaunchKernelGGL(k_mse_fwd_bwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, s, t, n, grad_scale, loss, ds);
+  CONVDR_CHECK_LAUNCH("k_mse_fwd_bwd");
+  return 0;
+}
+
+extern "C" int convdr_rank_ce_fwd_bwd(const float* embs, const float* docs, int B, int K, int E, float grad_scale,
+                                      float* loss_per_query, float* d_embs, int accumulate, convdr_stream_t stream) {
+  CONVDR_REQUIRE(B > 0 && K > 0 && K <= 64 && E > 0, "convdr_rank_ce_fwd_bwd: bad sizes B=%d K=%d E=%d", B, K, E);
+  hipLaunchKernelGGL(k_rank_ce_fwd_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, embs, docs, B, K, E, grad_scale,
+                     loss_per_query, d_embs, accumulate);
+  CONVDR_CHECK_LAUNCH("k_rank_ce_fwd_bwd");
+  return 0;
+}
+
+extern "C" int convdr_grad_norm_clip(float* grads, int64_t n, float max_norm, float* scratch /* >= 1024 floats */,
+                                     float* norm_and_coef /* [2] */, int apply, convdr_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)(ceil_div64(n, 256) < 1024 ? ceil_div64(n, 256) : 1024);
+  hipLaunchKernelGGL(k_sumsq_partial, dim3(blocks), dim3(256), 0, st, grads, n, scratch);
+  hipLaunchKernelGGL(k_norm_finish, dim3(1), dim3(64), 0, st, scratch, blocks, max_norm, norm_and_coef);
+  if (apply) hipLaunchKernelGGL(k_scale_inplace, dim3(blocks), dim3(256), 0, st, grads, n, norm_and_coef + 1);
+  CONVDR_CHECK_LAUNCH("convdr_grad_norm_clip");
+  return 0;
+}
+
+extern "C" int convdr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                                 double beta2, double eps, double weight_decay, int step, int correct_bias,
+                                 const float* grad_scale, convdr_stream_t stream) {
+  CONVDR_REQUIRE(n >= 0 && step >= 1, "convdr_adamw_step: bad n/step");
+  if (n == 0) return 0;
+  double step_size = lr;
+  if (correct_bias) step_size = lr * sqrt(1.0 - pow(beta2, (double)step)) / (1.0 - pow(beta1, (double)step));
+  const int blocks = (int)(ceil_div64(n, 256) < 4096 ? ceil_div64(n, 256) : 4096);
+  hipLaunchKernelGGL(k_adamw_hf, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)beta1,
+                     (float)beta2, (float)eps, (float)weight_decay, (float)step_size, grad_scale);
+  CONVDR_CHECK_LAUNCH("k_adamw_hf");
+  return 0;
+}
+
+// x[i] *= scale[0] (device scalar)
+extern "C" int convdr_scale_f32(float* x, int64_t n, const float* scale, convdr_stream_t stream) {
+  if (n <= 0) return 0;
+  const int blocks = (int)(ceil_div64(n, 256) < 2048 ? ceil_div64(n, 256) : 2048);
+  hipLaunchKernelGGL(k_scale_inplace, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, scale);
+  CONVDR_CHECK_LAUNCH("k_scale_inplace");
+  return 0;
+}

@@ -1,0 +1,641 @@
+// Backward-pass kernels of the dual-encoder training step on gfx950.
+//
+// Replaces what `loss.backward()` (/root/reference/drivers/run_convdr_train.py:178) runs through torch autograd
+// for the student encoder: LayerNorm / GELU / attention / embedding backward and the data-layout helpers the
+// dgrad / wgrad MFMA GEMMs need.  All dense contractions reuse the NT tile engine (gemm_nt.hpp):
+//   dgrad  dX[t,k]  = sum_n dY[t,n] W[n,k]    -> operands dY [rows,N] and W^T [K,N]   (W^T kept packed)
+//   wgrad  dW[n,k]  = sum_t dY[t,n] X[t,k]    -> operands X^T [K,Tp] and dY^T [N,Tp]  (k_transpose_bf16), split over t
+#pragma once
+#include "encoder_kernels.hpp"
+
+namespace convdr {
+
+// ---------------------------------------------------------------------------------------------
+// bf16 [rows, C] (row stride ld_in) -> [C, ldt] transposed; columns t in [rows, tcols) are written as zeros so the
+// result can be used as a zero-padded contraction operand.  64 x 64 tiles through LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_transpose_bf16(const bf16_t* __restrict__ in, int64_t rows, int C,
+                                                        int64_t ld_in, bf16_t* __restrict__ out, int64_t ldt,
+                                                        int64_t tcols) {
+  __shared__ bf16_t tile[64][66];
+  const int c0 = blockIdx.x * 64;
+  const int64_t t0 = (int64_t)blockIdx.y * 64;
+  {
+    const int r = threadIdx.x >> 2, cq = (threadIdx.x & 3) * 16;  // 64 rows x 4 quarter-rows of 16 elements
+    const int64_t t = t0 + r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = cq + 8 * h;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (t < rows && c0 + c < C) v = *(const uint4*)(in + t * ld_in + c0 + c);
+      const bf16_t* e = (const bf16_t*)&v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tile[r][c + j] = e[j];
+    }
+  }
+  __syncthreads();
+  {
+    const int c = threadIdx.x >> 2, tq = (threadIdx.x & 3) * 16;
+    if (c0 + c < C) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int tt = tq + 8 * h;
+        if (t0 + tt < tcols) {
+          bf16_t e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = tile[tt + j][c];
+          *(uint4*)(out + (int64_t)(c0 + c) * ldt + t0 + tt) = *(const uint4*)e;
+        }
+      }
+    }
+  }
+}
+
+// fp32 [n, k] -> bf16 [k, n]  (weight packing for dgrad: W^T)
+__global__ void __launch_bounds__(256) k_transpose_f32_bf16(const float* __restrict__ in, int n, int k,
+                                                            bf16_t* __restrict__ out) {
+  __shared__ float tile[64][65];
+  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (n0 + r < n && k0 + c < k) ? in[(int64_t)(n0 + r) * k + k0 + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;  // out row = k0 + r, col = n0 + c
+    if (k0 + r < k && n0 + c < n) out[(int64_t)(k0 + r) * n + n0 + c] = f32_to_bf16(tile[c][r]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward, one wave per row (grid-stride), H <= 1024.
+//   xhat = (y - mean) * rstd;  gdy = g * dy;  dx = rstd * (gdy - mean(gdy) - xhat * mean(gdy * xhat))
+// Per-workgroup partial sums of dgamma = sum dy * xhat and dbeta = sum dy go to part[block][2][H]
+// (k_reduce_partials adds them into the gradient in a fixed order: deterministic).
+// `rowmap` (optional) gathers the input rows (CLS rows) and `scatter` (optional) redirects the output rows.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__ dY, const float* __restrict__ Yin,
+                                                       int64_t rows, int H, const float* __restrict__ g, float eps,
+                                                       float* __restrict__ dXf, bf16_t* __restrict__ dXb,
+                                                       float* __restrict__ part) {
+  __shared__ float red[4][2][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 ag[4], ab[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { ag[j] = make_float4(0, 0, 0, 0); ab[j] = make_float4(0, 0, 0, 0); }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    float4 y[4], d[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e0 = 256 * j + 4 * lane;
+      if (e0 < H) {
+        y[j] = *(const float4*)(Yin + row * H + e0);
+        d[j] = *(const float4*)(dY + row * H + e0);
+        s += y[j].x + y[j].y + y[j].z + y[j].w;
+      }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (256 * j + 4 * lane < H) {
+        y[j].x -= mean; y[j].y -= mean; y[j].z -= mean; y[j].w -= mean;
+        q += y[j].x * y[j].x + y[j].y * y[j].y + y[j].z * y[j].z + y[j].w * y[j].w;
+      }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e0 = 256 * j + 4 * lane;
+      if (e0 < H) {
+        const float4 gg = *(const float4*)(g + e0);
+        y[j].x *= rstd; y[j].y *= rstd; y[j].z *= rstd; y[j].w *= rstd;  // xhat
+        ab[j].x += d[j].x; ab[j].y += d[j].y; ab[j].z += d[j].z; ab[j].w += d[j].w;
+        ag[j].x += d[j].x * y[j].x; ag[j].y += d[j].y * y[j].y; ag[j].z += d[j].z * y[j].z; ag[j].w += d[j].w * y[j].w;
+        d[j].x *= gg.x; d[j].y *= gg.y; d[j].z *= gg.z; d[j].w *= gg.w;  // g * dy
+        m1 += d[j].x + d[j].y + d[j].z + d[j].w;
+        m2 += d[j].x * y[j].x + d[j].y * y[j].y + d[j].z * y[j].z + d[j].w * y[j].w;
+      }
+    }
+    m1 = wave_sum(m1) / (float)H;
+    m2 = wave_sum(m2) / (float)H;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e0 = 256 * j + 4 * lane;
+      if (e0 < H) {
+        float4 o;
+        o.x = rstd * (d[j].x - m1 - y[j].x * m2);
+        o.y = rstd * (d[j].y - m1 - y[j].y * m2);
+        o.z = rstd * (d[j].z - m1 - y[j].z * m2);
+        o.w = rstd * (d[j].w - m1 - y[j].w * m2);
+        if (dXf) *(float4*)(dXf + row * H + e0) = o;
+        if (dXb) {
+          uint2 p;
+          p.x = pack_bf16x2(o.x, o.y);
+          p.y = pack_bf16x2(o.z, o.w);
+          *(uint2*)(dXb + row * H + e0) = p;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e0 = 256 * j + 4 * lane;
+    if (e0 < H) {
+      *(float4*)&red[wave][0][e0] = ag[j];
+      *(float4*)&red[wave][1][e0] = ab[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * H; i += 256) {
+    const int k = i / H, e = i - k * H;
+    part[((int64_t)blockIdx.x * 2 + k) * H + e] = red[0][k][e] + red[1][k][e] + red[2][k][e] + red[3][k][e];
+  }
+}
+
+// out[e] (+)= sum_p part[p * stride + e], p in fixed order (deterministic)
+__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, int nparts, int64_t stride,
+                                                         int64_t n, float* __restrict__ out, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * stride + i];
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+// column sums of a bf16 matrix [rows, C]: part[chunk][C]; grid (ceil(C/256), chunks)
+__global__ void __launch_bounds__(256) k_colsum_bf16(const bf16_t* __restrict__ in, int64_t rows, int C,
+                                                     float* __restrict__ part) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+  const int64_t t0 = per * blockIdx.y, t1 = t0 + per < rows ? t0 + per : rows;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int64_t t = t0; t < t1; ++t) s += bf16_to_f32(in[t * C + c]);
+  part[(int64_t)blockIdx.y * C + c] = s;
+}
+
+// dst[cu[b], :] = src[b, :] for b < B (dst pre-zeroed): scatter CLS-row gradients into a [rows, H] matrix
+__global__ void __launch_bounds__(256) k_scatter_cls(const int32_t* __restrict__ cu, int B, int H,
+                                                     const float* __restrict__ src, float* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int64_t row = cu[b];
+  for (int e0 = 4 * lane; e0 < H; e0 += 256) *(float4*)(dst + row * H + e0) = *(const float4*)(src + (int64_t)b * H + e0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// embeddings backward: dX0 -> LayerNorm backward (embedding sum recomputed from the tables) -> atomic adds into
+// d_word[id], d_pos[p]; d_type[0] and the LayerNorm dgamma / dbeta go through per-block partials.
+// part[block][3][H] = (dgamma, dbeta, dtype0)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_embed_bwd(const float* __restrict__ dX, const int32_t* __restrict__ tok_id,
+                                                   const int32_t* __restrict__ tok_pos, int64_t rows, int H,
+                                                   const float* __restrict__ word, const float* __restrict__ pos,
+                                                   const float* __restrict__ type0, const float* __restrict__ g,
+                                                   float eps, float* __restrict__ d_word, float* __restrict__ d_pos,
+                                                   float* __restrict__ part) {
+  __shared__ float red[4][3][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 ag[4], ab[4], at[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { ag[j] = make_float4(0, 0, 0, 0); ab[j] = ag[j]; at[j] = ag[j]; }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const int id = tok_id[row];
+    if (id < 0) continue;  // alignment row: no parameters behind it
+    const int pp = tok_pos[row];
+    float4 y[4], d[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e0 = 256 * j + 4 * lane;
+      if (e0 < H) {
+        const float4 a = *(const float4*)(word + (int64_t)id * H + e0), c = *(const float4*)(pos + (int64_t)pp * H + e0),
+                     t = *(const float4*)(type0 + e0);
+        y[j] = make_float4(a.x + c.x + t.x, a.y + c.y + t.y, a.z + c.z + t.z, a.w + c.w + t.w);
+        d[j] = *(const float4*)(dX + row * H + e0);
+        s += y[j].x + y[j].y + y[j].z + y[j].w;
+      }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (256 * j + 4 * lane < H) {
+        y[j].x -= mean; y[j].y -= mean; y[j].z -= mean; y[j].w -= mean;
+        q += y[j].x * y[j].x + y[j].y * y[j].y + y[j].z * y[j].z + y[j].w * y[j].w;
+      }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e0 = 256 * j + 4 * lane;
+      if (e0 < H) {
+        const float4 gg = *(const float4*)(g + e0);
+        y[j].x *= rstd; y[j].y *= rstd; y[j].z *= rstd; y[j].w *= rstd;
+        ab[j].x += d[j].x; ab[j].y += d[j].y; ab[j].z += d[j].z; ab[j].w += d[j].w;
+        ag[j].x += d[j].x * y[j].x; ag[j].y += d[j].y * y[j].y; ag[j].z += d[j].z * y[j].z; ag[j].w += d[j].w * y[j].w;
+        d[j].x *= gg.x; d[j].y *= gg.y; d[j].z *= gg.z; d[j].w *= gg.w;
+        m1 += d[j].x + d[j].y + d[j].z + d[j].w;
+        m2 += d[j].x * y[j].x + d[j].y * y[j].y + d[j].z * y[j].z + d[j].w * y[j].w;
+      }
+    }
+    m1 = wave_sum(m1) / (float)H;
+    m2 = wave_sum(m2) / (float)H;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e0 = 256 * j + 4 * lane;
+      if (e0 < H) {
+        float4 o;
+        o.x = rstd * (d[j].x - m1 - y[j].x * m2);
+        o.y = rstd * (d[j].y - m1 - y[j].y * m2);
+        o.z = rstd * (d[j].z - m1 - y[j].z * m2);
+        o.w = rstd * (d[j].w - m1 - y[j].w * m2);
+        at[j].x += o.x; at[j].y += o.y; at[j].z += o.z; at[j].w += o.w;
+        float* dw = d_word + (int64_t)id * H + e0;
+        float* dp = d_pos + (int64_t)pp * H + e0;
+        atomicAdd(dw + 0, o.x); atomicAdd(dw + 1, o.y); atomicAdd(dw + 2, o.z); atomicAdd(dw + 3, o.w);
+        atomicAdd(dp + 0, o.x); atomicAdd(dp + 1, o.y); atomicAdd(dp + 2, o.z); atomicAdd(dp + 3, o.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e0 = 256 * j + 4 * lane;
+    if (e0 < H) {
+      *(float4*)&red[wave][0][e0] = ag[j];
+      *(float4*)&red[wave][1][e0] = ab[j];
+      *(float4*)&red[wave][2][e0] = at[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * H; i += 256) {
+    const int k = i / H, e = i - k * H;
+    part[((int64_t)blockIdx.x * 3 + k) * H + e] = red[0][k][e] + red[1][k][e] + red[2][k][e] + red[3][k][e];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention backward
+// ---------------------------------------------------------------------------------------------
+// D[h, t] = sum_d dO[t, 64 h + d] * O[t, 64 h + d]; one wave per token (lane owns 256 j + 4 lane + c: each
+// 16-lane group covers one head per j)
+__global__ void __launch_bounds__(256) k_attn_rowdot(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
+                                                     int64_t rows, int H, float* __restrict__ D, int64_t ldt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  for (int e0 = 4 * lane; e0 < H; e0 += 256) {
+    const uint2 a = *(const uint2*)(dO + row * H + e0), b = *(const uint2*)(O + row * H + e0);
+    float s = __uint_as_float(a.x << 16) * __uint_as_float(b.x << 16) +
+              __uint_as_float(a.x & 0xffff0000u) * __uint_as_float(b.x & 0xffff0000u) +
+              __uint_as_float(a.y << 16) * __uint_as_float(b.y << 16) +
+              __uint_as_float(a.y & 0xffff0000u) * __uint_as_float(b.y & 0xffff0000u);
+    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
+    if ((lane & 15) == 0) D[(int64_t)(e0 >> 6) * ldt + row] = s;
+  }
+}
+
+struct AttnBwdArgs {
+  const bf16_t* QKV;   // [rows, 3H] token-major (Q | K | V)
+  const bf16_t* QKVt;  // [3H, ldt] feature-major, zero beyond the last row
+  const bf16_t* dO;    // [rows, H]
+  const bf16_t* dOt;   // [H, ldt]
+  const float* LSE;    // [heads, ldt]
+  const float* Dr;     // [heads, ldt]
+  int64_t ldt;
+  const int32_t *cu, *lens;
+  int H;
+  bf16_t* dQKV;        // [rows, 3H]
+  float scale;
+};
+
+constexpr int ATTB_TILE = 64 * 128;  // one 64-row x 128-byte LDS tile
+
+// stage a 64 x 128 B tile (rows `row_stride_elems` apart) with the engine's swizzle
+__device__ __forceinline__ void attn_stage64(const bf16_t* src, int64_t row_stride, char* lds, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r0 = (i * 4 + wave) * 8;
+    const int row = r0 + (lane >> 3);
+    const int gch = (lane & 7) ^ ((row >> 1) & 7);
+    glds16((const char*)(src + (int64_t)row * row_stride) + gch * 16, lds + r0 * 128);
+  }
+}
+
+// dQ: workgroup = 128 queries of one (sequence, head); loop over 64-key tiles.  Same lane-local layout as the
+// forward: S^T and dP^T = V dO^T have lane = query, registers = keys; dQ^T = K^T dS^T with dS^T fed from registers.
+__global__ void __launch_bounds__(256) k_attention_bwd_dq(const AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + ATTB_TILE;
+  char* sKt = smem + 2 * ATTB_TILE;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int len = a.lens[b];
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= len) return;
+  const int64_t base = a.cu[b];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  const int q = q0 + wave * 32 + li;
+  const int qc = q < len ? q : len - 1;
+  const int H = a.H, H3 = 3 * a.H;
+  bf16x8 qf[4], dof[4];
+  {
+    const bf16_t* qp = a.QKV + (base + qc) * H3 + h * 64 + 8 * hi;
+    const bf16_t* dp = a.dO + (base + qc) * H + h * 64 + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { qf[s] = *(const bf16x8*)(qp + 16 * s); dof[s] = *(const bf16x8*)(dp + 16 * s); }
+  }
+  const float c = a.scale * 1.44269504088896341f;
+  const float lse2 = a.LSE[(int64_t)h * a.ldt + base + qc] * 1.44269504088896341f;
+  const float Di = a.Dr[(int64_t)h * a.ldt + base + qc];
+  f32x16 dq[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+  const int sw = (lane >> 1) & 7;
+  const int krow = (li & ~12) | ((li & 4) << 1) | ((li & 8) >> 1);
+  const int ksw = (krow >> 1) & 7;
+
+  for (int kv0 = 0; kv0 < len; kv0 += 64) {
+    __syncthreads();
+    attn_stage64(a.QKV + (base + kv0) * H3 + H + h * 64, H3, sK, wave, lane);
+    attn_stage64(a.QKV + (base + kv0) * H3 + 2 * H + h * 64, H3, sV, wave, lane);
+    attn_stage64(a.QKVt + (int64_t)(H + h * 64) * a.ldt + base + kv0, a.ldt, sKt, wave, lane);
+    lds_dma_wait_all();
+    __syncthreads();
+    f32x16 st[2], dp[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[kt][r] = 0.f; dp[kt][r] = 0.f; }
+      const char* kp = sK + (kt * 32 + krow) * 128;
+      const char* vp = sV + (kt * 32 + krow) * 128;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int ch = ((2 * s + hi) ^ ksw) * 16;
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp + ch), qf[s], st[kt], 0, 0, 0);
+        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(vp + ch), dof[s], dp[kt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
+        const float p = exp2f(st[kt][r] * c - lse2);
+        st[kt][r] = key < len ? p * (dp[kt][r] - Di) * a.scale : 0.f;  // dS^T (select, never 0 * junk)
+      }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int kt = s4 >> 1, r0 = (s4 & 1) * 8;
+      union { bf16x8 v; uint32_t u[4]; } pb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pb.u[j] = pack_bf16x2(st[kt][r0 + 2 * j], st[kt][r0 + 2 * j + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8 kf = *(const bf16x8*)(sKt + (dt * 32 + li) * 128 + (((2 * s4 + hi) ^ sw) * 16));
+        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, pb.v, dq[dt], 0, 0, 0);
+      }
+    }
+  }
+  const int plen = a.cu[b + 1] - (int)base;
+  if (q < plen) {
+    const float keep = q < len ? 1.f : 0.f;
+    bf16_t* dst = a.dQKV + (base + q) * H3 + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 ov;
+        ov.x = pack_bf16x2(dq[dt][4 * g + 0] * keep, dq[dt][4 * g + 1] * keep);
+        ov.y = pack_bf16x2(dq[dt][4 * g + 2] * keep, dq[dt][4 * g + 3] * keep);
+        *(uint2*)(dst + dt * 32 + 8 * g + 4 * hi) = ov;
+      }
+  }
+}
+
+// dK, dV: workgroup = 128 keys of one (sequence, head), lane = key; loop over 64-query tiles.
+//   S = Q K^T and dP = dO V^T with A = query rows (registers), B = this lane's key;
+//   dV^T = dO^T P and dK^T = Q^T dS with P / dS fed from registers.
+__global__ void __launch_bounds__(256) k_attention_bwd_dkv(const AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQ = smem;
+  char* sdO = smem + ATTB_TILE;
+  char* sQt = smem + 2 * ATTB_TILE;
+  char* sdOt = smem + 3 * ATTB_TILE;
+  float* sLse = (float*)(smem + 4 * ATTB_TILE);
+  float* sD = sLse + 64;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int len = a.lens[b];
+  const int k0 = blockIdx.x * 128;
+  if (k0 >= len) return;
+  const int64_t base = a.cu[b];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  const int key = k0 + wave * 32 + li;
+  const int kc = key < len ? key : len - 1;
+  const int H = a.H, H3 = 3 * a.H;
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16_t* kp = a.QKV + (base + kc) * H3 + H + h * 64 + 8 * hi;
+    const bf16_t* vp = a.QKV + (base + kc) * H3 + 2 * H + h * 64 + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { kf[s] = *(const bf16x8*)(kp + 16 * s); vf[s] = *(const bf16x8*)(vp + 16 * s); }
+  }
+  const float c = a.scale * 1.44269504088896341f;
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+  const int sw = (lane >> 1) & 7;
+  const int qrow = (li & ~12) | ((li & 4) << 1) | ((li & 8) >> 1);
+  const int qsw = (qrow >> 1) & 7;
+
+  for (int q0 = 0; q0 < len; q0 += 64) {
+    __syncthreads();
+    attn_stage64(a.QKV + (base + q0) * H3 + h * 64, H3, sQ, wave, lane);
+    attn_stage64(a.dO + (base + q0) * H + h * 64, H, sdO, wave, lane);
+    attn_stage64(a.QKVt + (int64_t)(h * 64) * a.ldt + base + q0, a.ldt, sQt, wave, lane);
+    attn_stage64(a.dOt + (int64_t)(h * 64) * a.ldt + base + q0, a.ldt, sdOt, wave, lane);
+    if (threadIdx.x < 64) {
+      sLse[threadIdx.x] = a.LSE[(int64_t)h * a.ldt + base + q0 + threadIdx.x] * 1.44269504088896341f;
+      sD[threadIdx.x] = a.Dr[(int64_t)h * a.ldt + base + q0 + threadIdx.x];
+    }
+    lds_dma_wait_all();
+    __syncthreads();
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {  // 32 queries at a time (keeps the register footprint at one S / dP tile)
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      const char* qp = sQ + (qt * 32 + qrow) * 128;
+      const char* op = sdO + (qt * 32 + qrow) * 128;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int ch = ((2 * s4 + hi) ^ qsw) * 16;
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qp + ch), kf[s4], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(op + ch), vf[s4], dp, 0, 0, 0);
+      }
+      // register r <-> query q0 + 32 qt + 16 (r >> 3) + 8 hi + (r & 7)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = 32 * qt + 16 * (r >> 3) + 8 * hi + (r & 7);
+        const bool ok = q0 + qi < len;
+        const float p = ok ? exp2f(s[r] * c - sLse[qi]) : 0.f;
+        s[r] = p;                                               // P
+        dp[r] = ok ? p * (dp[r] - sD[qi]) * a.scale : 0.f;      // dS
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {  // 16 queries per MFMA k-step
+        const int r0 = half * 8;
+        union { bf16x8 v; uint32_t u[4]; } pb, sb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pb.u[j] = pack_bf16x2(s[r0 + 2 * j], s[r0 + 2 * j + 1]);
+          sb.u[j] = pack_bf16x2(dp[r0 + 2 * j], dp[r0 + 2 * j + 1]);
+        }
+        const int chq = (((2 * (2 * qt + half) + hi) ^ sw) * 16);  // queries 32 qt + 16 half + 8 hi .. +8
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 of = *(const bf16x8*)(sdOt + (dt * 32 + li) * 128 + chq);
+          const bf16x8 qf = *(const bf16x8*)(sQt + (dt * 32 + li) * 128 + chq);
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, pb.v, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, sb.v, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int plen = a.cu[b + 1] - (int)base;
+  if (key < plen) {
+    const float keep = key < len ? 1.f : 0.f;
+    bf16_t* dstk = a.dQKV + (base + key) * H3 + H + h * 64;
+    bf16_t* dstv = a.dQKV + (base + key) * H3 + 2 * H + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 ok, ov;
+        ok.x = pack_bf16x2(dk[dt][4 * g + 0] * keep, dk[dt][4 * g + 1] * keep);
+        ok.y = pack_bf16x2(dk[dt][4 * g + 2] * keep, dk[dt][4 * g + 3] * keep);
+        ov.x = pack_bf16x2(dv[dt][4 * g + 0] * keep, dv[dt][4 * g + 1] * keep);
+        ov.y = pack_bf16x2(dv[dt][4 * g + 2] * keep, dv[dt][4 * g + 3] * keep);
+        *(uint2*)(dstk + dt * 32 + 8 * g + 4 * hi) = ok;
+        *(uint2*)(dstv + dt * 32 + 8 * g + 4 * hi) = ov;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// losses (run_convdr_train.py:114-115, :160-171) and the optimizer (utils/dpr_utils.py:80-87 -> HF AdamW)
+// ---------------------------------------------------------------------------------------------
+// loss = mean((s - t)^2) over n elements; ds = 2 (s - t) / n * gscale.  Single workgroup: n = B * 768 is small.
+__global__ void __launch_bounds__(1024) k_mse_fwd_bwd(const float* __restrict__ s, const float* __restrict__ t,
+                                                      int64_t n, float gscale, float* __restrict__ loss,
+                                                      float* __restrict__ ds) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  const float k = 2.f / (float)n * gscale;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float d = s[i] - t[i];
+    acc += d * d;
+    if (ds) ds[i] = k * d;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < 16; ++i) tot += red[i];
+    *loss = tot / (float)n;
+  }
+}
+
+// ranking loss: logits[b, k] = <e_b, d_{b,k}>, loss = mean_b(-log_softmax(logits[b])[0]);
+// de_b (+)= gscale / B * sum_k (softmax_k - [k == 0]) d_{b,k}.  One workgroup (256 threads) per b; K <= 64.
+__global__ void __launch_bounds__(256) k_rank_ce_fwd_bwd(const float* __restrict__ e, const float* __restrict__ docs,
+                                                         int B, int K, int E, float gscale,
+                                                         float* __restrict__ loss_per_b, float* __restrict__ de,
+                                                         int accumulate) {
+  __shared__ float logit[64];
+  __shared__ float prob[64];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* eb = e + (int64_t)b * E;
+  for (int k = wave; k < K; k += 4) {
+    const float* d = docs + ((int64_t)b * K + k) * E;
+    float s = 0.f;
+    for (int i = lane; i < E; i += 64) s += eb[i] * d[i];
+    s = wave_sum(s);
+    if (lane == 0) logit[k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mx = logit[0];
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, logit[k]);
+    float z = 0.f;
+    for (int k = 0; k < K; ++k) z += expf(logit[k] - mx);
+    const float lz = logf(z) + mx;
+    for (int k = 0; k < K; ++k) prob[k] = expf(logit[k] - lz);
+    loss_per_b[b] = lz - logit[0];
+  }
+  __syncthreads();
+  if (de) {
+    const float sc = gscale / (float)B;
+    for (int i = threadIdx.x; i < E; i += 256) {
+      float g = 0.f;
+      for (int k = 0; k < K; ++k) g += (prob[k] - (k == 0 ? 1.f : 0.f)) * docs[((int64_t)b * K + k) * E + i];
+      g *= sc;
+      de[(int64_t)b * E + i] = accumulate ? de[(int64_t)b * E + i] + g : g;
+    }
+  }
+}
+
+// sum of squares, two stages (deterministic): part[block]
+__global__ void __launch_bounds__(256) k_sumsq_partial(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += x[i] * x[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// norm_out[0] = sqrt(sum part) ; norm_out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))  (torch clip_grad_norm_)
+__global__ void k_norm_finish(const float* __restrict__ part, int nparts, float max_norm, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nparts; ++i) s += part[i];
+    const float nm = (float)sqrt(s);
+    out[0] = nm;
+    const float cf = max_norm / (nm + 1e-6f);
+    out[1] = cf < 1.f ? cf : 1.f;
+  }
+}
+
+// HF transformers==2.3.0 AdamW (not torch.optim.AdamW):
+//   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps);  p -= lr wd p
+// g is multiplied by *gscale (the clip coefficient, device scalar) first.
+__global__ void __launch_bounds__(256) k_adamw_hf(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                  float b1, float b2, float eps, float wd, float step_size,
+                                                  const float* __restrict__ gscale) {
+  const float gs = gscale ? gscale[0] : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * gs;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    float pi = p[i] - step_size * mi / (sqrtf(vi) + eps);
+    if (wd > 0.f) pi -= lr * wd * pi;
+    m[i] = mi; v[i] = vi; p[i] = pi;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_scale_inplace(float* __restrict__ x, int64_t n, const float* __restrict__ s) {
+  const float f = s[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= f;
+}
+
+}  // namespace convdr

@@ -1,0 +1,333 @@
+"""KD + ranking training step on MI355X.
+
+Mirrors /root/reference/drivers/run_convdr_train.py:101-193 (the step body of ``train``) and
+/root/reference/utils/dpr_utils.py:80-87 (``get_optimizer``): student forward + backward, MSE KD loss, optional
+ranking cross-entropy over 1 positive + ``num_negatives`` documents, global-norm clip, HF-semantics AdamW and the
+linear warm-up/decay schedule -- every tensor operation runs in libconvdr_hip.so (csrc/train*.hip).
+
+Integration with torch autograd: ``encoder_autograd`` is a ``torch.autograd.Function`` whose forward keeps the
+activations inside a device workspace and whose backward runs the hand-written backward kernels and returns the
+parameter gradients (views of one flat fp32 buffer), so ``loss.backward()``, ``.grad``, ``zero_grad`` and any
+``torch.optim`` optimizer keep working -- as do the fused ``clip_grad_norm_`` / ``AdamW`` below.
+
+Deviation (documented, SURVEY.md §7 hard part 4): dropout is the identity.  The reference trains the student with
+hidden / attention dropout 0.1 whose RNG streams cannot be reproduced; parity is therefore defined at p = 0.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+# --------------------------------------------------------------------------------------------
+# parameter order of the flat gradient buffer (per layer: q,k,v weights adjacent -> one [3H, H] region)
+# --------------------------------------------------------------------------------------------
+def _tower_params(tower, head):
+    e = tower.embeddings
+    out = [e.word_embeddings.weight, e.position_embeddings.weight, e.token_type_embeddings.weight,
+           e.LayerNorm.weight, e.LayerNorm.bias]
+    for ly in tower.encoder.layer:
+        s = ly.attention.self
+        out += [s.query.weight, s.key.weight, s.value.weight, s.query.bias, s.key.bias, s.value.bias,
+                ly.attention.output.dense.weight, ly.attention.output.dense.bias,
+                ly.attention.output.LayerNorm.weight, ly.attention.output.LayerNorm.bias,
+                ly.intermediate.dense.weight, ly.intermediate.dense.bias,
+                ly.output.dense.weight, ly.output.dense.bias, ly.output.LayerNorm.weight, ly.output.LayerNorm.bias]
+    if head is not None:
+        out += [head[0].weight, head[0].bias, head[1].weight, head[1].bias]
+    return out
+
+
+def _packed_t(tower, head):
+    """Transposed bf16 weights for the data-gradient GEMMs (cached with the forward packing)."""
+    c, w, keep = tower.packed(head)
+    cache = getattr(tower, "_packed_t", None)
+    if cache is not None and cache[0] is keep:
+        return cache[1], cache[2]
+    L = _lib.lib()
+    dev = tower.embeddings.word_embeddings.weight.device
+    hold = []
+
+    def tr(t):
+        t = t.detach().float().contiguous()
+        n, k = t.shape
+        o = torch.empty((k, n), dtype=torch.bfloat16, device=dev)
+        _lib.check(L.convdr_transpose_f32_bf16(_lib.ptr(t), n, k, _lib.ptr(o), _lib.stream_ptr()), "convdr_transpose_f32_bf16")
+        hold.append((t, o))
+        return o.data_ptr()
+
+    with torch.cuda.device(dev):
+        arr = (_lib.LayerWeightsT * len(tower.encoder.layer))()
+        for i, ly in enumerate(tower.encoder.layer):
+            s = ly.attention.self
+            arr[i].wqkv_t = tr(torch.cat([s.query.weight, s.key.weight, s.value.weight], 0))
+            arr[i].wo_t = tr(ly.attention.output.dense.weight)
+            arr[i].w1_t = tr(ly.intermediate.dense.weight)
+            arr[i].w2_t = tr(ly.output.dense.weight)
+        head_t = tr(head[0].weight) if head is not None else None
+    hold.append(arr)
+    tower._packed_t = (keep, arr, head_t, hold)
+    return arr, head_t
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tower, head, input_ids, attention_mask, *params):
+        L_ = _lib.lib()
+        ids = input_ids.long().contiguous()
+        mask = attention_mask.long().contiguous()
+        if ids.device.type != "cuda":
+            raise _lib.ConvdrError("encoder inputs must be CUDA tensors (no CPU fallback)")
+        B, L = ids.shape
+        dev = ids.device
+        seq_lens = mask.sum(1).to(torch.int32)
+        lens_host = seq_lens.cpu().numpy()
+        if lens_host.min() < 1 or not bool(mask[:, 0].all()):
+            raise ValueError("every sequence needs attention_mask[:, 0] == 1")
+        cu_host = np.zeros(B + 1, np.int32)
+        np.cumsum((lens_host + 7) // 8 * 8, out=cu_host[1:])
+        rows, max_len = int(cu_host[-1]), int(lens_host.max())
+        cu = torch.as_tensor(cu_host, device=dev)
+        with torch.cuda.device(dev):
+            c, w, _keep = tower.packed(head)
+            out = torch.empty((B, c.out_dim or c.hidden), dtype=torch.float32, device=dev)
+            need = L_.convdr_encoder_train_workspace_bytes(C.byref(c), rows, B)
+            ws = getattr(tower, "_train_ws", None)
+            if ws is None or ws.numel() < need or ws.device != dev:
+                ws = tower._train_ws = torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev)
+            _lib.check(L_.convdr_encoder_train_forward(C.byref(c), C.byref(w), _lib.ptr(ids), 0, _lib.ptr(mask), B, L,
+                                                       _lib.ptr(cu), _lib.ptr(seq_lens), rows, max_len, _lib.ptr(ws),
+                                                       ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
+                       "convdr_encoder_train_forward")
+        ctx.tower, ctx.head = tower, head
+        ctx.saved = (cu, seq_lens, B, rows, max_len, ws)
+        ctx.shapes = [p.shape for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        L_ = _lib.lib()
+        tower, head = ctx.tower, ctx.head
+        cu, seq_lens, B, rows, max_len, ws = ctx.saved
+        dev = grad_out.device
+        go = grad_out.float().contiguous()
+        sizes = [int(np.prod(s)) for s in ctx.shapes]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        flat = torch.zeros(int(offs[-1]), dtype=torch.float32, device=dev)
+        views = [flat[int(o):int(o) + n].view(s) for o, n, s in zip(offs[:-1], sizes, ctx.shapes)]
+        ptr = [v.data_ptr() for v in views]
+        nl = len(tower.encoder.layer)
+        with torch.cuda.device(dev):
+            c, w, _keep = tower.packed(head)
+            wt, head_t = _packed_t(tower, head)
+            lg = (_lib.LayerGrads * nl)()
+            for i in range(nl):
+                b = 5 + 16 * i
+                g = lg[i]
+                g.wqkv, g.bqkv = ptr[b], ptr[b + 3]           # q,k,v weights / biases are adjacent
+                g.wo, g.bo, g.ln1_g, g.ln1_b = ptr[b + 6], ptr[b + 7], ptr[b + 8], ptr[b + 9]
+                g.w1, g.b1, g.w2, g.b2 = ptr[b + 10], ptr[b + 11], ptr[b + 12], ptr[b + 13]
+                g.ln2_g, g.ln2_b = ptr[b + 14], ptr[b + 15]
+            gr = _lib.EncoderGrads()
+            gr.word_emb, gr.pos_emb, gr.type_emb, gr.emb_ln_g, gr.emb_ln_b = ptr[0], ptr[1], ptr[2], ptr[3], ptr[4]
+            gr.layers = C.cast(lg, C.POINTER(_lib.LayerGrads))
+            if head is not None:
+                b = 5 + 16 * nl
+                gr.head_w, gr.head_b, gr.head_ln_g, gr.head_ln_b = ptr[b], ptr[b + 1], ptr[b + 2], ptr[b + 3]
+            _lib.check(L_.convdr_encoder_backward(C.byref(c), C.byref(w), wt, _lib.ptr(cu), _lib.ptr(seq_lens),
+                                                  C.c_void_p(head_t) if head_t else None, B, rows, max_len, _lib.ptr(ws),
+                                                  ws.numel(), _lib.ptr(go), C.byref(gr), _lib.stream_ptr()),
+                       "convdr_encoder_backward")
+        return (None, None, None, None) + tuple(views)
+
+
+def encoder_autograd(model, tower, head, input_ids, attention_mask):
+    """Differentiable embeddings of `tower` (+ optional (Linear, LayerNorm) head)."""
+    cfg = tower.config
+    if model.training and (cfg.hidden_dropout_prob or cfg.attention_probs_dropout_prob):
+        if not getattr(model, "_dropout_notice", False):
+            model._dropout_notice = True
+            print("convdr_amd: training without dropout (p treated as 0; see convdr_amd/train.py)")
+    return _EncoderFn.apply(tower, head, input_ids, attention_mask, *_tower_params(tower, head))
+
+
+# --------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------
+class _MSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s, t):
+        s32, t32 = s.float().contiguous(), t.float().contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=s.device)
+        ds = torch.empty_like(s32)
+        with torch.cuda.device(s.device):
+            _lib.check(_lib.lib().convdr_mse_fwd_bwd(_lib.ptr(s32), _lib.ptr(t32), s32.numel(), 1.0, _lib.ptr(loss),
+                                                     _lib.ptr(ds), _lib.stream_ptr()), "convdr_mse_fwd_bwd")
+        ctx.save_for_backward(ds)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (ds,) = ctx.saved_tensors
+        return ds * g, None
+
+
+def mse_loss(student_embs, teacher_embs):
+    """nn.MSELoss() (run_convdr_train.py:460, :115); gradient flows to the student only."""
+    return _MSE.apply(student_embs, teacher_embs.detach())
+
+
+class _RankCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, embs, docs):
+        e32, d32 = embs.float().contiguous(), docs.float().contiguous()
+        B, K, E = d32.shape
+        per = torch.empty(B, dtype=torch.float32, device=embs.device)
+        de = torch.empty_like(e32)
+        with torch.cuda.device(embs.device):
+            _lib.check(_lib.lib().convdr_rank_ce_fwd_bwd(_lib.ptr(e32), _lib.ptr(d32), B, K, E, 1.0, _lib.ptr(per),
+                                                         _lib.ptr(de), 0, _lib.stream_ptr()), "convdr_rank_ce_fwd_bwd")
+        ctx.save_for_backward(de)
+        return per.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (de,) = ctx.saved_tensors
+        return de * g, None
+
+
+def ranking_loss(embs, pos_and_negs_embeddings):
+    """CrossEntropy(logits, 0) with logits[b, k] = <embs[b], docs[b, k]> (run_convdr_train.py:160-170);
+    docs [B, K, E] come from the frozen teacher (no gradient)."""
+    return _RankCE.apply(embs, pos_and_negs_embeddings.detach())
+
+
+# --------------------------------------------------------------------------------------------
+# clip + optimizer + schedule
+# --------------------------------------------------------------------------------------------
+def _flat_view(tensors):
+    """The single flat buffer the tensors tile contiguously, or None."""
+    if not tensors:
+        return None
+    base = tensors[0]
+    start = base.data_ptr()
+    off = start
+    for t in tensors:
+        if not t.is_contiguous() or t.dtype != torch.float32 or t.data_ptr() != off or \
+                t.untyped_storage().data_ptr() != base.untyped_storage().data_ptr():
+            return None
+        off += t.numel() * 4
+    n = (off - start) // 4
+    return torch.as_strided(base, (n,), (1,), base.storage_offset())
+
+
+def clip_grad_norm_(parameters, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (run_convdr_train.py:188-189) in one or a few kernels.  Returns the total
+    norm as a device scalar (no host sync)."""
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.zeros(())
+    dev = grads[0].device
+    L = _lib.lib()
+    scratch = torch.empty(1024, dtype=torch.float32, device=dev)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        flat = _flat_view(grads)
+        if flat is not None:
+            _lib.check(L.convdr_grad_norm_clip(_lib.ptr(flat), flat.numel(), float(max_norm), _lib.ptr(scratch), _lib.ptr(out),
+                                               1, _lib.stream_ptr()), "convdr_grad_norm_clip")
+            return out[0]
+        norms = torch.empty((len(grads), 2), dtype=torch.float32, device=dev)
+        for i, g in enumerate(grads):
+            assert g.is_contiguous() and g.dtype == torch.float32
+            _lib.check(L.convdr_grad_norm_clip(_lib.ptr(g), g.numel(), float(max_norm), _lib.ptr(scratch), _lib.ptr(norms[i]),
+                                               0, _lib.stream_ptr()), "convdr_grad_norm_clip")
+        total = norms[:, 0].double().pow(2).sum().sqrt().float()
+        coef = (max_norm / (total + 1e-6)).clamp(max=1.0).reshape(1).contiguous()
+        for g in grads:
+            _lib.check(L.convdr_scale_f32(_lib.ptr(g), g.numel(), _lib.ptr(coef), _lib.stream_ptr()), "convdr_scale_f32")
+        return total
+
+
+class AdamW(torch.optim.Optimizer):
+    """transformers==2.3.0 ``AdamW`` (what utils/dpr_utils.py:87 constructs) with the fused HIP update."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        L = _lib.lib()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p.data, dtype=torch.float32)
+                    st["exp_avg_sq"] = torch.zeros_like(p.data, dtype=torch.float32)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                assert p.data.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32
+                with torch.cuda.device(p.device):
+                    _lib.check(L.convdr_adamw_step(_lib.ptr(p.data), _lib.ptr(g), _lib.ptr(st["exp_avg"]),
+                                                   _lib.ptr(st["exp_avg_sq"]), p.numel(), group["lr"], b1, b2, group["eps"],
+                                                   group["weight_decay"], st["step"], int(group["correct_bias"]), None,
+                                                   _lib.stream_ptr()), "convdr_adamw_step")
+
+
+def get_optimizer(args, model, weight_decay=0.0):
+    """utils/dpr_utils.py:80-87: two groups split on 'bias' / 'LayerNorm.weight' in the parameter NAME
+    (so the head's ``norm.weight`` lands in the decayed group, exactly as in the reference)."""
+    no_decay = ["bias", "LayerNorm.weight"]
+    groups = [
+        {"params": [p for n, p in model.named_parameters() if not any(nd in n for nd in no_decay)],
+         "weight_decay": weight_decay},
+        {"params": [p for n, p in model.named_parameters() if any(nd in n for nd in no_decay)], "weight_decay": 0.0},
+    ]
+    return AdamW(groups, lr=args.learning_rate, eps=args.adam_epsilon)
+
+
+def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, last_epoch=-1):
+    """transformers.get_linear_schedule_with_warmup (run_convdr_train.py:71-74)."""
+    def lr_lambda(step):
+        if step < num_warmup_steps:
+            return float(step) / float(max(1, num_warmup_steps))
+        return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - num_warmup_steps)))
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda, last_epoch)
+
+
+def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=None, doc_mask=None):
+    """One iteration of the reference loop body (run_convdr_train.py:101-193) with pre-tokenised ranking documents
+    (`doc_ids` / `doc_mask` int64 [B * (num_negatives + 1), Ld], positive first within each group).
+    Returns (loss, loss1, loss2) as device scalars."""
+    concat_ids, concat_id_mask, target_ids, target_id_mask = batch
+    model.train()
+    teacher_model.eval()
+    embs = model(concat_ids, concat_id_mask)
+    with torch.no_grad():
+        teacher_embs = teacher_model(target_ids, target_id_mask).detach()
+    loss1 = None if getattr(args, "no_mse", False) else mse_loss(embs, teacher_embs)
+    loss, loss2 = loss1, None
+    if getattr(args, "ranking_task", False):
+        bs = concat_ids.shape[0]
+        outs = []
+        with torch.no_grad():
+            for i in range(0, doc_ids.shape[0], 8):                       # doc_batch_size = 8 (:139)
+                outs.append(teacher_model(doc_ids[i:i + 8], doc_mask[i:i + 8], is_query=False).detach())
+        docs = torch.cat(outs, 0).view(bs, args.num_negatives + 1, -1)
+        loss2 = ranking_loss(embs, docs)
+        loss = loss1 + loss2 if loss1 is not None else loss2
+    if getattr(args, "gradient_accumulation_steps", 1) > 1:
+        loss = loss / args.gradient_accumulation_steps
+    loss.backward()
+    clip_grad_norm_(list(model.parameters()), args.max_grad_norm)
+    optimizer.step()
+    scheduler.step()
+    model.zero_grad()
+    return loss.detach(), loss1, loss2

@@ -132,6 +132,80 @@ int convdr_encoder_forward(const convdr_encoder_config* cfg, const convdr_encode
                            const int32_t* cu_seqlens, const int32_t* seq_lens, int64_t rows, int max_len,
                            void* workspace, size_t workspace_bytes, float* out, convdr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training step of the student encoder: replaces, for /root/reference/drivers/run_convdr_train.py:109-191,
+ *   embs = model(concat_ids, concat_id_mask)          -> convdr_encoder_train_forward (keeps activations)
+ *   loss_fn(embs, teacher_embs)           :115, :460   -> convdr_mse_fwd_bwd
+ *   logits / loss_fn_2(logits, labels)    :160-170     -> convdr_rank_ce_fwd_bwd
+ *   loss.backward()                       :178         -> convdr_encoder_backward
+ *   clip_grad_norm_(.., max_grad_norm)    :188-189     -> convdr_grad_norm_clip
+ *   optimizer.step()  (HF AdamW, utils/dpr_utils.py:80-87) -> convdr_adamw_step
+ * Dropout is the identity (p = 0): train-mode RNG streams cannot match torch's (SURVEY.md §7 hard part 4).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {   /* bf16 transposed weights for the data-gradient GEMMs (device pointers) */
+  const void* wqkv_t;  /* [H, 3H] */
+  const void* wo_t;    /* [H, H]  */
+  const void* w1_t;    /* [H, I]  */
+  const void* w2_t;    /* [I, H]  */
+} convdr_layer_weights_t;
+
+typedef struct {   /* fp32 gradient buffers, ACCUMULATED into (+=); same shapes as the parameters */
+  float *wqkv, *bqkv, *wo, *bo, *ln1_g, *ln1_b, *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;
+} convdr_layer_grads;
+
+typedef struct {
+  float *word_emb, *pos_emb, *type_emb;   /* only row 0 of type_emb receives gradient */
+  float *emb_ln_g, *emb_ln_b;
+  const convdr_layer_grads* layers;       /* HOST array */
+  float *head_w, *head_b, *head_ln_g, *head_ln_b;
+} convdr_encoder_grads;
+
+size_t convdr_encoder_train_workspace_bytes(const convdr_encoder_config* cfg, int64_t rows, int B);
+
+/* Same contract as convdr_encoder_forward; additionally leaves every activation the backward needs in `workspace`
+ * (which must stay untouched until convdr_encoder_backward has been enqueued). */
+int convdr_encoder_train_forward(const convdr_encoder_config* cfg, const convdr_encoder_weights* w,
+                                 const void* input_ids, int ids_are_int32, const int64_t* attention_mask, int B, int L,
+                                 const int32_t* cu_seqlens, const int32_t* seq_lens, int64_t rows, int max_len,
+                                 void* workspace, size_t workspace_bytes, float* out, convdr_stream_t stream);
+
+/* d_out: fp32 [B, out_dim or hidden] gradient of the loss w.r.t. the embeddings.  wt: HOST array of `layers`
+ * entries; head_w_t: bf16 [hidden, out_dim] (NULL when out_dim == 0). */
+int convdr_encoder_backward(const convdr_encoder_config* cfg, const convdr_encoder_weights* w,
+                            const convdr_layer_weights_t* wt, const int32_t* cu_seqlens, const int32_t* seq_lens,
+                            const void* head_w_t, int B, int64_t rows, int max_len, void* workspace,
+                            size_t workspace_bytes, const float* d_out, const convdr_encoder_grads* grads,
+                            convdr_stream_t stream);
+
+/* fp32 [n, k] row-major -> bf16 [k, n] (packing of the transposed weights) */
+int convdr_transpose_f32_bf16(const float* x, int n, int k, void* y, convdr_stream_t stream);
+
+/* loss[0] = mean((s - t)^2) over n elements (nn.MSELoss); ds (nullable) = grad_scale * 2 (s - t) / n */
+int convdr_mse_fwd_bwd(const float* s, const float* t, int64_t n, float grad_scale, float* loss, float* ds,
+                       convdr_stream_t stream);
+
+/* logits[b, k] = <embs[b], docs[b, k]>, k = 0 is the positive; loss_per_query[b] = -log_softmax(logits[b])[0]
+ * (nn.CrossEntropyLoss = their mean); d_embs (nullable) (+)= grad_scale / B * sum_k (softmax - onehot0) docs[b, k].
+ * embs [B, E], docs [B, K, E] fp32, K <= 64. */
+int convdr_rank_ce_fwd_bwd(const float* embs, const float* docs, int B, int K, int E, float grad_scale,
+                           float* loss_per_query, float* d_embs, int accumulate, convdr_stream_t stream);
+
+/* torch.nn.utils.clip_grad_norm_ over one flat fp32 gradient buffer: norm_and_coef[0] = ||g||_2,
+ * norm_and_coef[1] = min(1, max_norm / (norm + 1e-6)); apply != 0 scales the gradients in place.
+ * scratch: >= 1024 floats. */
+int convdr_grad_norm_clip(float* grads, int64_t n, float max_norm, float* scratch, float* norm_and_coef, int apply,
+                          convdr_stream_t stream);
+
+/* x[i] *= scale[0] (device scalar), e.g. the clip coefficient */
+int convdr_scale_f32(float* x, int64_t n, const float* scale, convdr_stream_t stream);
+
+/* transformers==2.3.0 AdamW on flat fp32 buffers (NOT torch.optim.AdamW: eps is added to sqrt(v) before the bias
+ * correction, decoupled weight decay is applied after the update).  grad_scale: optional device scalar multiplied
+ * into g first (the clip coefficient).  step >= 1. */
+int convdr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, int step, int correct_bias, const float* grad_scale,
+                      convdr_stream_t stream);
+
 /* Test aid: byte offsets of the activation buffers inside the encoder workspace, in the order tok_id, tok_pos, X, Q, K,
  * Vt, ctx, Hm, Y, cls_b, cls_y, cls_f, head_y; out[13] = leading dimension of Vt. */
 int convdr_encoder_debug_layout(const convdr_encoder_config* cfg, int64_t rows, int B, int64_t* out);
