@@ -252,6 +252,15 @@ def clip_grad_norm_(parameters, max_norm):
         return total
 
 
+def _bump_version(t):
+    inc = getattr(torch.autograd.graph, "increment_version", None)
+    if inc is not None:
+        inc(t)
+    else:
+        with torch.no_grad():
+            t.add_(0)
+
+
 class AdamW(torch.optim.Optimizer):
     """transformers==2.3.0 ``AdamW`` (what utils/dpr_utils.py:87 constructs) with the fused HIP update."""
 
@@ -279,6 +288,7 @@ class AdamW(torch.optim.Optimizer):
                                                    _lib.ptr(st["exp_avg_sq"]), p.numel(), group["lr"], b1, b2, group["eps"],
                                                    group["weight_decay"], st["step"], int(group["correct_bias"]), None,
                                                    _lib.stream_ptr()), "convdr_adamw_step")
+                _bump_version(p)     # the kernel wrote through the raw pointer: tell torch (packed-weight cache key)
 
 
 def get_optimizer(args, model, weight_decay=0.0):

@@ -24,6 +24,7 @@ reference code:
 """
 import importlib.machinery
 import json
+import logging
 import os
 import pickle
 import sys
@@ -358,7 +359,109 @@ def gen_encode_loop():
     print("encode-loop fixture written", e.shape, i[:5])
 
 
-GROUPS = {"encoder": gen_encoder, "search": gen_search, "encode_loop": gen_encode_loop}
+def gen_train():
+    """Drive the reference's own `train()` (run_convdr_train.py:41-252) for 4 optimizer steps on a synthetic dataset:
+    KD (MSE) + ranking task, dropout 0, and record what it computed."""
+    import random
+    import torch
+    sys.argv = sys.argv[:1]
+    M, U, DU, T = import_reference()
+    sys.path.insert(0, os.path.join(REF, "drivers"))
+    import run_convdr_train as R
+    torch.manual_seed(7)
+    cfg = tiny_roberta_config(dropout=0.0)
+    student = M.MSMarcoConfigDict["rdot_nll"].model_class(cfg)
+    with torch.no_grad():
+        for n, p in student.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.05)
+            elif "LayerNorm.weight" in n or n == "norm.weight":
+                p.add_(torch.randn_like(p) * 0.1)
+    init_sd = {k: v.detach().clone() for k, v in student.state_dict().items()}
+    teacher = M.MSMarcoConfigDict["rdot_nll"].model_class(cfg)
+    teacher.load_state_dict(init_sd)            # the reference loads teacher and student from the same checkpoint
+
+    rng = np.random.RandomState(7)
+    N, Lc, Lt, K = 16, 40, 12, 3
+    examples = []
+    for i in range(N):
+        lc, lt = rng.randint(5, Lc + 1), rng.randint(3, Lt + 1)
+        c_ids, c_mask = synth_ids(rng, 1, Lc, [lc])
+        t_ids, t_mask = synth_ids(rng, 1, Lt, [lt])
+        docs = [" ".join(str(x) for x in rng.randint(3, 200, size=rng.randint(4, 30))) for _ in range(K + 1)]
+        examples.append(dict(idx=i, concat_ids=c_ids[0], concat_id_mask=c_mask[0], target_ids=t_ids[0],
+                             target_id_mask=t_mask[0], documents=docs))
+
+    log = dict(batches=[], docs=[], loss1=[], loss2=[], norms=[], scalars=[])
+
+    class DS:
+        def __len__(self):
+            return N
+
+        def __getitem__(self, i):
+            return examples[i]
+
+        def get_collate_fn(self, args, mode):
+            def fn(feats):
+                log["batches"].append([f["idx"] for f in feats])
+                out = {k: torch.tensor(np.stack([f[k] for f in feats]), dtype=torch.long)
+                       for k in ("concat_ids", "concat_id_mask", "target_ids", "target_id_mask")}
+                out["documents"] = [f["documents"] for f in feats]
+                return out
+            return fn
+
+    class Tok:
+        def encode(self, text, text_pair=None, add_special_tokens=True, max_length=512):
+            ids = [0] + [int(x) for x in text.split()] + [2]
+            log["docs"].append(ids)
+            return ids[:max_length]
+
+    class Writer:
+        def add_scalar(self, tag, v, step):
+            log["scalars"].append((tag, float(v), int(step)))
+
+    mse, ce = torch.nn.MSELoss(), torch.nn.CrossEntropyLoss()
+
+    def loss_fn(a, b):
+        v = mse(a, b); log["loss1"].append(float(v)); return v
+
+    def loss_fn_2(a, b):
+        v = ce(a, b); log["loss2"].append(float(v)); return v
+
+    orig_clip = torch.nn.utils.clip_grad_norm_
+
+    def clip(params, max_norm):
+        n = orig_clip(params, max_norm); log["norms"].append(float(n)); return n
+    torch.nn.utils.clip_grad_norm_ = clip
+    with tempfile.TemporaryDirectory() as td:
+        args = types.SimpleNamespace(
+            per_gpu_train_batch_size=4, n_gpu=0, device=torch.device("cpu"), max_steps=3, num_train_epochs=1,
+            gradient_accumulation_steps=1, learning_rate=2e-4, adam_epsilon=1e-8, weight_decay=0.01, warmup_steps=1,
+            max_grad_norm=1.0, log_steps=1, save_steps=-1, no_mse=False, ranking_task=True, num_negatives=K,
+            model_type="rdot_nll", output_dir=td, seed=42)
+        try:
+            gs, _ = R.train(args, DS(), student, teacher, loss_fn, logging.getLogger("golden"), Writer(),
+                            cross_validate_id=0, loss_fn_2=loss_fn_2, tokenizer=Tok())
+        finally:
+            torch.nn.utils.clip_grad_norm_ = orig_clip
+    out = {"config": json.dumps({**TINY, "layer_norm_eps": 1e-5, "type_vocab_size": 1, "pad_token_id": 1}),
+           "steps": np.array(gs), "batches": np.array(log["batches"]), "loss1": np.array(log["loss1"]),
+           "loss2": np.array(log["loss2"]), "grad_norm": np.array(log["norms"]),
+           "docs": np.array([(d + [-1] * 64)[:64] for d in log["docs"]], np.int32),
+           "hyper": json.dumps(dict(lr=2e-4, eps=1e-8, weight_decay=0.01, warmup=1, t_total=3, max_grad_norm=1.0,
+                                    num_negatives=K, batch=4))}
+    for i, e in enumerate(examples):
+        for k in ("concat_ids", "concat_id_mask", "target_ids", "target_id_mask"):
+            out["ex/%d/%s" % (i, k)] = e[k]
+    for k, v in init_sd.items():
+        out["w0/" + k] = v.numpy()
+    for k, v in student.state_dict().items():
+        out["w1/" + k] = v.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "train_step.npz"), **out)
+    print("train fixture written: steps", gs, "loss1", log["loss1"], "loss2", log["loss2"], "norms", log["norms"])
+
+
+GROUPS = {"encoder": gen_encoder, "search": gen_search, "encode_loop": gen_encode_loop, "train": gen_train}
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

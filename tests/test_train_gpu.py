@@ -146,3 +146,77 @@ def test_clip_and_adamw_match_oracle():
             OT.hf_adamw_step(p, g * coef, ref_m[i], ref_v[i], step, 1e-3, eps=1e-8, weight_decay=0.01 if i < 2 else 0.0)
         for p, r in zip(ps, ref_p):
             assert torch.allclose(p.detach().cpu(), r, rtol=2e-5, atol=1e-7)
+
+
+def test_train_steps_match_reference_run(golden_dir):
+    """Replay the 4 optimizer steps the reference's own train() ran (tests/golden/make_golden.py::gen_train):
+    same batches, same sampled documents, KD + ranking loss, clip 1.0, HF AdamW (two param groups, wd 0.01),
+    linear schedule with 1 warm-up step -- and compare losses, gradient norms and the final parameters."""
+    from types import SimpleNamespace
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    from convdr_amd import train as TR
+    z = np.load(os.path.join(golden_dir, "train_step.npz"))
+    cfg = json.loads(str(z["config"]))
+    hp = json.loads(str(z["hyper"]))
+    sd0 = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w0/")}
+    sd1 = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w1/")}
+
+    def build():
+        m = MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **cfg))
+        missing, unexpected = m.load_state_dict(sd0, strict=False)
+        assert not unexpected
+        return m.cuda()
+    student, teacher = build(), build()
+    args = SimpleNamespace(learning_rate=hp["lr"], adam_epsilon=hp["eps"], max_grad_norm=hp["max_grad_norm"],
+                           ranking_task=True, no_mse=False, num_negatives=hp["num_negatives"], gradient_accumulation_steps=1)
+    opt = TR.get_optimizer(args, student, weight_decay=hp["weight_decay"])
+    sched = TR.get_linear_schedule_with_warmup(opt, num_warmup_steps=hp["warmup"], num_training_steps=hp["t_total"])
+    docs_all = z["docs"]
+    K1 = hp["num_negatives"] + 1
+    dptr = 0
+    norms = []
+    orig = TR.clip_grad_norm_
+
+    def spy(params, max_norm):
+        n = orig(params, max_norm)
+        norms.append(float(n))
+        return n
+    TR.clip_grad_norm_ = spy
+    try:
+        for step, idxs in enumerate(z["batches"]):
+            g = lambda k: torch.from_numpy(np.stack([z["ex/%d/%s" % (i, k)] for i in idxs])).cuda()
+            n_docs = len(idxs) * K1
+            rows = docs_all[dptr:dptr + n_docs]
+            dptr += n_docs
+            doc_ids = np.zeros((n_docs, 512), np.int64)          # pad_input_ids_with_mask(doc_ids, 512) (:136-137)
+            doc_mask = np.zeros((n_docs, 512), np.int64)
+            for r, row in enumerate(rows):
+                n = int((row >= 0).sum())
+                doc_ids[r, :n] = row[:n]
+                doc_mask[r, :n] = 1
+            loss, l1, l2 = TR.train_step(args, student, teacher, opt, sched,
+                                         (g("concat_ids"), g("concat_id_mask"), g("target_ids"), g("target_id_mask")),
+                                         torch.from_numpy(doc_ids).cuda(), torch.from_numpy(doc_mask).cuda())
+            assert abs(l1.item() - z["loss1"][step]) < 2e-2 * z["loss1"][step] + 2e-5, (step, l1.item(), z["loss1"][step])
+            # logits are 768-d dots of ~27-norm vectors (|logit| ~ 10^2): bf16-level embedding error moves the CE by ~1e-2
+            assert abs(l2.item() - z["loss2"][step]) < 3e-2, (step, l2.item(), z["loss2"][step])
+    finally:
+        TR.clip_grad_norm_ = orig
+    # the ranking-loss gradient (softmax - onehot) . docs inherits the CE sensitivity above: direction cos ~0.97, norm +5 %
+    np.testing.assert_allclose(norms, z["grad_norm"], rtol=8e-2)
+    # parameters: compare the UPDATE (w1 - w0).  Adam normalises every element's step to ~lr, so elements whose
+    # gradient is rounding noise (exactly-zero true gradients such as key.bias, tiny LayerNorm terms) move by a
+    # full-size pseudo-random step in BOTH implementations; the optimizer arithmetic itself is pinned bit-tight by
+    # test_clip_and_adamw_match_oracle.  Here: overall direction and magnitude of the update.
+    got = student.state_dict()
+    dot = nu = nr = 0.0
+    for k, w1 in sd1.items():
+        if not w1.dtype.is_floating_point or k not in got or k.endswith("key.bias"):
+            continue
+        du = (got[k].detach().cpu() - sd0[k]).double()
+        dr = (w1 - sd0[k]).double()
+        dot += float((du * dr).sum()); nu += float((du ** 2).sum()); nr += float((dr ** 2).sum())
+        if dr.abs().max() == 0:
+            assert du.abs().max() < 1e-7, k          # untouched parameters (pooler / classifier) stay untouched
+    assert nr > 0 and dot / (nu * nr) ** 0.5 > 0.9, dot / (nu * nr) ** 0.5
+    assert abs((nu / nr) ** 0.5 - 1) < 0.05, (nu / nr) ** 0.5
