@@ -80,6 +80,88 @@ def cpu_baseline(nq, d, k, L, budget_s=12.0):
                       "search: %d queries x %d passages x %d reps, fp32 SGEMM + topk(%d)" % (B, L, reps, nq, n, r2, k)}
 
 
+def main_train(args):
+    """configs[2]: run_convdr_train.py KD-only loop (MSE teacher-student), batch 64, seq 256, synthetic turns."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from types import SimpleNamespace
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    from convdr_amd import _lib, train as TR
+    from convdr_amd.parallel import DataParallelStudent
+    L_ = _lib.lib()
+    Bt, Ls, Lt = args.train_batch, 256, 64
+    student = random_rdot_model(0).to(dev)
+    teacher = random_rdot_model(0).to(dev).eval()
+    student.config.hidden_dropout_prob = student.config.attention_probs_dropout_prob = 0.0
+    targs = SimpleNamespace(learning_rate=1e-5, adam_epsilon=1e-8, max_grad_norm=1.0, ranking_task=False, no_mse=False,
+                            num_negatives=9, gradient_accumulation_steps=1)
+    opt = TR.get_optimizer(targs, student, weight_decay=0.0)
+    sched = TR.get_linear_schedule_with_warmup(opt, 0, 10_000)
+    ddp = DataParallelStudent(student) if world > 1 else None
+    g = torch.Generator(device=dev).manual_seed(rank)
+    def turns(L, lo):
+        ids = torch.randint(3, 50000, (Bt, L), generator=g, device=dev)
+        ids[:, 0] = 0
+        lens = torch.randint(lo, L + 1, (Bt,), generator=g, device=dev)
+        mask = (torch.arange(L, device=dev)[None, :] < lens[:, None]).long()
+        return ids * mask, mask
+    batches = [turns(Ls, 32) + turns(Lt, 8) for _ in range(4)]
+
+    def step(i):
+        return TR.train_step(targs, student, teacher, opt, sched, batches[i % 4], ddp=ddp)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    L_.convdr_prof_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)[0]
+    sync_all()
+    el = time.perf_counter() - t0
+    names = ("gemm_qkv", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2", "gemm_dgrad", "gemm_wgrad", "attention", "attention_bwd",
+             "transpose", "layernorm_bwd")
+    kern = {}
+    for nme in names:
+        ms, cnt = _lib.prof_collect(nme)
+        if cnt:
+            kern[nme] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps}
+    L_.convdr_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    real_tokens = float(np.mean([b[1].sum().item() for b in batches]))
+    flop_dense = Bt * (3 * flop_per_passage(Ls) + flop_per_passage(Lt))
+    flop_real = 3 * LINEAR_FLOP_PER_TOKEN * real_tokens
+    sps = world * Bt * args.steps / el
+    print(json.dumps({
+        "metric": "KD training samples/s (configs[2]: run_convdr_train.py KD-only, batch %d, seq %d/%d)" % (Bt, Ls, Lt),
+        "value": sps, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 compute, fp32 master weights / optimizer", "data": "synthetic OR-QuAC-shaped turns (ragged)",
+        "config": {"workload": "configs[2] train_kd", "batch_per_gpu": Bt, "student_seq": Ls, "teacher_seq": Lt,
+                   "parallelism": "dp%d" % world, "mean_real_student_tokens": real_tokens},
+        "final_loss": float(loss),
+        "TFLOPs_dense_padded_count": sps / world * flop_dense / Bt / 1e12,
+        "TFLOPs_real_token_count_linear_only": flop_real * args.steps / el / 1e12,
+        "kernels": kern}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +173,13 @@ def main():
     ap.add_argument("--enc-batch", type=int, default=2048)
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="encode_search", choices=["encode_search", "train_kd"],
+                    help="encode_search = BASELINE configs[1] (the headline line); train_kd = configs[2]: KD-only "
+                         "(MSE teacher-student) training steps, batch 64, student seq 256, teacher seq 64")
+    ap.add_argument("--train-batch", type=int, default=64)
     args = ap.parse_args()
+    if args.workload == "train_kd":
+        return main_train(args)
 
     import numpy as np
     import torch

@@ -1,0 +1,84 @@
+"""Multi-GPU pieces of the hot path: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl" on ROCm;
+"gloo" in the CPU tests).  Only the steps that are real exchanges use a collective:
+
+  corpus encode   no collective: rank r encodes records i % W == r and writes its own block pair (encode.py)
+  search          every rank searches its resident block with the replicated query matrix; the per-rank top-k lists
+                  (k scores + k record offsets per query: 9.6 MB at W = 8, Nq = 1k, k = 100) are all-gathered once and
+                  merged with the reference's tie rule "earlier block first" (run_convdr_inference.py:218);
+                  queries encoded data-parallel are all-gathered first (3 MB at Nq = 1k)
+  training        the reference uses single-process nn.DataParallel (run_convdr_train.py:77-78); here: one replica per
+                  GPU, per-rank batches, ONE all-reduce of the flat fp32 gradient buffer per step (the backward already
+                  writes every gradient into one contiguous arena, so there is nothing to bucket), averaged over ranks
+"""
+import torch
+import torch.distributed as dist
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def all_gather_rows(x, group=None):
+    """[n_local, d] on every rank (equal n_local) -> [W * n_local, d], rank order."""
+    W = _world()
+    if W == 1:
+        return x
+    parts = [torch.empty_like(x) for _ in range(W)]
+    dist.all_gather(parts, x.contiguous(), group=group)
+    return torch.cat(parts, 0)
+
+
+def merge_rank_topk(D_all, I_all, k):
+    """D_all / I_all: [W, nq, k] per-rank results (each row sorted descending) -> global [nq, k].
+    Ties keep the lower rank (= earlier block) first, then the earlier position: a stable descending sort of the
+    rank-ordered concatenation, which is what chaining the reference's `>=` two-way merge over blocks 0..W-1 gives."""
+    W, nq, kk = D_all.shape
+    d = D_all.permute(1, 0, 2).reshape(nq, W * kk)
+    i = I_all.permute(1, 0, 2).reshape(nq, W * kk)
+    order = torch.sort(d, dim=1, descending=True, stable=True).indices[:, :k]
+    return torch.gather(d, 1, order), torch.gather(i, 1, order)
+
+
+def search_sharded(index, queries, k, embid, group=None):
+    """Exact global top-k over a corpus whose block r is resident on rank r.
+    index: FlatIPIndex (or any object with .search(q, k) -> numpy (D, I)); embid: this block's int64 record offsets
+    (passage__embid_p__data_obj_{rank}.pb).  Returns (D float32 [nq, k], offsets int64 [nq, k]) on every rank."""
+    import numpy as np
+    D, I = index.search(queries, k)
+    ids = np.where(I >= 0, np.asarray(embid)[np.clip(I, 0, None)], -1)
+    dev = getattr(index, "device", torch.device("cpu"))
+    Dt, It = torch.from_numpy(D).to(dev), torch.from_numpy(ids).to(dev)
+    W = _world()
+    if W == 1:
+        return D, ids
+    Dl = [torch.empty_like(Dt) for _ in range(W)]
+    Il = [torch.empty_like(It) for _ in range(W)]
+    dist.all_gather(Dl, Dt, group=group)
+    dist.all_gather(Il, It, group=group)
+    Dm, Im = merge_rank_topk(torch.stack(Dl), torch.stack(Il), k)
+    return Dm.cpu().numpy(), Im.cpu().numpy()
+
+
+class DataParallelStudent:
+    """Gradient synchronisation for one-process-per-GPU training of the student."""
+
+    def __init__(self, model, group=None, broadcast=True):
+        self.model, self.group = model, group
+        if broadcast and _world() > 1:   # what the DDP constructor does (gen_passage_embeddings.py:64-69)
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, 0, group=group)
+
+    def allreduce_grads(self):
+        W = _world()
+        if W == 1:
+            return
+        from .train import _flat_view
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        flat = _flat_view(grads)
+        if flat is not None:                       # the usual case: one arena written by convdr_encoder_backward
+            dist.all_reduce(flat, group=self.group)
+            flat.div_(W)
+            return
+        for g in grads:
+            dist.all_reduce(g, group=self.group)
+            g.div_(W)

@@ -312,7 +312,7 @@ def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_st
     return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda, last_epoch)
 
 
-def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=None, doc_mask=None):
+def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=None, doc_mask=None, ddp=None):
     """One iteration of the reference loop body (run_convdr_train.py:101-193) with pre-tokenised ranking documents
     (`doc_ids` / `doc_mask` int64 [B * (num_negatives + 1), Ld], positive first within each group).
     Returns (loss, loss1, loss2) as device scalars."""
@@ -336,6 +336,8 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
     if getattr(args, "gradient_accumulation_steps", 1) > 1:
         loss = loss / args.gradient_accumulation_steps
     loss.backward()
+    if ddp is not None:
+        ddp.allreduce_grads()          # one all-reduce of the flat gradient arena (parallel.py)
     clip_grad_norm_(list(model.parameters()), args.max_grad_norm)
     optimizer.step()
     scheduler.step()

@@ -1,0 +1,91 @@
+"""world_size-2 gloo tests of the multi-process paths (CPU): corpus sharding, sharded search merge, gradient
+all-reduce.  The per-rank compute is played by the CPU oracle here; the GPU kernels are covered by the -m gpu tests."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, fn, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2, port=29611):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _search_job(rank, world):
+    from convdr_amd import blocks, parallel
+    from oracle import search as OS
+    rs = np.random.RandomState(0)
+    N, d, k = 601, 64, 20
+    P = rs.randn(N, d).astype(np.float32)
+    P[300] = P[7]                               # exact duplicate across ranks -> tie rule
+    Q = rs.randn(9, d).astype(np.float32)
+    mine = blocks.shard_indices(N, world, rank)  # records i % W == rank, like the encode loop writes them
+
+    class OracleIndex:
+        device = torch.device("cpu")
+
+        def search(self, q, kk):
+            return OS.flat_ip_search(q, P[mine], kk)
+    D, I = parallel.search_sharded(OracleIndex(), Q, k, mine)
+    # reference semantics: search_one_by_one over blocks 0..W-1
+    blocks_all = [(P[blocks.shard_indices(N, world, r)], blocks.shard_indices(N, world, r)) for r in range(world)]
+    mD, mI = OS.search_one_by_one(blocks_all, Q, k)
+    return bool(np.array_equal(I, mI[:, :k]) and np.allclose(D, mD[:, :k]))
+
+
+def test_sharded_search_merge_matches_search_one_by_one():
+    assert all(_run(_search_job, 2, 29611))
+
+
+def _ddp_job(rank, world):
+    from convdr_amd import parallel
+    torch.manual_seed(0)
+    model = torch.nn.Linear(8, 4)
+    if rank == 1:
+        with torch.no_grad():
+            model.weight.add_(1.0)               # ranks start different: the constructor must broadcast rank 0
+    ddp = parallel.DataParallelStudent(model)
+    w_after_bcast = model.weight.detach().clone()
+    flat = torch.zeros(36)
+    model.weight.grad = flat[:32].view(4, 8)     # one gradient arena, like convdr_encoder_backward produces
+    model.bias.grad = flat[32:].view(4)
+    flat.fill_(float(rank + 1))
+    ddp.allreduce_grads()
+    return w_after_bcast.sum().item(), model.weight.grad.mean().item(), model.bias.grad.mean().item()
+
+
+def test_gradient_allreduce_averages_flat_arena():
+    r = _run(_ddp_job, 2, 29612)
+    assert r[0][0] == r[1][0]                                   # parameters broadcast from rank 0
+    for w, gw, gb in r:
+        assert gw == pytest.approx(1.5) and gb == pytest.approx(1.5)
+
+
+def _gather_job(rank, world):
+    from convdr_amd import parallel
+    x = torch.full((3, 5), float(rank))
+    y = parallel.all_gather_rows(x)
+    return y[:, 0].tolist()
+
+
+def test_all_gather_rows_is_rank_ordered():
+    for r in _run(_gather_job, 2, 29613):
+        assert r == [0.0] * 3 + [1.0] * 3
