@@ -73,7 +73,7 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
   p.Drow = (float*)take((size_t)c->heads * p.ldt * 4);
   p.slab_elems = SLAB_ELEMS;
   p.slab = (float*)take(p.slab_elems * 4);
-  p.part = (float*)take((size_t)LN_BWD_BLOCKS * 3 * 3072 * 4 + (size_t)16 * 3 * 3072 * 4);
+  p.part = (float*)take((size_t)LN_BWD_BLOCKS * 3 * 3072 * 4 + (size_t)64 * 3 * 3072 * 4);
   p.dcls_y = (float*)take(Bp * H * 4);
   p.dcls_f = (float*)take(Bp * H * 4);
   p.dhead_y = (float*)take(Bp * E * 4);
@@ -143,9 +143,10 @@ static int wgrad(const bf16_t* dYt, int N, const bf16_t* Xt, int K, int64_t Tp, 
 
 static int bias_grad(const bf16_t* dY, int64_t rows, int C, const TrainBufs& p, float* db, hipStream_t st) {
   float* part = p.part + (size_t)LN_BWD_BLOCKS * 3 * 3072;
-  hipLaunchKernelGGL(k_colsum_bf16, dim3((C + 255) / 256, 16), dim3(256), 0, st, dY, rows, C, part);
+  const int chunks = rows >= 2048 ? 64 : 8;
+  hipLaunchKernelGGL(k_colsum_bf16, dim3((C + 127) / 128, chunks), dim3(256), 0, st, dY, rows, C, part);
   CONVDR_CHECK_LAUNCH("k_colsum_bf16");
-  hipLaunchKernelGGL(k_reduce_partials, dim3((C + 255) / 256), dim3(256), 0, st, part, 16, (int64_t)C, (int64_t)C, db, 1);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((C + 255) / 256), dim3(256), 0, st, part, chunks, (int64_t)C, (int64_t)C, db, 1);
   CONVDR_CHECK_LAUNCH("k_reduce_partials(bias)");
   return 0;
 }

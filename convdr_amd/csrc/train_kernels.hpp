@@ -164,16 +164,28 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict
   }
 }
 
-// column sums of a bf16 matrix [rows, C]: part[chunk][C]; grid (ceil(C/256), chunks)
-__global__ void __launch_bounds__(256) k_colsum_bf16(const bf16_t* __restrict__ in, int64_t rows, int C,
-                                                     float* __restrict__ part) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+// column sums of a bf16 matrix [rows, C] (C even): part[chunk][C]; grid (ceil(C/128), chunks).
+// 256 threads = 64 column pairs x 4 row lanes; each block sums its row chunk, then folds the 4 row lanes in LDS.
+static __global__ void __launch_bounds__(256) k_colsum_bf16(const bf16_t* __restrict__ in, int64_t rows, int C,
+                                                            float* __restrict__ part) {
+  __shared__ float red[4][128];
+  const int cp = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 128 + 2 * cp;
   const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
   const int64_t t0 = per * blockIdx.y, t1 = t0 + per < rows ? t0 + per : rows;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int64_t t = t0; t < t1; ++t) s += bf16_to_f32(in[t * C + c]);
-  part[(int64_t)blockIdx.y * C + c] = s;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C)
+    for (int64_t t = t0 + rl; t < t1; t += 4) {
+      const uint32_t v = *(const uint32_t*)(in + t * C + c);
+      s0 += __uint_as_float(v << 16);
+      s1 += __uint_as_float(v & 0xffff0000u);
+    }
+  red[rl][2 * cp] = s0;
+  red[rl][2 * cp + 1] = s1;
+  __syncthreads();
+  if (threadIdx.x < 128 && blockIdx.x * 128 + threadIdx.x < C)
+    part[(int64_t)blockIdx.y * C + blockIdx.x * 128 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // dst[cu[b], :] = src[b, :] for b < B (dst pre-zeroed): scatter CLS-row gradients into a [rows, H] matrix

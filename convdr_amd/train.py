@@ -212,6 +212,7 @@ def _flat_view(tensors):
     """The single flat buffer the tensors tile contiguously, or None."""
     if not tensors:
         return None
+    tensors = sorted(tensors, key=lambda t: t.data_ptr())     # parameter order != arena order
     base = tensors[0]
     start = base.data_ptr()
     off = start
