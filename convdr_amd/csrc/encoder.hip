@@ -9,7 +9,7 @@ namespace convdr {
 
 struct EncBufs {
   int32_t *tok_id, *tok_pos;
-  bf16_t *X, *Q, *K, *Vt, *ctx, *Hm, *cls_b;
+  bf16_t *X, *Q, *K, *Vt, *ctx, *Hm, *cls_b, *cls_ctx, *cls_x, *cls_x1;
   float *Y, *cls_y, *cls_f, *head_y;
   int64_t ldt;
   size_t total;
@@ -33,6 +33,9 @@ static EncBufs enc_plan(const convdr_encoder_config* c, int64_t rows, int B, cha
   p.Y = (float*)take(rs * H * 4);
   const int64_t Bp = B + 128;
   p.cls_b = (bf16_t*)take(Bp * H * 2);
+  p.cls_ctx = (bf16_t*)take(Bp * H * 2);
+  p.cls_x = (bf16_t*)take(Bp * H * 2);
+  p.cls_x1 = (bf16_t*)take(Bp * H * 2);
   p.cls_y = (float*)take(Bp * H * 4);
   p.cls_f = (float*)take(Bp * H * 4);
   p.head_y = (float*)take(Bp * (c->out_dim > 0 ? c->out_dim : 1) * 4);
@@ -50,9 +53,13 @@ static int check_config(const convdr_encoder_config* c) {
 }
 
 // One transformer layer on packed rows; buffers may be shared across layers (inference).
+// cls_only (last layer): only the CLS rows of the output are live (models.py:43), so after attention the CLS rows of
+// ctx and of the layer input are gathered into compact [B, H] buffers and the output projection, LayerNorm and FFN run
+// on B rows instead of `rows` (K and V still need every token): saves 9/12 of the last layer's GEMM work.
+// On return the pre-LayerNorm2 sums are in p.Y: rows [0, rows) normally, rows [0, B) = one per sequence when cls_only.
 int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_weights* w, const EncBufs& p,
                           const int32_t* cu, const int32_t* lens, int64_t rows, int B, int max_len, float* lse,
-                          hipStream_t st) {
+                          bool cls_only, hipStream_t st) {
   const int H = c->hidden, I = c->intermediate;
   GemmArgs g{};
   g.rows = rows;
@@ -63,25 +70,38 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
   {
     AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, (int64_t)H, p.ctx, lse, 0.125f};
     ProfScope prof("attention", st);
-    hipLaunchKernelGGL(k_attention_fwd, dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
+    // cls_only: the first query block of every sequence is enough (it contains the CLS row)
+    hipLaunchKernelGGL(k_attention_fwd, dim3(cls_only ? 1 : (max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st,
+                       a);
     CONVDR_CHECK_LAUNCH("k_attention_fwd");
   }
-  // attention output dense + residual -> Y (fp32) -> LayerNorm -> X
+  const bf16_t *xin = p.X, *ctx = p.ctx;
+  bf16_t* x1 = p.X;
+  int64_t n = rows;
+  if (cls_only) {
+    hipLaunchKernelGGL(k_gather_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu, B, H, p.ctx, (const float*)nullptr, p.cls_ctx,
+                       (float*)nullptr);
+    hipLaunchKernelGGL(k_gather_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu, B, H, p.X, (const float*)nullptr, p.cls_x,
+                       (float*)nullptr);
+    CONVDR_CHECK_LAUNCH("k_gather_cls");
+    xin = p.cls_x; ctx = p.cls_ctx; x1 = p.cls_x1; n = B;
+  }
+  // attention output dense + residual -> Y (fp32) -> LayerNorm -> X1
   g = GemmArgs{};
-  g.rows = rows; g.W = (const bf16_t*)w->wo; g.X = p.ctx; g.N = H; g.K = H; g.bias = w->bo; g.Cf = p.Y; g.R = p.X;
+  g.rows = n; g.W = (const bf16_t*)w->wo; g.X = ctx; g.N = H; g.K = H; g.bias = w->bo; g.Cf = p.Y; g.R = xin;
   if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_attn_out")) return e;
   {
     ProfScope prof("layernorm", st);
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.Y, rows, H, w->ln1_g,
-                       w->ln1_b, c->ln_eps, p.X, (float*)nullptr);
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, st, p.Y, n, H, w->ln1_g, w->ln1_b,
+                       c->ln_eps, x1, (float*)nullptr);
     CONVDR_CHECK_LAUNCH("k_layernorm");
   }
   // FFN
   g = GemmArgs{};
-  g.rows = rows; g.W = (const bf16_t*)w->w1; g.X = p.X; g.N = I; g.K = H; g.bias = w->b1; g.Cb = p.Hm;
+  g.rows = n; g.W = (const bf16_t*)w->w1; g.X = x1; g.N = I; g.K = H; g.bias = w->b1; g.Cb = p.Hm;
   if (int e = launch_gemm<EPI_GELU_BF16>(g, st, "gemm_ffn1")) return e;
   g = GemmArgs{};
-  g.rows = rows; g.W = (const bf16_t*)w->w2; g.X = p.Hm; g.N = H; g.K = I; g.bias = w->b2; g.Cf = p.Y; g.R = p.X;
+  g.rows = n; g.W = (const bf16_t*)w->w2; g.X = p.Hm; g.N = H; g.K = I; g.bias = w->b2; g.Cf = p.Y; g.R = x1;
   if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_ffn2")) return e;
   return 0;
 }
@@ -129,19 +149,17 @@ extern "C" int convdr_encoder_forward(const convdr_encoder_config* cfg, const co
   }
   for (int l = 0; l < cfg->layers; ++l) {
     const convdr_layer_weights* lw = &w->layers[l];
-    if (int e = encoder_layer_forward(cfg, lw, p, cu_seqlens, seq_lens, rows, B, max_len, nullptr, st)) return e;
-    if (l + 1 < cfg->layers) {
+    const bool last = l + 1 == cfg->layers;
+    if (int e = encoder_layer_forward(cfg, lw, p, cu_seqlens, seq_lens, rows, B, max_len, nullptr, last, st)) return e;
+    if (!last) {
       ProfScope prof("layernorm", st);
       hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.Y, rows, H, lw->ln2_g,
                          lw->ln2_b, cfg->ln_eps, p.X, (float*)nullptr);
       CONVDR_CHECK_LAUNCH("k_layernorm");
     } else {
-      // only the CLS rows of the last layer are live (models.py:43): gather their pre-LN sums, LayerNorm B rows
-      hipLaunchKernelGGL(k_gather_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, (const bf16_t*)nullptr,
-                         p.Y, (bf16_t*)nullptr, p.cls_y);
-      CONVDR_CHECK_LAUNCH("k_gather_cls");
+      // the last layer ran its tail on the CLS rows only: p.Y[0..B) are their pre-LN sums
       float* cls_out = cfg->out_dim > 0 ? p.cls_f : out;
-      hipLaunchKernelGGL(k_layernorm, dim3((B + 3) / 4), dim3(256), 0, st, p.cls_y, (int64_t)B, H, lw->ln2_g, lw->ln2_b,
+      hipLaunchKernelGGL(k_layernorm, dim3((B + 3) / 4), dim3(256), 0, st, p.Y, (int64_t)B, H, lw->ln2_g, lw->ln2_b,
                          cfg->ln_eps, p.cls_b, cls_out);
       CONVDR_CHECK_LAUNCH("k_layernorm(cls)");
     }
