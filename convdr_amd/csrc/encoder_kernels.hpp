@@ -397,12 +397,11 @@ struct AttnArgs {
   float scale;      // 1 / sqrt(head_dim)
 };
 
-constexpr int ATT_SMEM_BYTES = 2 * 64 * 128;  // K tile + V^T tile, 8 KB each
+constexpr int ATT_TILE_PAIR = 2 * 64 * 128;   // K tile + V^T tile, 8 KB each
+constexpr int ATT_SMEM_BYTES = 2 * ATT_TILE_PAIR;  // double buffered
 
-static __global__ void __launch_bounds__(256) k_attention_fwd(const AttnArgs a) {
+static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;
-  char* sV = smem + 64 * 128;
   const int b = blockIdx.z, h = blockIdx.y;
   const int len = a.lens[b];
   const int q0 = blockIdx.x * 128;
@@ -431,18 +430,26 @@ static __global__ void __launch_bounds__(256) k_attention_fwd(const AttnArgs a) 
   const int krow = (li & ~12) | ((li & 4) << 1) | ((li & 8) >> 1);  // bits 2 <-> 3
   const int ksw = (krow >> 1) & 7;
 
-  for (int kv0 = 0; kv0 < len; kv0 += 64) {
-    __syncthreads();  // previous tile fully consumed
+  // K / V^T tiles are double buffered: the LDS-DMA of tile t+1 flies under the MFMAs of tile t
+  auto stage_tile = [&](int kv0, int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {  // 64 rows x 128 B per tile = 2 LDS-DMA rounds of 256 lanes x 16 B
       const int r0 = (i * 4 + wave) * 8;
       const int row = r0 + (lane >> 3);
       const int gch = (lane & 7) ^ ((row >> 1) & 7);
-      glds16((const char*)(a.K + (base + kv0 + row) * a.ldq + h * 64) + gch * 16, sK + r0 * 128);
-      glds16((const char*)(a.Vt + (int64_t)(h * 64 + row) * a.ldt + base + kv0) + gch * 16, sV + r0 * 128);
+      glds16((const char*)(a.K + (base + kv0 + row) * a.ldq + h * 64) + gch * 16, smem + buf * ATT_TILE_PAIR + r0 * 128);
+      glds16((const char*)(a.Vt + (int64_t)(h * 64 + row) * a.ldt + base + kv0) + gch * 16,
+             smem + buf * ATT_TILE_PAIR + 64 * 128 + r0 * 128);
     }
+  };
+  stage_tile(0, 0);
+  for (int kv0 = 0, it = 0; kv0 < len; kv0 += 64, ++it) {
+    const int buf = it & 1;
     lds_dma_wait_all();  // explicit: hipcc's automatic vmcnt wait for LDS-DMA is not reliable (gemm_nt.hpp)
-    __syncthreads();
+    __syncthreads();     // tile `it` landed for everyone; everyone finished reading tile it-1 (the other buffer)
+    if (kv0 + 64 < len) stage_tile(kv0 + 64, buf ^ 1);
+    const char* sK = smem + buf * ATT_TILE_PAIR;
+    const char* sV = sK + 64 * 128;
 
     // ---- S^T = K Q^T for the 64 keys of this tile ----
     f32x16 st[2];
@@ -459,24 +466,30 @@ static __global__ void __launch_bounds__(256) k_attention_fwd(const AttnArgs a) 
     }
     // register r of tile kt <-> key kv0 + 32 kt + 16 (r >> 3) + 8 hi + (r & 7)
     float mx = -INFINITY;
+    if (kv0 + 64 > len) {  // ragged last tile only (workgroup-uniform): mask the keys past the sequence
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
+          if (key >= len) st[kt][r] = -INFINITY;
+        }
+    }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
-        if (key >= len) st[kt][r] = -INFINITY;
-        mx = fmaxf(mx, st[kt][r]);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);               // finite: every tile has >= 1 valid key
-    const float alpha = exp2f((m - mn) * c);     // m = -inf on the first tile -> 0
+    const float mnc = mn * c;
+    const float alpha = __builtin_amdgcn_exp2f(m * c - mnc);   // m = -inf on the first tile -> 0
     m = mn;
     float ps = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f((st[kt][r] - mn) * c);
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], c, -mnc));   // one FMA + one v_exp_f32 per score
         st[kt][r] = p;
         ps += p;
       }
