@@ -2,6 +2,7 @@
 // Reference call sites replaced:  model/models.py:140-148 (RobertaDot_NLL_LN.query_emb/body_emb),
 // :205-211 + :227-235 (HFBertEncoder / BiEncoder.query_emb/body_emb).
 #include "gemm_launch.hpp"
+#include "gemm_ln.hpp"
 
 #include "../../include/convdr_hip.h"
 
@@ -43,6 +44,36 @@ static EncBufs enc_plan(const convdr_encoder_config* c, int64_t rows, int B, cha
   return p;
 }
 
+static int64_t g_fused_ln_min_rows = 128 * 192;   // below this the 128-token tiles cannot fill the 256 CUs
+
+// Y = A W^T + bias + R, X = LayerNorm(Y): fused row-complete kernel for hidden size 768 and enough rows to fill the
+// chip, else GEMM (fp32 sums) + LayerNorm kernel.  `Yf` is the fp32 scratch of the unfused path.
+static int gemm_resid_ln(const bf16_t* W, const bf16_t* A, int64_t rows, int H, int K, const float* bias, const bf16_t* R,
+                         const float* gamma, const float* beta, float eps, float* Yf, bf16_t* X, const char* name,
+                         hipStream_t st) {
+  if (H == 768 && rows >= g_fused_ln_min_rows && K % LN_SLICE == 0) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      CONVDR_CHECK_HIP(
+          hipFuncSetAttribute((const void*)k_gemm_resid_ln, hipFuncAttributeMaxDynamicSharedMemorySize, LN_SMEM_BYTES));
+      attr_done = true;
+    }
+    GemmLnArgs a{W, A, rows, K, bias, R, gamma, beta, eps, X};
+    ProfScope prof(name, st);
+    hipLaunchKernelGGL(k_gemm_resid_ln, dim3((unsigned)ceil_div64(rows, TileLN::TL)), dim3(512), LN_SMEM_BYTES, st, a);
+    CONVDR_CHECK_LAUNCH("k_gemm_resid_ln");
+    return 0;
+  }
+  GemmArgs g{};
+  g.rows = rows; g.W = W; g.X = A; g.N = H; g.K = K; g.bias = bias; g.Cf = Yf; g.R = R;
+  if (int e = launch_gemm<EPI_RESID_F32>(g, st, name)) return e;
+  ProfScope prof("layernorm", st);
+  hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, Yf, rows, H, gamma, beta, eps, X,
+                     (float*)nullptr);
+  CONVDR_CHECK_LAUNCH("k_layernorm");
+  return 0;
+}
+
 static int check_config(const convdr_encoder_config* c) {
   CONVDR_REQUIRE(c->hidden % 128 == 0 && c->hidden <= 1024, "encoder: hidden must be a multiple of 128, <= 1024 (got %d)",
                  c->hidden);
@@ -56,7 +87,8 @@ static int check_config(const convdr_encoder_config* c) {
 // cls_only (last layer): only the CLS rows of the output are live (models.py:43), so after attention the CLS rows of
 // ctx and of the layer input are gathered into compact [B, H] buffers and the output projection, LayerNorm and FFN run
 // on B rows instead of `rows` (K and V still need every token): saves 9/12 of the last layer's GEMM work.
-// On return the pre-LayerNorm2 sums are in p.Y: rows [0, rows) normally, rows [0, B) = one per sequence when cls_only.
+// On return: p.X holds the layer output (LayerNorm2 applied); when cls_only, p.Y[0..B) holds the pre-LayerNorm2 sums of
+// the B CLS rows instead.
 int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_weights* w, const EncBufs& p,
                           const int32_t* cu, const int32_t* lens, int64_t rows, int B, int max_len, float* lse,
                           bool cls_only, hipStream_t st) {
@@ -86,24 +118,20 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
     CONVDR_CHECK_LAUNCH("k_gather_cls");
     xin = p.cls_x; ctx = p.cls_ctx; x1 = p.cls_x1; n = B;
   }
-  // attention output dense + residual -> Y (fp32) -> LayerNorm -> X1
-  g = GemmArgs{};
-  g.rows = n; g.W = (const bf16_t*)w->wo; g.X = ctx; g.N = H; g.K = H; g.bias = w->bo; g.Cf = p.Y; g.R = xin;
-  if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_attn_out")) return e;
-  {
-    ProfScope prof("layernorm", st);
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, st, p.Y, n, H, w->ln1_g, w->ln1_b,
-                       c->ln_eps, x1, (float*)nullptr);
-    CONVDR_CHECK_LAUNCH("k_layernorm");
-  }
+  // attention output dense + residual + LayerNorm -> X1
+  if (int e = gemm_resid_ln((const bf16_t*)w->wo, ctx, n, H, H, w->bo, xin, w->ln1_g, w->ln1_b, c->ln_eps, p.Y, x1,
+                            "gemm_attn_out", st))
+    return e;
   // FFN
-  g = GemmArgs{};
-  g.rows = n; g.W = (const bf16_t*)w->w1; g.X = x1; g.N = I; g.K = H; g.bias = w->b1; g.Cb = p.Hm;
-  if (int e = launch_gemm<EPI_GELU_BF16>(g, st, "gemm_ffn1")) return e;
-  g = GemmArgs{};
-  g.rows = n; g.W = (const bf16_t*)w->w2; g.X = p.Hm; g.N = H; g.K = I; g.bias = w->b2; g.Cf = p.Y; g.R = x1;
-  if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_ffn2")) return e;
-  return 0;
+  GemmArgs g2{};
+  g2.rows = n; g2.W = (const bf16_t*)w->w1; g2.X = x1; g2.N = I; g2.K = H; g2.bias = w->b1; g2.Cb = p.Hm;
+  if (int e = launch_gemm<EPI_GELU_BF16>(g2, st, "gemm_ffn1")) return e;
+  if (cls_only) {   // final embedding: fp32 pre-LN sums for the B CLS rows, LayerNorm'ed by the caller
+    g2 = GemmArgs{};
+    g2.rows = n; g2.W = (const bf16_t*)w->w2; g2.X = p.Hm; g2.N = H; g2.K = I; g2.bias = w->b2; g2.Cf = p.Y; g2.R = x1;
+    return launch_gemm<EPI_RESID_F32>(g2, st, "gemm_ffn2");
+  }
+  return gemm_resid_ln((const bf16_t*)w->w2, p.Hm, n, H, I, w->b2, x1, w->ln2_g, w->ln2_b, c->ln_eps, p.Y, p.X, "gemm_ffn2", st);
 }
 
 }  // namespace convdr
@@ -151,12 +179,7 @@ extern "C" int convdr_encoder_forward(const convdr_encoder_config* cfg, const co
     const convdr_layer_weights* lw = &w->layers[l];
     const bool last = l + 1 == cfg->layers;
     if (int e = encoder_layer_forward(cfg, lw, p, cu_seqlens, seq_lens, rows, B, max_len, nullptr, last, st)) return e;
-    if (!last) {
-      ProfScope prof("layernorm", st);
-      hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.Y, rows, H, lw->ln2_g,
-                         lw->ln2_b, cfg->ln_eps, p.X, (float*)nullptr);
-      CONVDR_CHECK_LAUNCH("k_layernorm");
-    } else {
+    if (last) {
       // the last layer ran its tail on the CLS rows only: p.Y[0..B) are their pre-LN sums
       float* cls_out = cfg->out_dim > 0 ? p.cls_f : out;
       hipLaunchKernelGGL(k_layernorm, dim3((B + 3) / 4), dim3(256), 0, st, p.Y, (int64_t)B, H, lw->ln2_g, lw->ln2_b,
@@ -184,4 +207,14 @@ extern "C" int convdr_encoder_debug_layout(const convdr_encoder_config* cfg, int
   for (int i = 0; i < 13; ++i) out[i] = (int64_t)(size_t)v[i];
   out[13] = p.ldt;
   return 0;
+}
+
+// Tuning / test knobs.  "fused_ln_min_rows": minimum packed rows for the fused GEMM + LayerNorm kernel.
+extern "C" int convdr_set_option(const char* name, int64_t value) {
+  if (strcmp(name, "fused_ln_min_rows") == 0) {
+    g_fused_ln_min_rows = value;
+    return 0;
+  }
+  set_error("convdr_set_option: unknown option %s", name);
+  return -1;
 }

@@ -206,6 +206,10 @@ int convdr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, d
                       double eps, double weight_decay, int step, int correct_bias, const float* grad_scale,
                       convdr_stream_t stream);
 
+/* Tuning / test knobs: "fused_ln_min_rows" = minimum packed rows for the fused GEMM + residual + LayerNorm kernel
+ * (default 24576; tests lower it to exercise that kernel on small inputs). */
+int convdr_set_option(const char* name, int64_t value);
+
 /* Test aid: byte offsets of the activation buffers inside the encoder workspace, in the order tok_id, tok_pos, X, Q, K,
  * Vt, ctx, Hm, Y, cls_b, cls_y, cls_f, head_y; out[13] = leading dimension of Vt. */
 int convdr_encoder_debug_layout(const convdr_encoder_config* cfg, int64_t rows, int B, int64_t* out);

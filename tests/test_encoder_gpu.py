@@ -155,3 +155,41 @@ def test_forward_is_bitwise_deterministic():
     assert not torch.isnan(outs[0]).any()
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+def test_fused_gemm_layernorm_kernel_matches_oracle():
+    """The row-complete GEMM + residual + LayerNorm kernel only engages for large batches; force it on a small one."""
+    from convdr_amd import _lib
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    torch.manual_seed(0)
+    model = MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig(vocab_size=1000, num_hidden_layers=3))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.02)
+            elif "LayerNorm.weight" in n or n == "norm.weight":
+                p.add_(torch.randn_like(p) * 0.05)
+    rs = np.random.RandomState(0)
+    lens = [128, 100, 65, 64, 63, 33, 32, 31, 17, 8, 2, 1, 77, 128]
+    ids = rs.randint(3, 1000, size=(len(lens), 128)).astype(np.int64)
+    ids[:, 0] = 0
+    mask = np.zeros_like(ids)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+        ids[b, n:] = 0
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = OE.rdot_nll_emb(sd, torch.from_numpy(ids), torch.from_numpy(mask), num_layers=3, num_heads=12).numpy()
+    model = model.cuda().eval()
+    L = _lib.lib()
+    try:
+        _lib.check(L.convdr_set_option(b"fused_ln_min_rows", 1), "convdr_set_option")
+        with torch.no_grad():
+            a = model.body_emb(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda())
+            b = model.body_emb(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda())
+    finally:
+        L.convdr_set_option(b"fused_ln_min_rows", 128 * 192)
+    assert torch.equal(a, b)
+    _check(a, ref, "fused gemm+ln")
+    with torch.no_grad():
+        c = model.body_emb(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda())     # unfused path
+    assert cosine(a.cpu().numpy(), c.cpu().numpy()).min() > 1 - 1e-4
