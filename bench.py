@@ -100,6 +100,7 @@ def main_train(args):
     student = random_rdot_model(0).to(dev)
     teacher = random_rdot_model(0).to(dev).eval()
     student.config.hidden_dropout_prob = student.config.attention_probs_dropout_prob = 0.0
+    TR.flatten_parameters(student)       # one fp32 arena: single-launch AdamW, single cast for the bf16 copies
     targs = SimpleNamespace(learning_rate=1e-5, adam_epsilon=1e-8, max_grad_norm=1.0, ranking_task=False, no_mse=False,
                             num_negatives=9, gradient_accumulation_steps=1)
     opt = TR.get_optimizer(targs, student, weight_decay=0.0)

@@ -436,3 +436,15 @@ extern "C" int convdr_scale_f32(float* x, int64_t n, const float* scale, convdr_
   CONVDR_CHECK_LAUNCH("k_scale_inplace");
   return 0;
 }
+
+// Batched weight packing for the data-gradient GEMMs: for i < count, fp32 [n[i], k[i]] at base + src_off[i] (elements)
+// -> bf16 [k[i], n[i]] at out + dst_off[i] (elements).  Host arrays; one launch per matrix, no Python round trips.
+extern "C" int convdr_pack_transposed(const float* base, int count, const int64_t* src_off, const int32_t* n, const int32_t* k,
+                                      const int64_t* dst_off, void* out, convdr_stream_t stream) {
+  for (int i = 0; i < count; ++i) {
+    hipLaunchKernelGGL(k_transpose_f32_bf16, dim3((k[i] + 63) / 64, (n[i] + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       base + src_off[i], n[i], k[i], (bf16_t*)out + dst_off[i]);
+  }
+  CONVDR_CHECK_LAUNCH("k_transpose_f32_bf16(batch)");
+  return 0;
+}

@@ -180,6 +180,10 @@ class EncoderTower(nn.Module):
         dev = self.embeddings.word_embeddings.weight.device
         if dev.type != "cuda":
             raise _lib.ConvdrError("the encoder runs on the GPU only (parameters are on %s); call .to('cuda')" % dev)
+        flat = getattr(self, "_flat", None)
+        if flat is not None and flat["head"] is (None if head is None else head[0]):
+            self._packed, self._packed_key = self._packed_from_flat(flat, head), key
+            return self._packed
         keep = []
 
         def f32(t):
@@ -224,6 +228,50 @@ class EncoderTower(nn.Module):
         keep.append(layers)
         self._packed, self._packed_key = (c, w, keep), key
         return self._packed
+
+    def _packed_from_flat(self, flat, head):
+        """Training fast path (train.flatten_parameters): every parameter is a view of ONE fp32 arena laid out so that
+        q/k/v weights (and biases) are adjacent, so the packed bf16 copies are a single cast of the arena's weight
+        range and every pointer is arena base + offset -- no torch.cat, no per-tensor kernels."""
+        cfg = self.config
+        P, off = flat["P"], flat["off"]
+        w0 = flat["w0"]                     # first element of the per-layer + head range
+        Pb = flat.get("Pb")
+        if Pb is None:
+            Pb = flat["Pb"] = torch.empty(P.numel() - w0, dtype=torch.bfloat16, device=P.device)
+        with torch.cuda.device(P.device):
+            _lib.check(_lib.lib().convdr_cast_f32_bf16(C.c_void_p(P.data_ptr() + 4 * w0), _lib.ptr(Pb), P.numel() - w0,
+                                                       _lib.stream_ptr()), "convdr_cast_f32_bf16")
+        f32 = lambda p: P.data_ptr() + 4 * off[id(p)]
+        b16 = lambda p: Pb.data_ptr() + 2 * (off[id(p)] - w0)
+        layers = (_lib.LayerWeights * cfg.num_hidden_layers)()
+        for i, ly in enumerate(self.encoder.layer):
+            s = ly.attention.self
+            lw = layers[i]
+            lw.wqkv, lw.bqkv = b16(s.query.weight), f32(s.query.bias)
+            lw.wo, lw.bo = b16(ly.attention.output.dense.weight), f32(ly.attention.output.dense.bias)
+            lw.ln1_g, lw.ln1_b = f32(ly.attention.output.LayerNorm.weight), f32(ly.attention.output.LayerNorm.bias)
+            lw.w1, lw.b1 = b16(ly.intermediate.dense.weight), f32(ly.intermediate.dense.bias)
+            lw.w2, lw.b2 = b16(ly.output.dense.weight), f32(ly.output.dense.bias)
+            lw.ln2_g, lw.ln2_b = f32(ly.output.LayerNorm.weight), f32(ly.output.LayerNorm.bias)
+        w = _lib.EncoderWeights()
+        e = self.embeddings
+        w.word_emb, w.pos_emb, w.type_emb = f32(e.word_embeddings.weight), f32(e.position_embeddings.weight), \
+            f32(e.token_type_embeddings.weight)
+        w.emb_ln_g, w.emb_ln_b = f32(e.LayerNorm.weight), f32(e.LayerNorm.bias)
+        w.layers = C.cast(layers, C.POINTER(_lib.LayerWeights))
+        out_dim, head_eps = 0, 1e-5
+        if head is not None:
+            lin, ln = head
+            w.head_w, w.head_b = b16(lin.weight), f32(lin.bias)
+            w.head_ln_g, w.head_ln_b = f32(ln.weight), f32(ln.bias)
+            out_dim, head_eps = lin.out_features, ln.eps
+        c = _lib.EncoderConfig(kind=0 if self.kind == "roberta" else 1, hidden=cfg.hidden_size,
+                               heads=cfg.num_attention_heads, layers=cfg.num_hidden_layers,
+                               intermediate=cfg.intermediate_size, vocab=e.word_embeddings.num_embeddings,
+                               max_pos=cfg.max_position_embeddings, pad_idx=cfg.pad_token_id if self.kind == "roberta" else 0,
+                               out_dim=out_dim, ln_eps=cfg.layer_norm_eps, head_ln_eps=head_eps)
+        return (c, w, [layers, P, Pb])
 
     # ---- forward ------------------------------------------------------------------------------
     def embed(self, input_ids, attention_mask, head=None, seq_lens=None):

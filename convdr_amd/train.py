@@ -41,6 +41,32 @@ def _tower_params(tower, head):
     return out
 
 
+def flatten_parameters(model):
+    """Re-home the student's trainable parameters into ONE contiguous fp32 arena (same order as the gradient arena
+    that convdr_encoder_backward fills), keeping every nn.Parameter object and name: ``p.data`` becomes a view.
+    Enables: a single fused AdamW launch, a single cast for the bf16 weight copies, one all-reduce for DDP.
+    Call after ``model.to(device)`` and before creating the optimizer."""
+    m = model.module if hasattr(model, "module") else model
+    if not hasattr(m, "roberta"):
+        return None                      # BiEncoder: two towers; the generic per-parameter path is used
+    tower, head = m.roberta, (m.embeddingHead, m.norm)
+    params = _tower_params(tower, head)
+    sizes = [p.numel() for p in params]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    dev = params[0].device
+    P = torch.empty(int(offs[-1]), dtype=torch.float32, device=dev)
+    off = {}
+    with torch.no_grad():
+        for p, o, n in zip(params, offs[:-1], sizes):
+            view = P[int(o):int(o) + n].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            off[id(p)] = int(o)
+    tower._flat = {"P": P, "off": off, "w0": int(offs[5]), "head": head[0], "params": params}
+    tower._packed = None
+    return tower._flat
+
+
 def _packed_t(tower, head):
     """Transposed bf16 weights for the data-gradient GEMMs (cached with the forward packing)."""
     c, w, keep = tower.packed(head)
@@ -49,6 +75,32 @@ def _packed_t(tower, head):
         return cache[1], cache[2]
     L = _lib.lib()
     dev = tower.embeddings.word_embeddings.weight.device
+    flat = getattr(tower, "_flat", None)
+    if flat is not None and flat["head"] is (None if head is None else head[0]):
+        mats = []
+        for ly in tower.encoder.layer:
+            s = ly.attention.self
+            mats += [(s.query.weight, 3), (ly.attention.output.dense.weight, 1), (ly.intermediate.dense.weight, 1),
+                     (ly.output.dense.weight, 1)]
+        if head is not None:
+            mats.append((head[0].weight, 1))
+        n = (C.c_int32 * len(mats))(*[p.shape[0] * mul for p, mul in mats])
+        k = (C.c_int32 * len(mats))(*[p.shape[1] for p, _ in mats])
+        src = (C.c_int64 * len(mats))(*[flat["off"][id(p)] for p, _ in mats])
+        dsts = np.concatenate([[0], np.cumsum([int(a) * int(b) for a, b in zip(n, k)])]).astype(np.int64)
+        dst = (C.c_int64 * len(mats))(*dsts[:-1].tolist())
+        T = flat.get("Pt")
+        if T is None:
+            T = flat["Pt"] = torch.empty(int(dsts[-1]), dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.convdr_pack_transposed(_lib.ptr(flat["P"]), len(mats), src, n, k, dst, _lib.ptr(T), _lib.stream_ptr()),
+                       "convdr_pack_transposed")
+        arr = (_lib.LayerWeightsT * len(tower.encoder.layer))()
+        for i in range(len(tower.encoder.layer)):
+            arr[i].wqkv_t, arr[i].wo_t, arr[i].w1_t, arr[i].w2_t = [T.data_ptr() + 2 * int(dsts[4 * i + j]) for j in range(4)]
+        head_t = T.data_ptr() + 2 * int(dsts[-2]) if head is not None else None
+        tower._packed_t = (keep, arr, head_t, [T, arr])
+        return arr, head_t
     hold = []
 
     def tr(t):
@@ -268,9 +320,42 @@ class AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
 
+    def _try_flat_step(self):
+        """One launch for the whole model when parameters live in a flat arena (flatten_parameters), the gradients are
+        the matching arena written by the backward, and all groups share their hyper-parameters."""
+        g0 = self.param_groups[0]
+        keys = ("lr", "betas", "eps", "weight_decay", "correct_bias")
+        if any(g[k] != g0[k] for g in self.param_groups for k in keys):
+            return False
+        ps = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if not ps:
+            return True
+        P = _flat_view([p.data for p in ps])
+        G = _flat_view([p.grad for p in ps])
+        if P is None or G is None or P.numel() != G.numel():
+            return False
+        order_p = sorted(ps, key=lambda p: p.data.data_ptr())
+        order_g = sorted(ps, key=lambda p: p.grad.data_ptr())
+        if any(a is not b for a, b in zip(order_p, order_g)):
+            return False
+        st = self.__dict__.setdefault("_flat_state", {})
+        if "m" not in st or st["m"].numel() != P.numel():
+            st["step"], st["m"], st["v"] = 0, torch.zeros_like(P), torch.zeros_like(P)
+        st["step"] += 1
+        b1, b2 = g0["betas"]
+        with torch.cuda.device(P.device):
+            _lib.check(_lib.lib().convdr_adamw_step(_lib.ptr(P), _lib.ptr(G), _lib.ptr(st["m"]), _lib.ptr(st["v"]), P.numel(),
+                                                    g0["lr"], b1, b2, g0["eps"], g0["weight_decay"], st["step"],
+                                                    int(g0["correct_bias"]), None, _lib.stream_ptr()), "convdr_adamw_step")
+        for p in ps:
+            _bump_version(p)
+        return True
+
     @torch.no_grad()
     def step(self, closure=None):
         L = _lib.lib()
+        if self._try_flat_step():
+            return
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:

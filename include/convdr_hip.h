@@ -180,6 +180,11 @@ int convdr_encoder_backward(const convdr_encoder_config* cfg, const convdr_encod
 /* fp32 [n, k] row-major -> bf16 [k, n] (packing of the transposed weights) */
 int convdr_transpose_f32_bf16(const float* x, int n, int k, void* y, convdr_stream_t stream);
 
+/* Batched form: for i < count, fp32 [n[i], k[i]] at base + src_off[i] -> bf16 [k[i], n[i]] at out + dst_off[i]
+ * (offsets in elements; src_off / n / k / dst_off are HOST arrays). */
+int convdr_pack_transposed(const float* base, int count, const int64_t* src_off, const int32_t* n, const int32_t* k,
+                           const int64_t* dst_off, void* out, convdr_stream_t stream);
+
 /* loss[0] = mean((s - t)^2) over n elements (nn.MSELoss); ds (nullable) = grad_scale * 2 (s - t) / n */
 int convdr_mse_fwd_bwd(const float* s, const float* t, int64_t n, float grad_scale, float* loss, float* ds,
                        convdr_stream_t stream);

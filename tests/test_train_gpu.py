@@ -220,3 +220,33 @@ def test_train_steps_match_reference_run(golden_dir):
             assert du.abs().max() < 1e-7, k          # untouched parameters (pooler / classifier) stay untouched
     assert nr > 0 and dot / (nu * nr) ** 0.5 > 0.9, dot / (nu * nr) ** 0.5
     assert abs((nu / nr) ** 0.5 - 1) < 0.05, (nu / nr) ** 0.5
+
+
+def test_flat_arena_training_matches_per_parameter_path():
+    """flatten_parameters + one-launch AdamW + single-cast weight packing == the per-parameter path, bit for bit."""
+    from types import SimpleNamespace
+    from convdr_amd import train as TR
+    rs = np.random.RandomState(5)
+    ids, mask = _batch(rs, 6, 48, [48, 20, 33, 5, 40, 12])
+    tid, tmask = _batch(rs, 6, 16, [16, 9, 4, 16, 7, 3])
+    batch = tuple(x.cuda() for x in (ids, mask, tid, tmask))
+    args = SimpleNamespace(learning_rate=1e-3, adam_epsilon=1e-8, max_grad_norm=1.0, ranking_task=False, no_mse=False,
+                           num_negatives=0, gradient_accumulation_steps=1)
+    results = []
+    for flat in (False, True):
+        student, teacher = _tiny(seed=3).cuda(), _tiny(seed=4).cuda().eval()
+        if flat:
+            assert TR.flatten_parameters(student) is not None
+            names = dict(student.named_parameters())
+            assert names["roberta.encoder.layer.0.attention.self.key.weight"].data_ptr() == \
+                names["roberta.encoder.layer.0.attention.self.query.weight"].data_ptr() + 128 * 128 * 4
+        opt = TR.get_optimizer(args, student, weight_decay=0.0)
+        sched = TR.get_linear_schedule_with_warmup(opt, 0, 10)
+        losses = [TR.train_step(args, student, teacher, opt, sched, batch)[0].item() for _ in range(3)]
+        results.append((losses, {k: v.detach().clone() for k, v in student.state_dict().items()}))
+    assert results[0][0] == results[1][0]
+    for k, v in results[0][1].items():
+        if "word_embeddings" in k or "position_embeddings" in k:
+            assert torch.allclose(v, results[1][1][k], rtol=1e-5, atol=1e-7), k
+        else:
+            assert torch.equal(v, results[1][1][k]), k
