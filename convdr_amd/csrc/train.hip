@@ -146,7 +146,7 @@ static int bias_grad(const bf16_t* dY, int64_t rows, int C, const TrainBufs& p, 
   const int chunks = rows >= 2048 ? 64 : 8;
   hipLaunchKernelGGL(k_colsum_bf16, dim3((C + 127) / 128, chunks), dim3(256), 0, st, dY, rows, C, part);
   CONVDR_CHECK_LAUNCH("k_colsum_bf16");
-  hipLaunchKernelGGL(k_reduce_partials, dim3((C + 255) / 256), dim3(256), 0, st, part, chunks, (int64_t)C, (int64_t)C, db, 1);
+  hipLaunchKernelGGL(k_reduce_partials_small, dim3((C + 63) / 64), dim3(256), 0, st, part, chunks, (int64_t)C, (int64_t)C, db, 1);
   CONVDR_CHECK_LAUNCH("k_reduce_partials(bias)");
   return 0;
 }
@@ -157,10 +157,15 @@ static int ln_bwd(const float* dY, const float* Yin, int64_t rows, int H, const 
   ProfScope prof("layernorm_bwd", st);
   hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, Yin, rows, H, g, eps, dXf, dXb, p.part);
   CONVDR_CHECK_LAUNCH("k_layernorm_bwd");
-  hipLaunchKernelGGL(k_reduce_partials, dim3((H + 255) / 256), dim3(256), 0, st, p.part, blocks, (int64_t)2 * H, (int64_t)H,
-                     dgamma, 1);
-  hipLaunchKernelGGL(k_reduce_partials, dim3((H + 255) / 256), dim3(256), 0, st, p.part + H, blocks, (int64_t)2 * H,
-                     (int64_t)H, dbeta, 1);
+  if (dbeta == dgamma + H) {   // weight and bias gradients adjacent in the arena: one launch
+    hipLaunchKernelGGL(k_reduce_partials_small, dim3((2 * H + 63) / 64), dim3(256), 0, st, p.part, blocks, (int64_t)2 * H,
+                       (int64_t)2 * H, dgamma, 1);
+  } else {
+    hipLaunchKernelGGL(k_reduce_partials_small, dim3((H + 63) / 64), dim3(256), 0, st, p.part, blocks, (int64_t)2 * H,
+                       (int64_t)H, dgamma, 1);
+    hipLaunchKernelGGL(k_reduce_partials_small, dim3((H + 63) / 64), dim3(256), 0, st, p.part + H, blocks, (int64_t)2 * H,
+                       (int64_t)H, dbeta, 1);
+  }
   CONVDR_CHECK_LAUNCH("k_reduce_partials(ln)");
   return 0;
 }
@@ -370,7 +375,7 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     CONVDR_CHECK_LAUNCH("k_embed_bwd");
     float* outs[3] = {gr->emb_ln_g, gr->emb_ln_b, gr->type_emb};
     for (int k = 0; k < 3; ++k) {
-      hipLaunchKernelGGL(k_reduce_partials, dim3((H + 255) / 256), dim3(256), 0, st, p.part + (size_t)k * H, blocks,
+      hipLaunchKernelGGL(k_reduce_partials_small, dim3((H + 63) / 64), dim3(256), 0, st, p.part + (size_t)k * H, blocks,
                          (int64_t)3 * H, (int64_t)H, outs[k], 1);
     }
     CONVDR_CHECK_LAUNCH("k_reduce_partials(embed)");

@@ -164,6 +164,25 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict
   }
 }
 
+// same contract for few outputs / many partials (LayerNorm and bias gradients): 64 outputs per block, the partials
+// are split over 4 thread rows and folded in LDS in a fixed order (deterministic)
+static __global__ void __launch_bounds__(256) k_reduce_partials_small(const float* __restrict__ part, int nparts,
+                                                                      int64_t stride, int64_t n, float* __restrict__ out,
+                                                                      int accumulate) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + c;
+  float s = 0.f;
+  if (i < n)
+    for (int p = r; p < nparts; p += 4) s += part[(int64_t)p * stride + i];
+  red[r][c] = s;
+  __syncthreads();
+  if (r == 0 && i < n) {
+    const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    out[i] = accumulate ? out[i] + t : t;
+  }
+}
+
 // column sums of a bf16 matrix [rows, C] (C even): part[chunk][C]; grid (ceil(C/128), chunks).
 // 256 threads = 64 column pairs x 4 row lanes; each block sums its row chunk, then folds the 4 row lanes in LDS.
 static __global__ void __launch_bounds__(256) k_colsum_bf16(const bf16_t* __restrict__ in, int64_t rows, int C,
