@@ -13,9 +13,10 @@ _SIGNATURES = {
     "convdr_last_error": (C.c_char_p, []),
     "convdr_prof_enable": (C.c_int, [C.c_int]),
     "convdr_prof_collect": (C.c_int, [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
-    "convdr_ip_prepare_block": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p, _p]),
+    "convdr_ip_column_mean": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p, _p]),
+    "convdr_ip_prepare_block": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p, _p, _p, _p]),
     "convdr_ip_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
-    "convdr_ip_search": (C.c_int, [_p, C.c_int, _p, _p, C.c_int64, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int,
+    "convdr_ip_search": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_int64, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int,
                                    _p, C.c_size_t, _p, _p, _p, _p, _p]),
     "convdr_ip_debug_counts": (_p, [_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "convdr_ip_debug_band": (_p, [_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),

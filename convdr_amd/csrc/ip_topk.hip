@@ -25,27 +25,43 @@ constexpr int IP_MODE_FULL = 0, IP_MODE_TOP2 = 1, IP_MODE_EMIT = 2;
 constexpr int IP_FULL_MAX_N = 32768;      // <= this many passages: "sample" = all scores, exact rank select
 constexpr int IP_SAMPLE_MIN = 32768;      // sampled passages (>= 1/32 of the block)
 constexpr int IP_SAMPLE_MAX = 262144;
-constexpr float IP_EPS_COEF = 0.0079f;    // 2u + u^2 + K*2^-24 with u = 2^-8, rounded up (K <= 4096)
+constexpr float IP_EPS_COEF = 0.0079f;    // bf16 scan: 2u + u^2 + K*2^-24 with u = 2^-8, rounded up (K <= 4096)
+// split-bf16 scan (hi*hi + hi*lo + lo*hi): dropped terms 3 u^2 = 4.6e-5, fp32 accumulation of 3K products
+// 3 * 4096 * 2^-24 = 7.4e-4 worst case -> rounded up
+constexpr float IP_EPS_COEF_X3 = 8.0e-4f;
 
 // ------------------------------------------------------------------------------------------
-// rows fp32 -> bf16 (+ per-row L2 norm, + global max norm).  One wave per row, float4 loads.
+// rows fp32 -> bf16 of (x - centre) (+ per-row L2 norm of the centred row, + global max norm).
+// Optional second output: the bf16 of the rounding remainder (x - centre) - hi, for the split-bf16 scan.
+// One wave per row, float4 loads.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_rows_to_bf16(const float* __restrict__ X, int64_t n, int d,
-                                                      bf16_t* __restrict__ Y, float* __restrict__ row_norm,
+                                                      const float* __restrict__ centre, bf16_t* __restrict__ Y,
+                                                      bf16_t* __restrict__ Ylo, float* __restrict__ row_norm,
                                                       float* __restrict__ max_norm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float wmax = 0.f;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n; row += (int64_t)gridDim.x * 4) {
     const float* x = X + row * d;
-    bf16_t* y = Y + row * d;
     float ss = 0.f;
     for (int e = lane * 4; e < d; e += 256) {
-      const float4 v = *(const float4*)(x + e);
+      float4 v = *(const float4*)(x + e);
+      if (centre) {
+        const float4 c = *(const float4*)(centre + e);
+        v.x -= c.x; v.y -= c.y; v.z -= c.z; v.w -= c.w;
+      }
       ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      const bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
       uint2 o;
-      o.x = pack_bf16x2(v.x, v.y);
-      o.y = pack_bf16x2(v.z, v.w);
-      *(uint2*)(y + e) = o;
+      o.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+      o.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+      *(uint2*)(Y + row * d + e) = o;
+      if (Ylo) {
+        uint2 l;
+        l.x = pack_bf16x2(v.x - bf16_to_f32(h0), v.y - bf16_to_f32(h1));
+        l.y = pack_bf16x2(v.z - bf16_to_f32(h2), v.w - bf16_to_f32(h3));
+        *(uint2*)(Ylo + row * d + e) = l;
+      }
     }
     ss = wave_sum(ss);
     const float nm = sqrtf(ss);
@@ -63,6 +79,25 @@ __global__ void __launch_bounds__(256) k_rows_to_bf16(const float* __restrict__ 
   }
 }
 
+// column sums of fp32 rows: part[chunk][d]; grid (ceil(d / 256), chunks)
+__global__ void __launch_bounds__(256) k_colsum_f32(const float* __restrict__ X, int64_t n, int d, float* __restrict__ part) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int64_t per = (n + gridDim.y - 1) / gridDim.y;
+  const int64_t t0 = per * blockIdx.y, t1 = t0 + per < n ? t0 + per : n;
+  if (c >= d) return;
+  float s = 0.f;
+  for (int64_t t = t0; t < t1; ++t) s += X[t * d + c];
+  part[(int64_t)blockIdx.y * d + c] = s;
+}
+__global__ void __launch_bounds__(256) k_colmean_finish(const float* __restrict__ part, int chunks, int d, int64_t n,
+                                                        float* __restrict__ mean) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d) return;
+  double s = 0.0;
+  for (int p = 0; p < chunks; ++p) s += part[(int64_t)p * d + c];
+  mean[c] = (float)(s / (double)n);
+}
+
 __global__ void k_fill_f32(float* p, int n, float v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -77,6 +112,8 @@ __global__ void k_fill_f32(float* p, int n, float v) {
 struct ScanArgs {
   const bf16_t* P;   // [n, d]
   const bf16_t* Qb;  // [nq_pad, d] (rows >= nq are zero)
+  const bf16_t* Plo; // split-bf16 scan: remainders (nullptr = plain bf16 scan)
+  const bf16_t* Qlo;
   int64_t n;
   int nq, nq_pad, d;
   int nPt, nQt;      // tiles actually visited / query tiles
@@ -101,6 +138,12 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan(const ScanArgs a) {
   GemmAcc<T> acc;
   acc.zero();
   gemm_nt_mainloop<T>(a.P, a.d, a.n, a.Qb, a.d, a.nq_pad, a.d, m0, n0, smem, acc, w);
+  if (a.Plo) {  // S~ = Ph Qh + Ph Ql + Pl Qh: fp32-class scores from three bf16 passes into the same accumulators
+    __syncthreads();
+    gemm_nt_mainloop<T>(a.P, a.d, a.n, a.Qlo, a.d, a.nq_pad, a.d, m0, n0, smem, acc, w);
+    __syncthreads();
+    gemm_nt_mainloop<T>(a.Plo, a.d, a.n, a.Qb, a.d, a.nq_pad, a.d, m0, n0, smem, acc, w);
+  }
 
   if constexpr (MODE == IP_MODE_EMIT) {
 #pragma unroll
@@ -227,8 +270,9 @@ __global__ void __launch_bounds__(1024) k_tau_select(const float* __restrict__ T
 __global__ void __launch_bounds__(256) k_ip_cut(int64_t n, int k, int cap, const uint32_t* __restrict__ counts,
                                                 uint32_t* __restrict__ cand_id, float* __restrict__ cand_s,
                                                 const float* __restrict__ tau, const float* __restrict__ qnorm,
-                                                const float* __restrict__ p_max_norm, uint32_t* __restrict__ m_out,
-                                                int32_t* __restrict__ status, float* __restrict__ tau_retry) {
+                                                const float* __restrict__ p_max_norm, float eps_coef,
+                                                uint32_t* __restrict__ m_out, int32_t* __restrict__ status,
+                                                float* __restrict__ tau_retry) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int sh_m;
   const int q = blockIdx.x;
@@ -261,7 +305,7 @@ __global__ void __launch_bounds__(256) k_ip_cut(int64_t n, int k, int cap, const
     }
   const int need = (int64_t)k < n ? k : (int)n;
   const float t = tau[q];
-  const float eps = IP_EPS_COEF * qnorm[q] * p_max_norm[0] * 1.001f + 1e-30f;
+  const float eps = eps_coef * qnorm[q] * p_max_norm[0] * 1.001f + 1e-30f;
   const bool have_k = need > 0 && c >= need;
   const float cut = have_k ? s[need - 1] - 2.f * eps : -INFINITY;
   for (int i = threadIdx.x; i < c; i += blockDim.x)
@@ -359,7 +403,7 @@ struct IpPlan {
   int nSt, stride;   // sampled passage tiles / tile stride
   int64_t nvals;     // values per query handed to k_tau_select
   int npow2;
-  size_t o_qb, o_qnorm, o_tau, o_counts, o_m, o_T, o_id, o_s, o_x, total;
+  size_t o_qb, o_qlo, o_qnorm, o_tau, o_counts, o_m, o_T, o_id, o_s, o_x, total;
 };
 
 static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
@@ -389,6 +433,7 @@ static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
   p.o_qb = take((size_t)p.nq_pad * d * 2);
+  p.o_qlo = take((size_t)p.nq_pad * d * 2);
   p.o_qnorm = take((size_t)p.nq_pad * 4);
   p.o_tau = take((size_t)p.nq_pad * 4);
   p.o_counts = take((size_t)p.nq_pad * 4);
@@ -427,15 +472,25 @@ static int launch_scan(const ScanArgs& a, bool big, hipStream_t st) {
 
 using namespace convdr;
 
-extern "C" int convdr_ip_prepare_block(const float* p_f32, int64_t n, int d, void* p_bf16, float* max_norm,
-                                       convdr_stream_t stream) {
+extern "C" int convdr_ip_column_mean(const float* p_f32, int64_t n, int d, float* scratch /* >= 64 * d floats */,
+                                     float* mean, convdr_stream_t stream) {
+  CONVDR_REQUIRE(n > 0 && d > 0, "convdr_ip_column_mean: empty block");
+  const int chunks = n >= 4096 ? 64 : 1;
+  hipLaunchKernelGGL(k_colsum_f32, dim3((d + 255) / 256, chunks), dim3(256), 0, (hipStream_t)stream, p_f32, n, d, scratch);
+  hipLaunchKernelGGL(k_colmean_finish, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, chunks, d, n, mean);
+  CONVDR_CHECK_LAUNCH("k_colsum_f32");
+  return 0;
+}
+
+extern "C" int convdr_ip_prepare_block(const float* p_f32, int64_t n, int d, const float* centre, void* p_bf16,
+                                       void* p_bf16_lo, float* max_norm, convdr_stream_t stream) {
   CONVDR_REQUIRE(n >= 0 && d > 0 && d % 64 == 0, "convdr_ip_prepare_block: need d %% 64 == 0 (got n=%lld d=%d)",
                  (long long)n, d);
   if (n == 0) return 0;
   const int64_t blocks = ceil_div64(n, 4);
   const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
-  hipLaunchKernelGGL(k_rows_to_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, p_f32, n, d, (bf16_t*)p_bf16,
-                     (float*)nullptr, max_norm);
+  hipLaunchKernelGGL(k_rows_to_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, p_f32, n, d, centre, (bf16_t*)p_bf16,
+                     (bf16_t*)p_bf16_lo, (float*)nullptr, max_norm);
   CONVDR_CHECK_LAUNCH("k_rows_to_bf16");
   return 0;
 }
@@ -453,7 +508,8 @@ extern "C" const uint32_t* convdr_ip_debug_band(const void* workspace, int nq, i
   return (const uint32_t*)((const char*)workspace + ip_plan(nq, n, d, k, cap).o_m);
 }
 
-extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, const void* p_bf16, int64_t n, int d,
+extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, const void* p_bf16, const void* p_bf16_lo,
+                                int64_t n, int d,
                                 int k, const float* p_max_norm, const float* tau_in, int cap, int rank_target,
                                 void* workspace, size_t workspace_bytes, float* D, int64_t* I, int32_t* status,
                                 float* tau_retry, convdr_stream_t stream) {
@@ -481,15 +537,17 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
   // queries -> bf16 (+ norms); padded rows stay zero
   CONVDR_CHECK_HIP(hipMemsetAsync(qb, 0, (size_t)p.nq_pad * d * 2, st));
   CONVDR_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)p.nq_pad * 4, st));
-  hipLaunchKernelGGL(k_rows_to_bf16, dim3((nq + 3) / 4), dim3(256), 0, st, q_f32, (int64_t)nq, d, qb, qnorm,
-                     (float*)nullptr);
+  bf16_t* qlo = p_bf16_lo ? (bf16_t*)(ws + p.o_qlo) : nullptr;
+  if (qlo) CONVDR_CHECK_HIP(hipMemsetAsync(qlo, 0, (size_t)p.nq_pad * d * 2, st));
+  hipLaunchKernelGGL(k_rows_to_bf16, dim3((nq + 3) / 4), dim3(256), 0, st, q_f32, (int64_t)nq, d, (const float*)nullptr, qb,
+                     qlo, qnorm, (float*)nullptr);
   CONVDR_CHECK_LAUNCH("k_rows_to_bf16(Q)");
 
   if (n == 0) {
     hipLaunchKernelGGL(k_fill_f32, dim3((p.nq_pad + 255) / 256), dim3(256), 0, st, tau, p.nq_pad, -INFINITY);
   } else {
     ScanArgs a;
-    a.P = (const bf16_t*)p_bf16; a.Qb = qb; a.n = n; a.nq = nq; a.nq_pad = p.nq_pad; a.d = d;
+    a.P = (const bf16_t*)p_bf16; a.Qb = qb; a.Plo = (const bf16_t*)p_bf16_lo; a.Qlo = qlo; a.n = n; a.nq = nq; a.nq_pad = p.nq_pad; a.d = d;
     a.nQt = p.nQt; a.tau = tau; a.counts = counts; a.cand_id = cand_id; a.cand_s = cand_s; a.cap = cap; a.T = T;
     if (tau_in) {
       CONVDR_CHECK_HIP(hipMemcpyAsync(tau, tau_in, (size_t)nq * 4, hipMemcpyDeviceToDevice, st));
@@ -532,7 +590,7 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
     attr_done2 = true;
   }
   hipLaunchKernelGGL(k_ip_cut, dim3(nq), dim3(256), (size_t)cap * 8, st, n, k, cap, counts, cand_id, cand_s, tau, qnorm,
-                     p_max_norm, band, status, tau_retry);
+                     p_max_norm, p_bf16_lo ? IP_EPS_COEF_X3 : IP_EPS_COEF, band, status, tau_retry);
   CONVDR_CHECK_LAUNCH("k_ip_cut");
   if (n > 0) {
     ProfScope prof("ip_rescore", st);

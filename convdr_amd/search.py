@@ -25,18 +25,26 @@ STATUS_OK, STATUS_OVERFLOW, STATUS_TOO_FEW, STATUS_UNCERTAIN = 0, 1, 2, 3
 
 
 class FlatIPIndex:
-    """Exact inner-product index resident in HBM.  ``add`` keeps the fp32 block and
-    builds its bf16 scan copy; ``search`` returns FAISS-shaped ``(D float32 [nq,k],
-    I int64 [nq,k])`` and is certified exact (see include/convdr_hip.h)."""
+    """Exact inner-product index resident in HBM.  ``add`` keeps the fp32 block and builds its bf16 scan copy;
+    ``search`` returns FAISS-shaped ``(D float32 [nq,k], I int64 [nq,k])`` and is certified exact
+    (see include/convdr_hip.h).
 
-    def __init__(self, d, device=None, cap=4096, rank_target=0):
+    precision: "auto" (default) scans in bf16 and re-runs the queries that cannot be certified with the
+    split-bf16 scan (three MFMA passes, ~10x tighter error band); "bf16" / "bf16x3" pin one rung.
+    center: subtract the column mean of the first added block from every passage before rounding to bf16
+    (ranking-neutral, shrinks the error band by |p| / |p - mean|; essential for real encoder outputs,
+    which share a large common component)."""
+
+    def __init__(self, d, device=None, cap=4096, rank_target=0, precision="auto", center=True):
         import torch
         if not torch.cuda.is_available():
             raise _lib.ConvdrError("FlatIPIndex needs a GPU (no CPU fallback)")
+        assert precision in ("auto", "bf16", "bf16x3")
         _lib.lib()
         self.d = int(d)
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.cap, self.rank_target = int(cap), int(rank_target)
+        self.precision, self.center = precision, bool(center)
         self.stats = {}
         self.reset()
 
@@ -49,8 +57,20 @@ class FlatIPIndex:
         import torch
         self._p32 = None
         self._pbf = None
+        self._plo = None
+        self._centre = None
         self._max_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._ws = None
+
+    def _prepare(self, t, want_lo):
+        import torch
+        L = _lib.lib()
+        pbf = torch.empty(t.shape, dtype=torch.bfloat16, device=self.device)
+        plo = torch.empty(t.shape, dtype=torch.bfloat16, device=self.device) if want_lo else None
+        _lib.check(L.convdr_ip_prepare_block(_lib.ptr(t), t.shape[0], self.d, _lib.ptr(self._centre), _lib.ptr(pbf),
+                                             _lib.ptr(plo), _lib.ptr(self._max_norm), _lib.stream_ptr()),
+                   "convdr_ip_prepare_block")
+        return pbf, plo
 
     def add(self, x):
         """x: numpy / torch [n, d] float32 (host or device).  Appends to the index."""
@@ -60,16 +80,31 @@ class FlatIPIndex:
             t = t.float()
         t = t.to(self.device, non_blocking=True).contiguous()
         assert t.dim() == 2 and t.shape[1] == self.d, "expected [n, %d], got %s" % (self.d, tuple(t.shape))
+        if t.shape[0] == 0:
+            return
         with torch.cuda.device(self.device):
-            pbf = torch.empty(t.shape, dtype=torch.bfloat16, device=self.device)
-            _lib.check(_lib.lib().convdr_ip_prepare_block(_lib.ptr(t), t.shape[0], self.d, _lib.ptr(pbf),
-                                                         _lib.ptr(self._max_norm), _lib.stream_ptr()),
-                       "convdr_ip_prepare_block")
+            if self._p32 is None and self.center:
+                self._centre = torch.empty(self.d, dtype=torch.float32, device=self.device)
+                scratch = torch.empty(64 * self.d, dtype=torch.float32, device=self.device)
+                _lib.check(_lib.lib().convdr_ip_column_mean(_lib.ptr(t), t.shape[0], self.d, _lib.ptr(scratch),
+                                                           _lib.ptr(self._centre), _lib.stream_ptr()),
+                           "convdr_ip_column_mean")
+            pbf, plo = self._prepare(t, self.precision == "bf16x3" or self._plo is not None)
         if self._p32 is None:
-            self._p32, self._pbf = t, pbf
-        else:  # FAISS semantics: add() appends
+            self._p32, self._pbf, self._plo = t, pbf, plo
+        else:  # FAISS semantics: add() appends (the centring vector stays the first block's mean)
             self._p32 = torch.cat([self._p32, t], 0)
             self._pbf = torch.cat([self._pbf, pbf], 0)
+            if plo is not None:
+                self._plo = torch.cat([self._plo, plo], 0)
+
+    def _ensure_lo(self):
+        """Remainder copy for the split-bf16 scan, built on first use."""
+        import torch
+        if self._plo is None and self._p32 is not None:
+            with torch.cuda.device(self.device):
+                self._max_norm_saved = self._max_norm.clone()
+                _, self._plo = self._prepare(self._p32, True)
 
     def update_rows(self, row0, emb):
         """Overwrite rows [row0, row0 + len(emb)) of the resident block with freshly encoded embeddings
@@ -78,10 +113,11 @@ class FlatIPIndex:
         m = int(emb.shape[0])
         assert emb.dtype == torch.float32 and emb.is_contiguous() and row0 + m <= self.ntotal
         dst32, dstbf = self._p32[row0:row0 + m], self._pbf[row0:row0 + m]
+        dstlo = None if self._plo is None else self._plo[row0:row0 + m]
         dst32.copy_(emb)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().convdr_ip_prepare_block(_lib.ptr(dst32), m, self.d, _lib.ptr(dstbf),
-                                                         _lib.ptr(self._max_norm), _lib.stream_ptr()),
+            _lib.check(_lib.lib().convdr_ip_prepare_block(_lib.ptr(dst32), m, self.d, _lib.ptr(self._centre), _lib.ptr(dstbf),
+                                                         _lib.ptr(dstlo), _lib.ptr(self._max_norm), _lib.stream_ptr()),
                        "convdr_ip_prepare_block")
 
     def _workspace(self, nbytes):
@@ -90,12 +126,16 @@ class FlatIPIndex:
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def search_device(self, q, k, tau_in=None, cap=None):
+    def search_device(self, q, k, tau_in=None, cap=None, x3=None):
         """One enqueue of the kernel pipeline; q is a device fp32 [nq, d] tensor.
         Returns device tensors (D, I, status, tau_retry); no sync."""
         import torch
         L = _lib.lib()
         cap = cap or self.cap
+        if x3 is None:
+            x3 = self.precision == "bf16x3"
+        if x3:
+            self._ensure_lo()
         nq, n = int(q.shape[0]), self.ntotal
         D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
@@ -105,8 +145,9 @@ class FlatIPIndex:
         ws = self._workspace(need)
         p32 = self._p32 if n else q  # never dereferenced when n == 0
         pbf = self._pbf if n else q
+        plo = self._plo if (x3 and n) else None
         with torch.cuda.device(self.device):
-            _lib.check(L.convdr_ip_search(_lib.ptr(q), nq, _lib.ptr(p32), _lib.ptr(pbf), n, self.d, k,
+            _lib.check(L.convdr_ip_search(_lib.ptr(q), nq, _lib.ptr(p32), _lib.ptr(pbf), _lib.ptr(plo), n, self.d, k,
                                           _lib.ptr(self._max_norm), _lib.ptr(tau_in), cap, self.rank_target,
                                           _lib.ptr(ws), ws.numel(), _lib.ptr(D), _lib.ptr(I), _lib.ptr(status),
                                           _lib.ptr(tau_retry), _lib.stream_ptr()), "convdr_ip_search")
@@ -122,10 +163,32 @@ class FlatIPIndex:
             out.append(self._ws[off:off + 4 * nq].view(_torch().int32))
         return tuple(out)
 
+    def _certify(self, qt, k, D, I, status, tau_retry, x3):
+        """Host loop around the kernel's certificate: re-run the queries that are not OK with the threshold the kernel
+        proposes (and a larger candidate capacity when needed).  Returns the indices still uncertified."""
+        import torch
+        st = status.cpu().numpy()
+        cap = self.cap
+        bad = np.nonzero(st != 0)[0]
+        rounds = 0
+        while len(bad) and rounds < 6:
+            rounds += 1
+            self.stats["rounds"] += 1
+            idx = torch.as_tensor(bad, device=self.device)
+            tau = tau_retry[idx].contiguous()
+            if (st[bad] == STATUS_OVERFLOW).any():
+                if cap >= 8192:
+                    break
+                cap *= 2
+            Db, Ib, sb, tb = self.search_device(qt[idx].contiguous(), k, tau_in=tau, cap=cap, x3=x3)
+            D[idx], I[idx], tau_retry[idx] = Db, Ib, tb
+            sb = sb.cpu().numpy()
+            st[bad] = sb
+            bad = bad[sb != 0]
+        return bad
+
     def search(self, q, k):
-        """FAISS ``index.search``: numpy in, numpy (D, I) out.  Queries whose first pass
-        is not certified are re-run with the threshold the kernel proposes (and a larger
-        candidate capacity when needed) until they are."""
+        """FAISS ``index.search``: numpy in, numpy (D, I) out; always the exact top-k or an exception."""
         import torch
         qt = torch.as_tensor(q)
         if qt.dtype != torch.float32:
@@ -133,27 +196,22 @@ class FlatIPIndex:
         qt = qt.to(self.device).contiguous()
         assert qt.dim() == 2 and qt.shape[1] == self.d
         k = int(k)
-        D, I, status, tau_retry = self.search_device(qt, k)
-        st = status.cpu().numpy()
-        self.stats = {"retried": int((st != 0).sum()), "rounds": 1}
-        cap = self.cap
-        bad = np.nonzero(st != 0)[0]
-        while len(bad):
-            self.stats["rounds"] += 1
-            if self.stats["rounds"] > 8:
-                raise _lib.ConvdrError("convdr_ip_search: could not certify %d queries" % len(bad))
+        x3 = self.precision == "bf16x3"
+        D, I, status, tau_retry = self.search_device(qt, k, x3=x3)
+        self.stats = {"retried": int((status != 0).sum().item()), "rounds": 1, "x3_queries": qt.shape[0] if x3 else 0}
+        bad = self._certify(qt, k, D, I, status, tau_retry, x3) if self.stats["retried"] else []
+        if len(bad) and self.precision == "auto":
+            # second rung: split-bf16 scan for the queries the bf16 error band cannot separate
             idx = torch.as_tensor(bad, device=self.device)
-            tau = tau_retry[idx].contiguous()
-            if (st[bad] == STATUS_OVERFLOW).any():
-                if cap >= 8192:
-                    raise _lib.ConvdrError("convdr_ip_search: candidate overflow at cap=8192 "
-                                           "(more than 8192 passages within the bf16 error band of the k-th score)")
-                cap *= 2
-            Db, Ib, sb, tb = self.search_device(qt[idx].contiguous(), k, tau_in=tau, cap=cap)
-            D[idx], I[idx], tau_retry[idx] = Db, Ib, tb
-            sb = sb.cpu().numpy()
-            st[bad] = sb
-            bad = bad[sb != 0]
+            qs = qt[idx].contiguous()
+            self.stats["x3_queries"] = len(bad)
+            Db, Ib, sb, tb = self.search_device(qs, k, x3=True)
+            bad2 = self._certify(qs, k, Db, Ib, sb, tb, True) if int((sb != 0).sum().item()) else []
+            D[idx], I[idx] = Db, Ib
+            bad = bad[np.asarray(bad2, dtype=np.int64)] if len(bad2) else []
+        if len(bad):
+            raise _lib.ConvdrError("convdr_ip_search: %d queries could not be certified (more than 8192 passages inside the "
+                                   "error band of the k-th score even with the split-bf16 scan)" % len(bad))
         return D.cpu().numpy(), I.cpu().numpy()
 
 

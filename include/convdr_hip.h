@@ -39,10 +39,17 @@ int convdr_prof_collect(const char* name, float* total_ms, int* launches);
  *   /root/reference/drivers/run_convdr_inference.py:353 (ctor), :180 (.add), :182 (.search), :202 (.reset)
  * ------------------------------------------------------------------------------------------ */
 
-/* .add(block): build the bf16 scan copy of an fp32 block [n, d] and fold max_i ||p_i||_2 into
- * *max_norm (device float, caller zero-initialises it on reset).  d % 64 == 0.               */
-int convdr_ip_prepare_block(const float* p_f32, int64_t n, int d, void* p_bf16, float* max_norm,
-                            convdr_stream_t stream);
+/* Column mean of an fp32 block [n, d] (the centring vector of the scan copies).  scratch: >= 64 * d floats. */
+int convdr_ip_column_mean(const float* p_f32, int64_t n, int d, float* scratch, float* mean, convdr_stream_t stream);
+
+/* .add(block): build the bf16 scan copy of an fp32 block [n, d]:  p_bf16 = bf16(p - centre)  (centre: device fp32 [d]
+ * or NULL).  Subtracting a fixed vector from every passage shifts all scores of a query by the same constant, so the
+ * ranking is unchanged while the rounding-error bound of the scan shrinks from |q| max|p| to |q| max|p - centre|
+ * (embeddings of one encoder share a large common component).  p_bf16_lo (nullable): bf16 of the rounding remainder
+ * (p - centre) - hi, needed by the split-bf16 scan.  max_i ||p_i - centre||_2 is folded into *max_norm (device float,
+ * caller zero-initialises it on reset).  d % 64 == 0. */
+int convdr_ip_prepare_block(const float* p_f32, int64_t n, int d, const float* centre, void* p_bf16, void* p_bf16_lo,
+                            float* max_norm, convdr_stream_t stream);
 
 /* Bytes of device workspace convdr_ip_search needs for these sizes. */
 size_t convdr_ip_workspace_bytes(int nq, int64_t n, int d, int k, int cap);
@@ -69,8 +76,11 @@ size_t convdr_ip_workspace_bytes(int nq, int64_t n, int d, int k, int cap);
  * Outputs (device): D [nq, k] fp32 scores (descending), I [nq, k] int64 row indices into the block
  * (-1 / -FLT_MAX padding when n < k, as FAISS does), status [nq] int32, tau_retry [nq] fp32.
  * tau_in: NULL, or device [nq] thresholds (retry path).  cap: candidate capacity per query
- * (power of two, 1024..8192).  rank_target: expected candidates per query (0 -> 16*k, at most cap/2). */
-int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, const void* p_bf16, int64_t n, int d,
+ * (power of two, 1024..8192).  rank_target: expected candidates per query (0 -> 16*k, at most cap/2).
+ * p_bf16_lo: NULL = plain bf16 scan (eps = 0.0079 |q| max|p'|); non-NULL = split-bf16 scan S~ = Ph Qh + Ph Ql + Pl Qh
+ * (three MFMA passes, eps = 8e-4 |q| max|p'|): the second rung for clustered embeddings whose top scores are closer
+ * together than the bf16 error band. */
+int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, const void* p_bf16, const void* p_bf16_lo, int64_t n, int d,
                      int k, const float* p_max_norm, const float* tau_in, int cap, int rank_target,
                      void* workspace, size_t workspace_bytes, float* D, int64_t* I, int32_t* status,
                      float* tau_retry, convdr_stream_t stream);

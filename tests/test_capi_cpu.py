@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_argument_validation_needs_no_gpu():
     L = _lib.lib()
     assert L.convdr_ip_workspace_bytes(1000, 1_000_000, 768, 100, 4096) > 0
-    rc = L.convdr_ip_prepare_block(None, 10, 70, None, None, None)     # d % 64 != 0 -> rejected before any launch
+    rc = L.convdr_ip_prepare_block(None, 10, 70, None, None, None, None, None)     # d % 64 != 0 -> rejected before any launch
     assert rc != 0 and b"d % 64" in L.convdr_last_error()
 
 

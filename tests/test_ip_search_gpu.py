@@ -148,3 +148,24 @@ def test_full_size_properties_1m_x_1k(torch_cuda):
         S = Q @ P[s:s + 125_000].T
         above += (S > kth + 5e-3).sum(1)
     assert (above <= k - 1).all(), above.max().item()
+
+
+@pytest.mark.parametrize("precision", ["auto", "bf16x3"])
+def test_clustered_embeddings_are_searched_exactly(torch_cuda, precision):
+    """Encoder outputs share a large common component (cosine ~0.9 between passages), which puts thousands of scores
+    inside the bf16 error band of the k-th one: centring + the split-bf16 rung must still return the exact top-k."""
+    rs = np.random.RandomState(0)
+    n, nq, d, k = 30000, 12, 768, 50
+    c = rs.randn(d).astype(np.float32)
+    P = (0.9 * c[None, :] + 0.12 * rs.randn(n, d)).astype(np.float32)
+    Q = (0.9 * c[None, :] + 0.12 * rs.randn(nq, d)).astype(np.float32)
+    Dr, Ir = OS.flat_ip_search(Q, P, k)
+    idx = _index(d, precision=precision)
+    idx.add(P)
+    D, I = idx.search(Q, k)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D, Dr)
+    raw = _index(d, precision="bf16", center=False)       # the un-centred bf16 rung cannot certify this data
+    raw.add(P)
+    with pytest.raises(Exception):
+        raw.search(Q, k)
