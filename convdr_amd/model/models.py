@@ -458,6 +458,54 @@ class RobertaDot_NLL_LN_Inference(RobertaDot_NLL_LN):
         return self.query_emb(input_ids, attention_mask)
 
 
+class NLL_MultiChunk(EmbeddingMixin):
+    """models.py:78-126: MaxP over 512-token chunks of the documents."""
+
+    def forward(self, query_ids, attention_mask_q, input_ids_a=None, attention_mask_a=None, input_ids_b=None,
+                attention_mask_b=None, is_query=True):
+        if input_ids_b is None and is_query:
+            return self.query_emb(query_ids, attention_mask_q)
+        elif input_ids_b is None:
+            return self.body_emb(query_ids, attention_mask_q)
+        q_embs = self.query_emb(query_ids, attention_mask_q)
+        a_embs = self.body_emb(input_ids_a, attention_mask_a)
+        b_embs = self.body_emb(input_ids_b, attention_mask_b)
+        batchS, full_length = input_ids_a.size()
+        chunk_factor = full_length // self.base_len
+
+        def maxp(embs, mask):
+            first = mask.reshape(batchS, chunk_factor, -1)[:, :, 0]
+            inverted_bias = ((1 - first) * (-9999)).float()
+            a12 = torch.matmul(q_embs.unsqueeze(1), embs.transpose(1, 2))
+            return (a12[:, 0, :] + inverted_bias).max(dim=-1, keepdim=False).values
+        logit_matrix = torch.cat([maxp(a_embs, attention_mask_a).unsqueeze(1), maxp(b_embs, attention_mask_b).unsqueeze(1)],
+                                 dim=1)
+        lsm = torch.nn.functional.log_softmax(logit_matrix, dim=1)
+        return ((-1.0 * lsm[:, 0]).mean(), )
+
+
+class RobertaDot_CLF_ANN_NLL_MultiChunk(NLL_MultiChunk, RobertaDot_NLL_LN):
+    """models.py:159-188: body_emb = [B, n_chunks, 768], one embedding per 512-token chunk.
+    Chunks whose first position is masked (pure padding) get a zero embedding here; the reference feeds them through
+    the encoder and then excludes them from the max with a -9999 bias (models.py:100-107), so their value is never
+    observable unless every chunk of a document is padding."""
+
+    def __init__(self, config, model_argobj=None):
+        RobertaDot_NLL_LN.__init__(self, config, model_argobj)
+        self.base_len = 512
+
+    def body_emb(self, input_ids, attention_mask):
+        batchS, full_length = input_ids.size()
+        chunk_factor = full_length // self.base_len
+        ids = input_ids.reshape(batchS * chunk_factor, full_length // chunk_factor)
+        mask = attention_mask.reshape(batchS * chunk_factor, full_length // chunk_factor)
+        live = mask[:, 0] != 0
+        out = torch.zeros((batchS * chunk_factor, 768), dtype=torch.float32, device=input_ids.device)
+        if bool(live.any()):
+            out[live] = RobertaDot_NLL_LN.query_emb(self, ids[live], mask[live])
+        return out.reshape(batchS, chunk_factor, 768)
+
+
 class HFBertEncoder(EncoderTower):
     """models.py:191-216: a BERT tower whose forward returns (sequence_output, pooled = CLS, None).
     Only the CLS row is materialised on this path (nothing in the reference reads the rest)."""
@@ -480,7 +528,11 @@ class HFBertEncoder(EncoderTower):
         return enc
 
     def forward(self, input_ids, attention_mask):
-        pooled = self.embed(input_ids, attention_mask)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from ..train import encoder_autograd
+            pooled = encoder_autograd(self, self, None, input_ids, attention_mask)
+        else:
+            pooled = self.embed(input_ids, attention_mask)
         return None, pooled, None
 
     def get_out_size(self):
@@ -534,6 +586,7 @@ class MSMarcoConfig:
 
 configs = [
     MSMarcoConfig(name="rdot_nll", model=RobertaDot_NLL_LN, use_mean=False),
+    MSMarcoConfig(name="rdot_nll_multi_chunk", model=RobertaDot_CLF_ANN_NLL_MultiChunk, use_mean=False),
     MSMarcoConfig(name="dpr", model=BiEncoder, tokenizer_class=BertTokenizer, config_class=BertConfig, use_mean=False),
 ]
 

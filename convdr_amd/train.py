@@ -199,6 +199,8 @@ class _EncoderFn(torch.autograd.Function):
 def encoder_autograd(model, tower, head, input_ids, attention_mask):
     """Differentiable embeddings of `tower` (+ optional (Linear, LayerNorm) head)."""
     cfg = tower.config
+    if head is None and tower is model:
+        pass  # BERT tower of the BiEncoder (no projection head)
     if model.training and (cfg.hidden_dropout_prob or cfg.attention_probs_dropout_prob):
         if not getattr(model, "_dropout_notice", False):
             model._dropout_notice = True
@@ -398,7 +400,7 @@ def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_st
     return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda, last_epoch)
 
 
-def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=None, doc_mask=None, ddp=None):
+def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=None, doc_mask=None, ddp=None, doc_embs=None):
     """One iteration of the reference loop body (run_convdr_train.py:101-193) with pre-tokenised ranking documents
     (`doc_ids` / `doc_mask` int64 [B * (num_negatives + 1), Ld], positive first within each group).
     Returns (loss, loss1, loss2) as device scalars."""
@@ -412,11 +414,16 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
     loss, loss2 = loss1, None
     if getattr(args, "ranking_task", False):
         bs = concat_ids.shape[0]
-        outs = []
-        with torch.no_grad():
-            for i in range(0, doc_ids.shape[0], 8):                       # doc_batch_size = 8 (:139)
-                outs.append(teacher_model(doc_ids[i:i + 8], doc_mask[i:i + 8], is_query=False).detach())
-        docs = torch.cat(outs, 0).view(bs, args.num_negatives + 1, -1)
+        if doc_embs is not None:
+            # the frozen teacher's document embeddings already exist in the corpus blocks whenever the
+            # ranking file carries doc ids; looking them up replaces 10 x 512-token encodes per sample per step
+            docs = doc_embs.view(bs, args.num_negatives + 1, -1)
+        else:
+            outs = []
+            with torch.no_grad():
+                for i in range(0, doc_ids.shape[0], 8):                       # doc_batch_size = 8 (:139)
+                    outs.append(teacher_model(doc_ids[i:i + 8], doc_mask[i:i + 8], is_query=False).detach())
+            docs = torch.cat(outs, 0).view(bs, args.num_negatives + 1, -1)
         loss2 = ranking_loss(embs, docs)
         loss = loss1 + loss2 if loss1 is not None else loss2
     if getattr(args, "gradient_accumulation_steps", 1) > 1:

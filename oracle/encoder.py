@@ -115,3 +115,22 @@ def pairwise_nll(q, a, b):
     """NLL.forward triple branch models.py:66-75 == BiEncoder.forward :254-262."""
     logits = torch.stack([(q * a).sum(-1), (q * b).sum(-1)], dim=1)
     return (-F.log_softmax(logits, dim=1)[:, 0]).mean()
+
+
+def rdot_multi_chunk_body_emb(sd, input_ids, attention_mask, *, num_layers, num_heads, base_len=512):
+    """RobertaDot_CLF_ANN_NLL_MultiChunk.body_emb (models.py:164-188): [B, n * 512] -> [B, n, 768]."""
+    B, full = input_ids.shape
+    n = full // base_len
+    e = rdot_nll_emb(sd, input_ids.reshape(B * n, base_len), attention_mask.reshape(B * n, base_len),
+                     num_layers=num_layers, num_heads=num_heads)
+    return e.reshape(B, n, -1)
+
+
+def multi_chunk_nll(q, a, b, mask_a, mask_b, base_len=512):
+    """NLL_MultiChunk.forward triple branch (models.py:92-126): MaxP over chunks, padding chunks biased by -9999."""
+    def maxp(embs, mask):
+        first = mask.reshape(mask.shape[0], -1, base_len)[:, :, 0]
+        s = torch.matmul(q.unsqueeze(1), embs.transpose(1, 2))[:, 0, :] + ((1 - first) * (-9999)).float()
+        return s.max(dim=-1).values
+    logits = torch.stack([maxp(a, mask_a), maxp(b, mask_b)], dim=1)
+    return (-F.log_softmax(logits, dim=1)[:, 0]).mean()

@@ -181,6 +181,30 @@ def gen_encoder():
     for n, v in dict(ids_q=ids_q, m_q=m_q, ids_a=ids_a, m_a=m_a, ids_b=ids_b, m_b=m_b).items():
         out["triple/" + n] = v
     out["triple/loss"] = np.array(loss.item(), np.float64)
+    # rdot_nll_multi_chunk (models.py:159-188, 78-126): same weights, documents of 2 x 512 tokens, one pure-padding chunk
+    mc = M.MSMarcoConfigDict["rdot_nll_multi_chunk"].model_class(cfg)
+    mc.load_state_dict(model.state_dict())
+    mc.eval()
+    def chunked(lens_per_chunk):
+        ids = np.zeros((len(lens_per_chunk), 1024), np.int64)
+        mask = np.zeros((len(lens_per_chunk), 1024), np.int64)
+        for b, lens in enumerate(lens_per_chunk):
+            for c, n in enumerate(lens):
+                if n:
+                    ids[b, 512 * c:512 * c + n] = rng.randint(3, 200, size=n)
+                    ids[b, 512 * c] = 0
+                    mask[b, 512 * c:512 * c + n] = 1
+        return ids, mask
+    ids_a, m_a = chunked([[512, 100], [30, 0]])
+    ids_b, m_b = chunked([[200, 512], [512, 7]])
+    ids_q2, m_q2 = synth_ids(rng, 2, 12, [12, 5])
+    with torch.no_grad():
+        emb_a = mc.body_emb(torch.from_numpy(ids_a), torch.from_numpy(m_a))
+        loss_mc = mc(*(torch.from_numpy(x) for x in (ids_q2, m_q2, ids_a, m_a, ids_b, m_b)))[0]
+    for n, v in dict(ids_a=ids_a, m_a=m_a, ids_b=ids_b, m_b=m_b, ids_q=ids_q2, m_q=m_q2).items():
+        out["mc/" + n] = v
+    out["mc/emb_a"] = emb_a.numpy()
+    out["mc/loss"] = np.array(loss_mc.item(), np.float64)
     np.savez_compressed(os.path.join(HERE, "encoder_rdot_nll.npz"), **out)
 
     # ---- dpr ----------------------------------------------------------------

@@ -193,3 +193,21 @@ def test_fused_gemm_layernorm_kernel_matches_oracle():
     with torch.no_grad():
         c = model.body_emb(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda())     # unfused path
     assert cosine(a.cpu().numpy(), c.cpu().numpy()).min() > 1 - 1e-4
+
+
+def test_multi_chunk_matches_reference_fixture(golden_dir):
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    z = np.load(os.path.join(golden_dir, "encoder_rdot_nll.npz"))
+    cfg = json.loads(str(z["config"]))
+    model = MSMarcoConfigDict["rdot_nll_multi_chunk"].model_class(RobertaConfig(**cfg))
+    model.load_state_dict(_sd(z), strict=False)
+    model = model.cuda().eval()
+    t = lambda k: torch.from_numpy(z["mc/" + k]).cuda()
+    with torch.no_grad():
+        a = model.body_emb(t("ids_a"), t("m_a"))
+        loss = model(t("ids_q"), t("m_q"), t("ids_a"), t("m_a"), t("ids_b"), t("m_b"))[0].item()
+    assert a.shape == (2, 2, 768)
+    live = z["mc/m_a"].reshape(2, 2, 512)[:, :, 0].astype(bool)
+    _check(a[torch.from_numpy(live).cuda()], z["mc/emb_a"][live], "multi chunk")
+    assert float(a[1, 1].abs().max()) == 0.0                                     # pure-padding chunk
+    assert abs(loss - float(z["mc/loss"])) < 2e-2 * max(1.0, abs(float(z["mc/loss"])))

@@ -109,3 +109,16 @@ def test_canonical_score_is_fp64_accurate():
     S = OS.canonical_scores(Q, P)
     ref = Q.astype(np.float64) @ P.astype(np.float64).T
     np.testing.assert_allclose(S, ref, rtol=1e-13, atol=1e-11)
+
+
+def test_multi_chunk_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "encoder_rdot_nll.npz"))
+    sd = _sd(z)
+    t = lambda k: torch.from_numpy(z["mc/" + k])
+    a = OE.rdot_multi_chunk_body_emb(sd, t("ids_a"), t("m_a"), num_layers=2, num_heads=2)
+    live = z["mc/m_a"].reshape(2, 2, 512)[:, :, 0].astype(bool)
+    np.testing.assert_allclose(a.numpy()[live], z["mc/emb_a"][live], atol=2e-5, rtol=0)   # padding chunks: don't care
+    b = OE.rdot_multi_chunk_body_emb(sd, t("ids_b"), t("m_b"), num_layers=2, num_heads=2)
+    q = OE.rdot_nll_emb(sd, t("ids_q"), t("m_q"), num_layers=2, num_heads=2)
+    loss = OE.multi_chunk_nll(q, a, b, t("m_a"), t("m_b"))
+    assert abs(loss.item() - float(z["mc/loss"])) < 1e-4 * max(1.0, abs(float(z["mc/loss"])))

@@ -250,3 +250,39 @@ def test_flat_arena_training_matches_per_parameter_path():
             assert torch.allclose(v, results[1][1][k], rtol=1e-5, atol=1e-7), k
         else:
             assert torch.equal(v, results[1][1][k]), k
+
+
+def test_dpr_tower_backward_matches_autograd():
+    """BiEncoder (two BERT towers, raw CLS, no head): gradients of the question tower."""
+    from convdr_amd.model.models import MSMarcoConfigDict, BertConfig
+    torch.manual_seed(11)
+    cfg = BertConfig(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                     max_position_embeddings=64, type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = MSMarcoConfigDict["dpr"].model_class(type("A", (), {"bert_config": cfg})())
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.05)
+            elif "LayerNorm.weight" in n:
+                p.add_(torch.randn_like(p) * 0.1)
+            elif p.dim() == 2:
+                p.normal_(0, 0.05)
+    rs = np.random.RandomState(11)
+    ids, mask = _batch(rs, 4, 40, [40, 9, 23, 2])
+    G = torch.from_numpy(rs.randn(4, 128).astype(np.float32))
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    emb = OE.dpr_emb(sd, ids, mask, tower="question_model", num_layers=2, num_heads=2)
+    (emb * G).sum().backward()
+    ref = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    model = model.cuda().train()
+    out = model(ids.cuda(), mask.cuda())
+    assert out.requires_grad and cosine(out.detach().cpu().numpy(), emb.detach().numpy()).min() > 1 - 1e-3
+    (out * G.cuda()).sum().backward()
+    seen = 0
+    for n, p in model.named_parameters():
+        if n in ref and not n.endswith("key.bias") and "pooler" not in n:
+            _compare(n, p.grad, ref[n])
+            seen += 1
+        elif n.startswith("ctx_model"):
+            assert p.grad is None
+    assert seen > 20
