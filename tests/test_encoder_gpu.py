@@ -183,11 +183,13 @@ def test_fused_gemm_layernorm_kernel_matches_oracle():
     L = _lib.lib()
     try:
         _lib.check(L.convdr_set_option(b"fused_ln_min_rows", 1), "convdr_set_option")
+        _lib.check(L.convdr_set_option(b"fused_ln_max_k", 1 << 20), "convdr_set_option")     # FFN2 (K = 3072) too
         with torch.no_grad():
             a = model.body_emb(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda())
             b = model.body_emb(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda())
     finally:
         L.convdr_set_option(b"fused_ln_min_rows", 128 * 192)
+        L.convdr_set_option(b"fused_ln_max_k", 1 << 30)
     assert torch.equal(a, b)
     _check(a, ref, "fused gemm+ln")
     with torch.no_grad():
