@@ -56,7 +56,18 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 pair, round to nearest even: one v_cvt_pk_bf16_f32 on gfx950 (the compiler selects it
+// from the vector conversion; the bit-twiddling form above costs ~6 VALU per element)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  return *(const uint32_t*)&r;
+}
+
+// same result from integer ops only; used where the hardware-convert form upsets register allocation (gemm_ln.hpp)
+__device__ __forceinline__ uint32_t pack_bf16x2_sw(float lo, float hi) {
   return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 

@@ -221,7 +221,7 @@ struct GemmArgs {
 // (|abs error| <= 1.5e-7, far below the bf16 output rounding) instead of libm's erff: 1 rcp + 1 exp + 7 FMA.
 __device__ __forceinline__ float gelu_erf(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));   // v_rcp_f32 (1 ulp), not the IEEE divide sequence
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
@@ -233,7 +233,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_grad(float x) {
   const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));   // v_rcp_f32 (1 ulp), not the IEEE divide sequence
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);

@@ -175,8 +175,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
         const float4 gg = *(const float4*)(sGam + f), bb = *(const float4*)(sBet + f);
         const f32x16& v = acc.c[mt][nt];
         uint2 o;
-        o.x = pack_bf16x2((v[4 * g + 0] - mean[nt]) * rstd * gg.x + bb.x, (v[4 * g + 1] - mean[nt]) * rstd * gg.y + bb.y);
-        o.y = pack_bf16x2((v[4 * g + 2] - mean[nt]) * rstd * gg.z + bb.z, (v[4 * g + 3] - mean[nt]) * rstd * gg.w + bb.w);
+        o.x = pack_bf16x2_sw((v[4 * g + 0] - mean[nt]) * rstd * gg.x + bb.x, (v[4 * g + 1] - mean[nt]) * rstd * gg.y + bb.y);
+        o.y = pack_bf16x2_sw((v[4 * g + 2] - mean[nt]) * rstd * gg.z + bb.z, (v[4 * g + 3] - mean[nt]) * rstd * gg.w + bb.w);
         *(uint2*)(dst + f) = o;
       }
   }
