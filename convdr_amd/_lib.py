@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libconvdr_hip.so")
+# CONVDR_HIP_LIB: load another build of the same library (kernel A/B experiments); default is the in-tree build
+LIB_PATH = os.environ.get("CONVDR_HIP_LIB") or os.path.join(_HERE, "libconvdr_hip.so")
 
 _lib = None
 

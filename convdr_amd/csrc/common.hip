@@ -23,6 +23,18 @@ int hip_fail(hipError_t e, const char* what) {
   return -2;
 }
 
+int device_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+      cus = 256;
+    n = cus & ~7;
+  }
+  return n;
+}
+
 // ---- optional per-kernel timing (hipEvents on the launch stream), used by bench.py ------------
 struct ProfSpan { const char* name; hipEvent_t a, b; };
 static std::vector<ProfSpan> g_spans;

@@ -15,6 +15,9 @@ typedef uint16_t bf16_t;  // storage type for bf16 in global memory
 // ---- error reporting across the C ABI ------------------------------------
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
+// compute units of the current device, rounded down to a multiple of the 8 XCDs (256 on MI355X); persistent kernels
+// launch this many workgroups (x resident workgroups per CU)
+int device_cu_count();
 
 #define CONVDR_CHECK_HIP(expr)                                   \
   do {                                                           \

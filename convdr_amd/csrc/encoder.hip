@@ -221,6 +221,10 @@ extern "C" int convdr_set_option(const char* name, int64_t value) {
     g_fused_ln_max_k = value;
     return 0;
   }
+  if (strcmp(name, "gemm_trace") == 0) {   // experiment: device buffer for k_gemm phase stamps (0 = off)
+    g_gemm_trace = (void*)(uintptr_t)value;
+    return 0;
+  }
   set_error("convdr_set_option: unknown option %s", name);
   return -1;
 }

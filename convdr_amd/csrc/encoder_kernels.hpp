@@ -215,19 +215,22 @@ struct GemmArgs {
   int64_t ldt;
   int tilesN, tilesT;
   int dbg_same_tile;  // experiment: every workgroup reads tile (0, 0) (all-L2-hit upper bound); results are garbage
+  int dbg_skip_epi;   // experiment: 1 no epilogue, 3 no global stores of bf16 tiles (results are garbage)
+  unsigned long long* trace;   // experiment: [workgroup][64 tiles][16 phases] s_memtime stamps of wave 0 (or null)
 };
 
-// exact-erf GELU (HF "gelu": x * 0.5 * (1 + erf(x / sqrt(2)))).  erf by Abramowitz & Stegun 7.1.26
-// (|abs error| <= 1.5e-7, far below the bf16 output rounding) instead of libm's erff: 1 rcp + 1 exp + 7 FMA.
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));   // v_rcp_f32 (1 ulp), not the IEEE divide sequence
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = 1.f - p * t * __expf(-z * z);   // erf(|x| / sqrt 2)
-  return 0.5f * x + 0.5f * fabsf(x) * e;          // 0.5 x (1 + sign(x) e)
+
+// HF "gelu" is x * 0.5 * (1 + erf(x / sqrt 2)).  The forward epilogue evaluates it through a logistic with a fitted odd
+// polynomial argument:  Phi(x) ~ 1 / (1 + exp(-x (a + b u + c u^2))),
+// u = min(x^2, 64).  Max |error| of x Phi(x) against the exact erf form is 2.7e-5 over all x (fp32 evaluation; fit and
+// check in DESIGN.md section 5) -- two orders below the bf16 rounding of the stored activation -- for 7 VALU + 2
+// transcendentals per element instead of 15 + 2.  The constants carry the -log2(e) of exp -> v_exp_f32.
+__device__ __forceinline__ float gelu_sig(float x) {
+  const float u = fminf(x * x, 64.f);
+  float t = fmaf(u, 0.001023812276f, -0.106834618f);
+  t = fmaf(t, u, -2.30105646f);
+  const float e = __builtin_amdgcn_exp2f(t * x);          // exp(-x (a + b u + c u^2)); +inf for very negative x
+  return x * __builtin_amdgcn_rcpf(1.f + e);              // rcp(+inf) = 0
 }
 
 // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
@@ -244,133 +247,302 @@ __device__ __forceinline__ float gelu_grad(float x) {
   return cdf + x * 0.3989422804014327f * ex;              // exp(-x^2 / 2) == ex
 }
 
+// ---- bf16 output tiles leave through LDS ---------------------------------------------------------------------
+// In the accumulator layout a lane owns 4 consecutive R indices of ONE L row, so a direct store instruction touches
+// 32 different output rows with 16 bytes each: 8192 partial-line write transactions per 256 x 256 tile.  Instead the
+// converted tile is parked in an idle operand stage as C[L row][R index] bf16 and written out cooperatively, 16
+// bytes per lane, every wave instruction covering whole 128-byte lines (QKV: 13.9 -> 11.5 ms per 12 layers).
+// One stage holds TL / PASSES rows, so the tile leaves in PASSES passes of NT / PASSES MFMA column blocks.
+// LDS rows are TR * 2 bytes; the 16-byte chunk index is XOR-swizzled with the row so that both the 8-byte column
+// writes and the row-major 16-byte reads spread over all banks.
+template <class T>
+struct CTile {
+  static constexpr int CH = T::TR / 8;                                   // 16-byte chunks per row
+  static constexpr int PASSES = (T::TL * T::TR * 2) / T::STAGE_BYTES;    // Tile256: 2, Tile128: 1
+  static constexpr int NTP = T::NT / PASSES;                             // MFMA column blocks per pass
+  static constexpr int ROWS = T::TL / PASSES;
+  static constexpr int STORES_PER_WAVE = ROWS * CH / T::THREADS;         // global store instructions per pass
+  static_assert(PASSES >= 1 && PASSES * NTP == T::NT && ROWS * T::TR * 2 <= T::STAGE_BYTES, "C tile must fit a stage");
+  __device__ static __forceinline__ int addr(int row, int chunk) {
+    return row * (T::TR * 2) + ((chunk ^ ((row ^ (row / CH)) & (CH - 1))) << 4);
+  }
+  // registers 4g..4g+3 of MFMA tile (mt, nt) of this lane, packed to bf16
+  __device__ static __forceinline__ void put(char* sC, const WavePos<T>& w, int mt, int nt, int g, uint2 o) {
+    const int fl = w.r_base(mt, g);
+    const int row = (w.wl * NTP + (nt % NTP)) * 32 + w.li;
+    *(uint2*)(sC + addr(row, fl >> 3) + (fl & 4) * 2) = o;
+  }
+  // dst -> element (L row 0, R index 0) of the tile; row_limit / col_limit = valid L rows / R indices (col_limit % 4 == 0).
+  // Thread t owns 16-byte chunk t % CH of rows t / CH + 16 i: all LDS reads are issued before the first store, the
+  // per-iteration row offsets are compile-time, and a tile that lies fully inside the matrix takes no bound checks
+  // (the store tail was issue-bound: 325 cycles per store with the generic index arithmetic, measured by s_memtime).
+  __device__ static __forceinline__ void store(const char* sC, int pass, bf16_t* dst, int64_t ld, int64_t row_limit,
+                                               int64_t col_limit) {
+    constexpr int RPI = T::THREADS / CH;   // rows covered per iteration
+    constexpr int BATCH = 4;               // LDS reads in flight before their stores (16 VGPRs; the kernel is at the cap)
+    static_assert(RPI * CH == T::THREADS && (32 * NTP) % RPI == 0 && ROWS % RPI == 0 && STORES_PER_WAVE % BATCH == 0,
+                  "store geometry");
+    const int r0 = threadIdx.x / CH, c = threadIdx.x - r0 * CH;
+    const int64_t nv = col_limit - c * 8;
+    bf16_t* p = dst + c * 8 + (int64_t)r0 * ld;
+    const char* q = sC + addr(r0, c);
+    const bool inside = row_limit >= T::TL && col_limit >= T::TR;   // workgroup-uniform
+#pragma unroll
+    for (int i0 = 0; i0 < STORES_PER_WAVE; i0 += BATCH) {
+      uint4 v[BATCH];
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        // rows i * RPI + r0 with RPI a multiple of CH... the swizzle term of addr() depends on the row only through
+        // (row ^ row / CH) & (CH - 1): recompute per row (cheap) rather than assume
+        v[j] = *(const uint4*)(sC + addr((i0 + j) * RPI + r0, c));
+      }
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        constexpr int blk = 32 * NTP;
+        const int i = i0 + j;
+        const int rowc = ((i * RPI) / blk * T::NT + pass * NTP) * 32 + (i * RPI) % blk;   // compile-time part of the row
+        bf16_t* pr = p + (int64_t)rowc * ld;
+        if (inside) {
+          *(uint4*)pr = v[j];
+        } else if (rowc + r0 < row_limit && nv > 0) {
+          if (nv >= 8) *(uint4*)pr = v[j];
+          else *(uint2*)pr = make_uint2(v[j].x, v[j].y);
+        }
+      }
+    }
+    (void)q;
+  }
+};
+
+// One workgroup walks a strided sequence of output tiles (persistent when the grid is smaller than the tile count:
+// gemm_launch.hpp launches one workgroup per CU-slot).  While the epilogue of tile i runs, the first K chunk of tile
+// i + 1 is already streaming into the idle operand stage, so neither the workgroup dispatch gap nor the first
+// HBM/L2 round trip of a tile (~2-3 us of a ~20-30 us tile) is exposed.
 template <int EPI, class T>
 static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // consecutive logical tiles sweep the feature tiles of one token tile: the activation tile stays in L2
-  const uint32_t logical = xcd_remap(blockIdx.x, gridDim.x);
-  int tt = logical / a.tilesN, tn = logical - tt * a.tilesN;
-  if (a.dbg_same_tile) { tt = 0; tn = 0; }
+  using CT = CTile<T>;
   const WavePos<T> w;
-  GemmAcc<T> acc;
-  acc.zero();
-  bool tokens_on_regs = false;
-  if constexpr (EPI == EPI_QKV) tokens_on_regs = tn * T::TR >= 2 * a.H;   // H % TR == 0 (checked by the launcher)
   const int64_t ldw = a.ldw ? a.ldw : a.K, ldx = a.ldx ? a.ldx : a.K;
   int kbeg = 0, klen = a.K;
   if constexpr (EPI == EPI_SLAB_F32) {
     if (a.k_split_len) { kbeg = blockIdx.y * a.k_split_len; klen = a.k_split_len; }
   }
+  // tile walk: XCD x (= blockIdx.x % 8) owns a contiguous chunk of the logical tile order -- consecutive logical
+  // tiles sweep the feature tiles of one token tile, so the activation tile stays in that XCD's L2 -- and its
+  // workgroups take the chunk's tiles round-robin (panel orders measured no better on any encoder shape)
+  const uint32_t ntiles = (uint32_t)a.tilesN * a.tilesT;
+  const uint32_t xcd = blockIdx.x & 7u, q8 = ntiles >> 3, r8 = ntiles & 7u;
+  const uint32_t chunk_base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const uint32_t chunk_len = q8 + (xcd < r8 ? 1u : 0u);
+  const uint32_t stride = (gridDim.x + 7u) >> 3;
+  uint32_t idx = blockIdx.x >> 3;
+  if (idx >= chunk_len) return;
 
-  if (tokens_on_regs) {  // V third of the fused QKV projection -> Vt[feature][token]: roles swapped
-    const int64_t t0 = (int64_t)tt * T::TL;      // the launcher lays tiles out as [tilesT][tilesN] with TR == TL
-    const int n0 = tn * T::TR;
-    gemm_nt_mainloop<T>(a.X, ldx, a.rows, a.W, ldw, a.N, a.K, t0, n0, smem, acc, w);
+  struct Coord { int64_t t0; int n0; bool swap; };   // swap: V third of the fused QKV projection (tokens on registers)
+  auto decode = [&](uint32_t i) {
+    const uint32_t logical = chunk_base + i;
+    int tt = logical / a.tilesN, tn = logical - tt * a.tilesN;
+    if (a.dbg_same_tile) { tt = 0; tn = 0; }
+    Coord c;
+    c.t0 = (int64_t)tt * T::TL;      // the launcher lays tiles out as [tilesT][tilesN] with TR == TL
+    c.n0 = tn * T::TR;
+    c.swap = false;
+    if constexpr (EPI == EPI_QKV) c.swap = c.n0 >= 2 * a.H;   // H % TR == 0 (checked by the launcher)
+    return c;
+  };
+  auto tile_src = [&](const Coord& c) {
+    return c.swap ? TileSrc<T>(a.X, ldx, a.rows, a.W, ldw, a.N, c.t0, c.n0, w)
+                  : TileSrc<T>(a.W + kbeg, ldw, a.N, a.X + kbeg, ldx, a.rows, c.n0, c.t0, w);
+  };
+
+  float* sbias = (float*)(smem + T::SMEM_BYTES);
+  int trace_tile = 0;
+#define CONVDR_TRACE(ph)                                                                                       \
+  if (a.trace && threadIdx.x == 0 && trace_tile < 64)                                                          \
+    a.trace[((size_t)blockIdx.x * 64 + trace_tile) * 16 + (ph)] = __builtin_amdgcn_s_memtime();
+  Coord c = decode(idx);
+  int buf = 0;
+  bool landed = false;   // chunk 0 of the current tile has been waited for
+  TileSrc<T> src = tile_src(c);
+  gemm_issue_stage<T>(src, 0, smem + buf * T::STAGE_BYTES, w);
+  for (;;) {
+    GemmAcc<T> acc;
+    acc.zero();
+    // bias values are fetched BEFORE the main loop and parked in LDS after it: an ordinary global load issued while
+    // the next tile's LDS-DMA is in flight would make hipcc drain the whole vector-memory queue at its first use
+    float bias_pre[T::NT];
+    if (c.swap) {
 #pragma unroll
-    for (int nt = 0; nt < T::NT; ++nt) {
-      const int f = n0 + w.l_index(nt);  // feature on the lane
-      if (f >= a.N) continue;
-      const float bv = a.bias[f];
-      bf16_t* dst = a.Vt + (int64_t)(f - 2 * a.H) * a.ldt;
+      for (int nt = 0; nt < T::NT; ++nt) {
+        const int f = c.n0 + w.l_index(nt);  // V third: feature on the lane
+        bias_pre[nt] = a.bias[f < a.N ? f : a.N - 1];
+      }
+    } else {
+      const int f = c.n0 + (int)threadIdx.x;
+      bias_pre[0] = (a.bias && threadIdx.x < T::TR && f < a.N) ? a.bias[f] : 0.f;
+    }
+    CONVDR_TRACE(0)
+    int idle;   // the stage the last K step did not read
+    idle = gemm_nt_mainloop<T>(src, c.swap ? a.K : klen, smem, acc, w, buf, true, landed);
+    landed = false;
+    CONVDR_TRACE(1)
+    const uint32_t next = idx + stride;
+    const bool has_next = next < chunk_len;
+    Coord cn = c;
+    if (has_next) {
+      cn = decode(next);
+      src = tile_src(cn);
+      gemm_issue_stage<T>(src, 0, smem + idle * T::STAGE_BYTES, w);
+    }
+    char* sC = smem + (idle ^ 1) * T::STAGE_BYTES;   // epilogue scratch: the stage of the last K step
+    const int64_t t0 = c.t0;
+    const int n0 = c.n0;
+
+    if (a.dbg_skip_epi == 1) {
+      float s = 0.f;
 #pragma unroll
       for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int64_t t = t0 + w.r_base(mt, g);  // 4 consecutive tokens (rows % 4 == 0)
-          if (t < a.rows) {
-            const f32x16& v = acc.c[mt][nt];
-            uint2 o;
-            o.x = pack_bf16x2(v[4 * g + 0] + bv, v[4 * g + 1] + bv);
-            o.y = pack_bf16x2(v[4 * g + 2] + bv, v[4 * g + 3] + bv);
-            *(uint2*)(dst + t) = o;
-          }
+        for (int nt = 0; nt < T::NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s += acc.c[mt][nt][r];
+      if (s == 12345.678f) a.Cb[0] = f32_to_bf16(s);
+    } else if (c.swap) {
+      // ---- V third -> Vt[feature][token]: features on lanes, tokens on registers ----
+      lds_barrier();   // every wave is done with the last K step's stage
+#pragma unroll
+      for (int pass = 0; pass < CT::PASSES; ++pass) {
+        if (pass) lds_barrier();   // the previous pass has been read out
+#pragma unroll
+        for (int ntl = 0; ntl < CT::NTP; ++ntl) {
+          const int nt = pass * CT::NTP + ntl;
+          const float bv = bias_pre[nt];
+#pragma unroll
+          for (int mt = 0; mt < T::MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x16& v = acc.c[mt][nt];
+              uint2 o;
+              o.x = pack_bf16x2(v[4 * g + 0] + bv, v[4 * g + 1] + bv);
+              o.y = pack_bf16x2(v[4 * g + 2] + bv, v[4 * g + 3] + bv);
+              CT::put(sC, w, mt, nt, g, o);
+            }
         }
-    }
-    return;
-  }
-
-  const int64_t t0 = (int64_t)tt * T::TL;
-  const int n0 = tn * T::TR;
-  gemm_nt_mainloop<T>(a.W, ldw, a.N, a.X, ldx, a.rows, klen, n0, t0, smem, acc, w, kbeg);
-
-  // ---- epilogue.  The operand buffers are dead: park the tile's bias slice in LDS (no vmcnt round trip per
-  // register quad), issue all residual loads of a 32-token column block up front, then convert and store. ----
-  __syncthreads();
-  float* sbias = (float*)smem;
-  for (int i = threadIdx.x; i < T::TR; i += T::THREADS) sbias[i] = (a.bias && n0 + i < a.N) ? a.bias[n0 + i] : 0.f;
-  __syncthreads();
-  const bool full_n = n0 + T::TR <= a.N;  // workgroup-uniform: no per-quad feature bound checks on the fast path
-#pragma unroll
-  for (int nt = 0; nt < T::NT; ++nt) {
-    const int64_t t = t0 + w.l_index(nt);  // token on the lane
-    const bool t_ok = t < a.rows;
-    const int64_t tc = t_ok ? t : a.rows - 1;
-    uint2 res[T::MT][4];
-    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_DGELU_BF16) {
-      if (EPI == EPI_DGELU_BF16 || a.Rf == nullptr) {
-#pragma unroll
-        for (int mt = 0; mt < T::MT; ++mt)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            int f = n0 + w.r_base(mt, g);
-            f = (full_n || f < a.N) ? f : a.N - 4;
-            res[mt][g] = *(const uint2*)(a.R + tc * a.N + f);
-          }
+        lds_barrier();
+        if (pass == CT::PASSES - 1 && has_next) {   // the prefetch has had the whole epilogue to land: retire it
+          lds_dma_wait_all();                        // BEFORE the last stores enter the (in-order) queue
+          landed = true;
+        }
+        CT::store(sC, pass, a.Vt + (int64_t)(n0 - 2 * a.H) * a.ldt + t0, a.ldt, a.N - n0, a.rows - t0);
       }
-    }
+    } else {
+      // ---- epilogue: the tile's bias slice is parked in LDS behind the stages (no vmcnt round trip per register
+      // quad), all residual loads of a 32-token column block are issued up front ----
+      // (the main loop's barriers separate this write from the previous tile's reads of sbias)
+      if (threadIdx.x < T::TR) sbias[threadIdx.x] = bias_pre[0];
+      lds_barrier();     // ... and every wave is done with the last K step's stage
+      CONVDR_TRACE(2)
+      const bool full_n = n0 + T::TR <= a.N;  // workgroup-uniform: no per-quad feature bound checks on the fast path
+      constexpr bool BF16_OUT = EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV || EPI == EPI_GELU_SAVE ||
+                                EPI == EPI_DGELU_BF16;
+      constexpr int NOUT = EPI == EPI_GELU_SAVE ? 2 : 1;   // second output: the pre-activation
 #pragma unroll
-    for (int mt = 0; mt < T::MT; ++mt)
+      for (int out = 0; out < NOUT; ++out)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int fl = w.r_base(mt, g);      // 4 consecutive features (N % 4 == 0)
-        const int f = n0 + fl;
-        const f32x16& v = acc.c[mt][nt];
-        const float4 bv = *(const float4*)(sbias + fl);
-        float y0 = v[4 * g + 0] + bv.x, y1 = v[4 * g + 1] + bv.y, y2 = v[4 * g + 2] + bv.z, y3 = v[4 * g + 3] + bv.w;
-        float p0 = y0, p1 = y1, p2 = y2, p3 = y3;  // pre-activation
-        if constexpr (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_SAVE) {
-          y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3);
-        }
-        if constexpr (EPI == EPI_DGELU_BF16) {
-          const uint2 r = res[mt][g];
-          y0 *= gelu_grad(__uint_as_float(r.x << 16)); y1 *= gelu_grad(__uint_as_float(r.x & 0xffff0000u));
-          y2 *= gelu_grad(__uint_as_float(r.y << 16)); y3 *= gelu_grad(__uint_as_float(r.y & 0xffff0000u));
-        }
-        if constexpr (EPI == EPI_RESID_F32) {
-          if (a.Rf) {
-            const int fc = (full_n || f < a.N) ? f : a.N - 4;
-            const float4 r = *(const float4*)(a.Rf + tc * a.N + fc);
-            y0 += r.x; y1 += r.y; y2 += r.z; y3 += r.w;
-          } else {
-            const uint2 r = res[mt][g];
-            y0 += __uint_as_float(r.x << 16); y1 += __uint_as_float(r.x & 0xffff0000u);
-            y2 += __uint_as_float(r.y << 16); y3 += __uint_as_float(r.y & 0xffff0000u);
-          }
-        }
-        if (t_ok && (full_n || f < a.N)) {
-          if constexpr (EPI == EPI_SLAB_F32) {
-            *(float4*)(a.Cf + ((int64_t)blockIdx.y * a.rows + t) * a.N + f) = make_float4(y0, y1, y2, y3);
-          } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_F32) {
-            *(float4*)(a.Cf + t * a.N + f) = make_float4(y0, y1, y2, y3);
-          } else {
-            uint2 o;
-            o.x = pack_bf16x2(y0, y1);
-            o.y = pack_bf16x2(y2, y3);
-            if constexpr (EPI == EPI_QKV) {
-              bf16_t* dst = f < a.H ? a.Qo + t * a.H + f : a.Ko + t * a.H + (f - a.H);
-              *(uint2*)dst = o;
-            } else {
-              *(uint2*)(a.Cb + t * a.N + f) = o;
-              if constexpr (EPI == EPI_GELU_SAVE) {
-                uint2 o2;
-                o2.x = pack_bf16x2(p0, p1);
-                o2.y = pack_bf16x2(p2, p3);
-                *(uint2*)(a.Cb2 + t * a.N + f) = o2;
+        for (int pass = 0; pass < CT::PASSES; ++pass) {
+          if (BF16_OUT && (pass || out)) lds_barrier();   // the previous pass has been read out
+#pragma unroll
+          for (int ntl = 0; ntl < CT::NTP; ++ntl) {
+            const int nt = pass * CT::NTP + ntl;
+            const int64_t t = t0 + w.l_index(nt);  // token on the lane
+            const bool t_ok = t < a.rows;
+            const int64_t tc = t_ok ? t : a.rows - 1;
+            uint2 res[T::MT][4];
+            if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_DGELU_BF16) {
+              if (EPI == EPI_DGELU_BF16 || a.Rf == nullptr) {
+#pragma unroll
+                for (int mt = 0; mt < T::MT; ++mt)
+#pragma unroll
+                  for (int g = 0; g < 4; ++g) {
+                    int f = n0 + w.r_base(mt, g);
+                    f = (full_n || f < a.N) ? f : a.N - 4;
+                    res[mt][g] = *(const uint2*)(a.R + tc * a.N + f);
+                  }
               }
             }
+#pragma unroll
+            for (int mt = 0; mt < T::MT; ++mt)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int fl = w.r_base(mt, g);      // 4 consecutive features (N % 4 == 0)
+                const int f = n0 + fl;
+                const f32x16& v = acc.c[mt][nt];
+                const float4 bv = *(const float4*)(sbias + fl);
+                f32x2_t y01 = (f32x2_t){v[4 * g + 0], v[4 * g + 1]} + (f32x2_t){bv.x, bv.y};
+                f32x2_t y23 = (f32x2_t){v[4 * g + 2], v[4 * g + 3]} + (f32x2_t){bv.z, bv.w};
+                float y0 = y01.x, y1 = y01.y, y2 = y23.x, y3 = y23.y;
+                if constexpr (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_SAVE) {
+                  if (out == 0) {
+                    y0 = gelu_sig(y0); y1 = gelu_sig(y1); y2 = gelu_sig(y2); y3 = gelu_sig(y3);
+                  }
+                }
+                if constexpr (EPI == EPI_DGELU_BF16) {
+                  const uint2 r = res[mt][g];
+                  y0 *= gelu_grad(__uint_as_float(r.x << 16)); y1 *= gelu_grad(__uint_as_float(r.x & 0xffff0000u));
+                  y2 *= gelu_grad(__uint_as_float(r.y << 16)); y3 *= gelu_grad(__uint_as_float(r.y & 0xffff0000u));
+                }
+                if constexpr (EPI == EPI_RESID_F32) {
+                  if (a.Rf) {
+                    const int fc = (full_n || f < a.N) ? f : a.N - 4;
+                    const float4 r = *(const float4*)(a.Rf + tc * a.N + fc);
+                    y0 += r.x; y1 += r.y; y2 += r.z; y3 += r.w;
+                  } else {
+                    const uint2 r = res[mt][g];
+                    y0 += __uint_as_float(r.x << 16); y1 += __uint_as_float(r.x & 0xffff0000u);
+                    y2 += __uint_as_float(r.y << 16); y3 += __uint_as_float(r.y & 0xffff0000u);
+                  }
+                }
+                if constexpr (BF16_OUT) {
+                  uint2 o;
+                  o.x = pack_bf16x2(y0, y1);
+                  o.y = pack_bf16x2(y2, y3);
+                  CT::put(sC, w, mt, nt, g, o);
+                } else if (t_ok && (full_n || f < a.N)) {
+                  if constexpr (EPI == EPI_SLAB_F32) {
+                    *(float4*)(a.Cf + ((int64_t)blockIdx.y * a.rows + t) * a.N + f) = make_float4(y0, y1, y2, y3);
+                  } else {
+                    *(float4*)(a.Cf + t * a.N + f) = make_float4(y0, y1, y2, y3);
+                  }
+                }
+              }
+          }
+          CONVDR_TRACE(3 + 4 * pass)
+          if constexpr (BF16_OUT) {
+            lds_barrier();
+            CONVDR_TRACE(4 + 4 * pass)
+            if (out == NOUT - 1 && pass == CT::PASSES - 1 && has_next) {   // see the V third above
+              lds_dma_wait_all();
+              landed = true;
+            }
+            CONVDR_TRACE(5 + 4 * pass)
+            if (a.dbg_skip_epi != 3) {
+              if constexpr (EPI == EPI_QKV) {   // the tile lies inside the Q or the K third (H % TR == 0)
+                bf16_t* dst = n0 < a.H ? a.Qo + t0 * a.H + n0 : a.Ko + t0 * a.H + (n0 - a.H);
+                CT::store(sC, pass, dst, a.H, a.rows - t0, T::TR);
+              } else {
+                CT::store(sC, pass, (out ? a.Cb2 : a.Cb) + t0 * a.N + n0, a.N, a.rows - t0, a.N - n0);
+              }
+            }
+            CONVDR_TRACE(6 + 4 * pass)
           }
         }
-      }
+    }
+    ++trace_tile;
+    if (!has_next) break;
+    idx = next;
+    c = cn;
+    buf = idle;
   }
 }
 

@@ -6,17 +6,23 @@
 
 namespace convdr {
 
+// experiment hook: when set (convdr_set_option "gemm_trace" = device pointer), FFN1 launches record phase stamps
+inline void* g_gemm_trace = nullptr;
+
 template <int EPI, class T>
 inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
   static_assert(T::TR == T::TL, "square tiles: the QKV kernel swaps operand roles per tile");
   static bool attr_done = false;
   if (!attr_done) {
     CONVDR_CHECK_HIP(
-        hipFuncSetAttribute((const void*)k_gemm<EPI, T>, hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM_BYTES));
+        hipFuncSetAttribute((const void*)k_gemm<EPI, T>, hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM_BYTES + T::TR * 4));
     attr_done = true;
   }
   static const int dbg = getenv("CONVDR_DBG_SAME_TILE") ? atoi(getenv("CONVDR_DBG_SAME_TILE")) : 0;
   a.dbg_same_tile = dbg;
+  static const int dbg_epi = getenv("CONVDR_DBG_SKIP_EPI") ? atoi(getenv("CONVDR_DBG_SKIP_EPI")) : 0;
+  a.dbg_skip_epi = dbg_epi;
+  a.trace = (EPI == EPI_GELU_BF16) ? (unsigned long long*)g_gemm_trace : nullptr;
   a.tilesN = (a.N + T::TR - 1) / T::TR;
   a.tilesT = (int)ceil_div64(a.rows, T::TL);
   if (a.tilesT == 0) return 0;
@@ -27,8 +33,12 @@ inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
     splits = a.K / a.k_split_len;
   }
   ProfScope prof(prof_name, st);
-  hipLaunchKernelGGL((k_gemm<EPI, T>), dim3((unsigned)a.tilesN * a.tilesT, splits), dim3(T::THREADS), T::SMEM_BYTES, st,
-                     a);
+  // persistent walk: at most one workgroup per resident slot (Tile256: 1 per CU, Tile128: 2 per CU)
+  static const int dbg_np = getenv("CONVDR_DBG_NONPERSISTENT") ? atoi(getenv("CONVDR_DBG_NONPERSISTENT")) : 0;
+  const int64_t slots = (int64_t)device_cu_count() * (T::SMEM_BYTES > 80 * 1024 ? 1 : 2);
+  int64_t grid = (int64_t)a.tilesN * a.tilesT;
+  if (!dbg_np && splits == 1 && grid > slots) grid = slots;
+  hipLaunchKernelGGL((k_gemm<EPI, T>), dim3((unsigned)grid, splits), dim3(T::THREADS), T::SMEM_BYTES + T::TR * 4, st, a);
   CONVDR_CHECK_LAUNCH("k_gemm");
   return 0;
 }
@@ -38,11 +48,14 @@ inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
 template <int EPI>
 inline int launch_gemm(GemmArgs a, hipStream_t st, const char* prof_name) {
   CONVDR_REQUIRE(a.K % GEMM_BK == 0 && a.N % 4 == 0, "gemm: need K %% 64 == 0 and N %% 4 == 0 (K=%d N=%d)", a.K, a.N);
-  if (EPI == EPI_QKV) CONVDR_REQUIRE(a.H % 128 == 0, "gemm: fused QKV needs hidden %% 128 == 0 (%d)", a.H);
+  if (EPI == EPI_QKV) CONVDR_REQUIRE(a.H % 128 == 0 && a.ldt % 8 == 0, "gemm: fused QKV needs hidden %% 128 == 0 (%d)", a.H);
+  if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_GELU_SAVE || EPI == EPI_DGELU_BF16)
+    CONVDR_REQUIRE(a.N % 8 == 0, "gemm: bf16 outputs are stored 16 bytes at a time, need N %% 8 == 0 (N=%d)", a.N);
   const bool fits = a.N % 256 == 0 && (EPI != EPI_QKV || a.H % 256 == 0);
   int64_t tiles256 = (int64_t)(a.N / 256) * ceil_div64(a.rows, 256);
   if (EPI == EPI_SLAB_F32 && a.k_split_len) tiles256 *= a.K / a.k_split_len;
-  if (fits && tiles256 >= 192) return launch_gemm_t<EPI, Tile256>(a, st, prof_name);
+  static const int force128 = getenv("CONVDR_DBG_TILE128") ? atoi(getenv("CONVDR_DBG_TILE128")) : 0;
+  if (fits && tiles256 >= 192 && !force128) return launch_gemm_t<EPI, Tile256>(a, st, prof_name);
   return launch_gemm_t<EPI, Tile128>(a, st, prof_name);
 }
 

@@ -37,13 +37,19 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // all of this wave's outstanding LDS-DMA (and other vector-memory) operations have completed
 __device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() additionally drains the vector-memory queue
+// (vmcnt(0)) whenever an LDS-DMA is in flight, which is exactly what must NOT happen in an epilogue that runs under
+// the next tile's prefetch.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int WR_, int WL_, int MT_, int NT_>
 struct TileCfg {
   static constexpr int WR = WR_, WL = WL_, MT = MT_, NT = NT_;
   static constexpr int TR = WR * MT * 32, TL = WL * NT * 32;   // tile extent on the R / L operand
   static constexpr int WAVES = WR * WL, THREADS = WAVES * 64;
   static constexpr int R_BYTES = TR * 128, L_BYTES = TL * 128;  // one K step of each operand
-  static constexpr int SMEM_BYTES = 2 * (R_BYTES + L_BYTES);
+  static constexpr int STAGE_BYTES = R_BYTES + L_BYTES;
+  static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
   static constexpr int MIN_WAVES_PER_SIMD = THREADS >= 512 ? 2 : 2;
 };
 using Tile128 = TileCfg<2, 2, 2, 2>;
@@ -82,56 +88,93 @@ struct WavePos {
 };
 
 // Stage rows [row0, row0 + ROWS) x k-chunk kt of G ([nrows, ld] bf16) into an LDS tile of ROWS x 128 B.
-// Rows past nrows-1 are clamped (their products are never stored).
+// The source goes through a buffer descriptor whose window starts at the tile's first row and ends at the end of
+// the operand: rows past nrows-1 are out of range for the hardware bounds check and arrive as zeros (their products
+// are never stored), and the whole address is ONE per-lane 32-bit offset (row-in-round x pitch + swizzled 16-byte
+// chunk) plus wave-uniform scalar offsets for the round and the K chunk -- no per-round 64-bit address registers in
+// the main loop (the flat-address form held 16 of them and pushed the persistent kernels into scratch).
+typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
+
+struct StageSrc {
+  __amdgpu_buffer_rsrc_t rsrc;   // window [tile row 0, end of operand)
+  uint32_t voff;                 // this lane's byte offset inside a round
+  uint32_t round_pitch;          // bytes between rounds (8 * WAVES rows)
+};
+
+template <int WAVES>
+__device__ __forceinline__ StageSrc gemm_stage_src(const bf16_t* __restrict__ G, int64_t ld, int64_t row0, int64_t nrows,
+                                                    int wave, int lane) {
+  StageSrc s;
+  int64_t bytes = (nrows - row0) * ld * 2;
+  bytes = bytes < 0 ? 0 : (bytes > 0xffffffffll ? 0xffffffffll : bytes);
+  // the descriptor must be provably wave-uniform or hipcc wraps every load in a waterfall loop
+  const uint64_t base = (uint64_t)(G + row0 * ld);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+  const uint32_t nb = __builtin_amdgcn_readfirstlane((uint32_t)bytes);
+  s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
+  const int row = wave * 8 + (lane >> 3);                       // row inside a round; rounds are 8 * WAVES rows apart,
+  const int gch = (lane & 7) ^ ((row >> 1) & 7);                // a multiple of 16, so the swizzle is round-independent
+  s.voff = (uint32_t)(row * ld * 2) + gch * 16;
+  s.round_pitch = __builtin_amdgcn_readfirstlane((uint32_t)(8 * WAVES * ld * 2));
+  return s;
+}
+
 template <int ROWS, int WAVES>
-__device__ __forceinline__ void gemm_stage(const bf16_t* __restrict__ G, int64_t ld, int64_t row0, int64_t nrows,
-                                           int kt, char* lds_tile, int wave, int lane) {
+__device__ __forceinline__ void gemm_stage(const StageSrc& s, int kt, char* lds_tile, int wave) {
   constexpr int ROUNDS = ROWS / (8 * WAVES);
   static_assert(ROUNDS * 8 * WAVES == ROWS, "tile rows must be a multiple of 8 * waves");
 #pragma unroll
-  for (int i = 0; i < ROUNDS; ++i) {
-    const int r0 = (i * WAVES + wave) * 8;
-    const int row = r0 + (lane >> 3);
-    int64_t grow = row0 + row;
-    grow = grow < nrows ? grow : nrows - 1;
-    const int gch = (lane & 7) ^ ((row >> 1) & 7);
-    const char* src = (const char*)G + ((grow * ld + (int64_t)kt * GEMM_BK) << 1) + gch * 16;
-    glds16(src, lds_tile + r0 * 128);
-  }
+  for (int i = 0; i < ROUNDS; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds_tile + (i * WAVES + wave) * 8 * 128), 16, s.voff,
+                                             i * s.round_pitch + kt * (GEMM_BK * 2), 0, 0);
+}
+
+// LDS image: two stages of STAGE_BYTES = R_BYTES + L_BYTES, each [R tile | L tile] (a whole stage is one contiguous
+// region, so the idle stage can serve as epilogue scratch while the other already receives the next tile).
+template <class T>
+struct TileSrc {
+  StageSrc R, L;
+  __device__ __forceinline__ TileSrc(const bf16_t* __restrict__ Rp, int64_t ldr, int64_t nR, const bf16_t* __restrict__ Lp,
+                                     int64_t ldl, int64_t nL, int64_t r0, int64_t l0, const WavePos<T>& w)
+      : R(gemm_stage_src<T::WAVES>(Rp, ldr, r0, nR, w.wave, w.lane)),
+        L(gemm_stage_src<T::WAVES>(Lp, ldl, l0, nL, w.wave, w.lane)) {}
+};
+
+template <class T>
+__device__ __forceinline__ void gemm_issue_stage(const TileSrc<T>& src, int kt, char* stage, const WavePos<T>& w) {
+  gemm_stage<T::TR, T::WAVES>(src.R, kt, stage, w.wave);
+  gemm_stage<T::TL, T::WAVES>(src.L, kt, stage + T::R_BYTES, w.wave);
 }
 
 // acc += R[r0:r0+TR, :] * L[l0:l0+TL, :]^T   (K must be a multiple of 64)
+// first_buf: the stage that holds (or receives) K chunk 0; stage0_in_flight: the caller has already issued it with
+// gemm_issue_stage (cross-tile prefetch of a persistent kernel); stage0_landed: ... and waited for it (vmcnt).  Returns the stage NOT read by the last K step: once
+// a wave is back from this call it may issue DMA into that stage (every wave has passed the last barrier, so all
+// reads of it are done); the other stage may be reused only after one more __syncthreads().
 template <class T>
-__device__ __forceinline__ void gemm_nt_mainloop(const bf16_t* __restrict__ R, int64_t ldr, int64_t nR,
-                                                 const bf16_t* __restrict__ L, int64_t ldl, int64_t nL, int K,
-                                                 int64_t r0, int64_t l0, char* smem, GemmAcc<T>& acc,
-                                                 const WavePos<T>& w, int k_begin = 0) {
-  // contraction range [k_begin, k_begin + K): split-K callers pass a slice
-  R += k_begin;
-  L += k_begin;
-  char* sR = smem;
-  char* sL = smem + 2 * T::R_BYTES;
+__device__ __forceinline__ int gemm_nt_mainloop(const TileSrc<T>& src, int K, char* smem, GemmAcc<T>& acc,
+                                                const WavePos<T>& w, int first_buf = 0, bool stage0_in_flight = false,
+                                                bool stage0_landed = false) {
   const int nk = K / GEMM_BK;
   const int sw = (w.lane >> 1) & 7;
   const int offR = (w.wr * T::MT * 32 + w.li) * 128;
-  const int offL = (w.wl * T::NT * 32 + w.li) * 128;
+  const int offL = T::R_BYTES + (w.wl * T::NT * 32 + w.li) * 128;
 
-  gemm_stage<T::TR, T::WAVES>(R, ldr, r0, nR, 0, sR, w.wave, w.lane);
-  gemm_stage<T::TL, T::WAVES>(L, ldl, l0, nL, 0, sL, w.wave, w.lane);
+  if (!stage0_in_flight) gemm_issue_stage<T>(src, 0, smem + first_buf * T::STAGE_BYTES, w);
 
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+    const int buf = (kt + first_buf) & 1;
     // Tile kt must have LANDED in LDS for every wave before anyone reads it.  LDS-DMA completion is tracked by
-    // vmcnt; hipcc's automatic wait before the barrier is NOT reliable for global_load_lds (observed missing in
-    // one of two inlined copies of this loop -> rare stale operand rows), so drain explicitly.
-    lds_dma_wait_all();
-    __syncthreads();  // ... and every wave is done reading buffer buf^1 (step kt-1)
-    if (kt + 1 < nk) {
-      gemm_stage<T::TR, T::WAVES>(R, ldr, r0, nR, kt + 1, sR + (buf ^ 1) * T::R_BYTES, w.wave, w.lane);
-      gemm_stage<T::TL, T::WAVES>(L, ldl, l0, nL, kt + 1, sL + (buf ^ 1) * T::L_BYTES, w.wave, w.lane);
-    }
-    const char* tR = sR + buf * T::R_BYTES + offR;
-    const char* tL = sL + buf * T::L_BYTES + offL;
+    // vmcnt; hipcc's automatic wait before the barrier is NOT reliable for LDS-DMA (observed missing in one of two
+    // inlined copies of this loop -> rare stale operand rows), so drain explicitly.
+    // (stage0_landed: the caller has already waited for chunk 0 -- before issuing its epilogue stores, so that this
+    // wait, which is in issue order, does not sit behind their write acknowledgements)
+    if (kt > 0 || !stage0_landed) lds_dma_wait_all();
+    lds_barrier();  // ... and every wave is done reading buffer buf^1 (step kt-1)
+    if (kt + 1 < nk) gemm_issue_stage<T>(src, kt + 1, smem + (buf ^ 1) * T::STAGE_BYTES, w);
+    const char* tR = smem + buf * T::STAGE_BYTES + offR;
+    const char* tL = smem + buf * T::STAGE_BYTES + offL;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int ch = ((2 * s + w.hi) ^ sw) * 16;
@@ -147,6 +190,17 @@ __device__ __forceinline__ void gemm_nt_mainloop(const bf16_t* __restrict__ R, i
           acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc.c[i][j], 0, 0, 0);
     }
   }
+  return (nk + first_buf) & 1;
+}
+
+// convenience form: contraction range [k_begin, k_begin + K) of R[r0.., :] and L[l0.., :]
+template <class T>
+__device__ __forceinline__ int gemm_nt_mainloop(const bf16_t* __restrict__ R, int64_t ldr, int64_t nR,
+                                                const bf16_t* __restrict__ L, int64_t ldl, int64_t nL, int K,
+                                                int64_t r0, int64_t l0, char* smem, GemmAcc<T>& acc,
+                                                const WavePos<T>& w, int k_begin = 0) {
+  const TileSrc<T> src(R + k_begin, ldr, nR, L + k_begin, ldl, nL, r0, l0, w);
+  return gemm_nt_mainloop<T>(src, K, smem, acc, w);
 }
 
 }  // namespace convdr

@@ -246,7 +246,7 @@ def test_flat_arena_training_matches_per_parameter_path():
         results.append((losses, {k: v.detach().clone() for k, v in student.state_dict().items()}))
     assert results[0][0] == results[1][0]
     for k, v in results[0][1].items():
-        if "word_embeddings" in k or "position_embeddings" in k:
+        if "embeddings." in k and "LayerNorm" not in k:   # embedding gradients are fp32 atomics: order-dependent rounding
             assert torch.allclose(v, results[1][1][k], rtol=1e-5, atol=1e-7), k
         else:
             assert torch.equal(v, results[1][1][k]), k
