@@ -60,7 +60,8 @@ static int gemm_resid_ln(const bf16_t* W, const bf16_t* A, int64_t rows, int H, 
           hipFuncSetAttribute((const void*)k_gemm_resid_ln, hipFuncAttributeMaxDynamicSharedMemorySize, LN_SMEM_BYTES));
       attr_done = true;
     }
-    GemmLnArgs a{W, A, rows, K, bias, R, gamma, beta, eps, X};
+    GemmLnArgs a{W, A, rows, K, bias, R, gamma, beta, eps, X,
+                 K == 768 ? (unsigned long long*)g_gemm_trace_ln : nullptr};
     ProfScope prof(name, st);
     hipLaunchKernelGGL(k_gemm_resid_ln, dim3((unsigned)ceil_div64(rows, TileLN::TL)), dim3(512), LN_SMEM_BYTES, st, a);
     CONVDR_CHECK_LAUNCH("k_gemm_resid_ln");
@@ -219,6 +220,10 @@ extern "C" int convdr_set_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "fused_ln_max_k") == 0) {
     g_fused_ln_max_k = value;
+    return 0;
+  }
+  if (strcmp(name, "gemm_trace_ln") == 0) {   // same for k_gemm_resid_ln (the K = 768 launches)
+    g_gemm_trace_ln = (void*)(uintptr_t)value;
     return 0;
   }
   if (strcmp(name, "gemm_trace") == 0) {   // experiment: device buffer for k_gemm phase stamps (0 = off)

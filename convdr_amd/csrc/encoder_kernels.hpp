@@ -270,32 +270,29 @@ struct CTile {
   __device__ static __forceinline__ void put(char* sC, const WavePos<T>& w, int mt, int nt, int g, uint2 o) {
     const int fl = w.r_base(mt, g);
     const int row = (w.wl * NTP + (nt % NTP)) * 32 + w.li;
-    *(uint2*)(sC + addr(row, fl >> 3) + (fl & 4) * 2) = o;
+    lds_write_b64_hidden(lds_off(sC) + addr(row, fl >> 3) + (fl & 4) * 2, (u32x2_t){o.x, o.y});
   }
   // dst -> element (L row 0, R index 0) of the tile; row_limit / col_limit = valid L rows / R indices (col_limit % 4 == 0).
   // Thread t owns 16-byte chunk t % CH of rows t / CH + 16 i: all LDS reads are issued before the first store, the
   // per-iteration row offsets are compile-time, and a tile that lies fully inside the matrix takes no bound checks
   // (the store tail was issue-bound: 325 cycles per store with the generic index arithmetic, measured by s_memtime).
   __device__ static __forceinline__ void store(const char* sC, int pass, bf16_t* dst, int64_t ld, int64_t row_limit,
-                                               int64_t col_limit) {
+                                               int64_t col_limit, int tid) {
     constexpr int RPI = T::THREADS / CH;   // rows covered per iteration
     constexpr int BATCH = 4;               // LDS reads in flight before their stores (16 VGPRs; the kernel is at the cap)
     static_assert(RPI * CH == T::THREADS && (32 * NTP) % RPI == 0 && ROWS % RPI == 0 && STORES_PER_WAVE % BATCH == 0,
                   "store geometry");
-    const int r0 = threadIdx.x / CH, c = threadIdx.x - r0 * CH;
+    const int r0 = tid / CH, c = tid - r0 * CH;
     const int64_t nv = col_limit - c * 8;
     bf16_t* p = dst + c * 8 + (int64_t)r0 * ld;
-    const char* q = sC + addr(r0, c);
     const bool inside = row_limit >= T::TL && col_limit >= T::TR;   // workgroup-uniform
 #pragma unroll
     for (int i0 = 0; i0 < STORES_PER_WAVE; i0 += BATCH) {
-      uint4 v[BATCH];
-#pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        // rows i * RPI + r0 with RPI a multiple of CH... the swizzle term of addr() depends on the row only through
-        // (row ^ row / CH) & (CH - 1): recompute per row (cheap) rather than assume
-        v[j] = *(const uint4*)(sC + addr((i0 + j) * RPI + r0, c));
-      }
+      u32x4_t v[BATCH];
+      static_assert(BATCH == 4, "lds_read4_b128_hidden reads four chunks");
+      const uint32_t sb = lds_off(sC);
+      lds_read4_b128_hidden(sb + addr((i0 + 0) * RPI + r0, c), sb + addr((i0 + 1) * RPI + r0, c),
+                            sb + addr((i0 + 2) * RPI + r0, c), sb + addr((i0 + 3) * RPI + r0, c), v[0], v[1], v[2], v[3]);
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         constexpr int blk = 32 * NTP;
@@ -303,14 +300,13 @@ struct CTile {
         const int rowc = ((i * RPI) / blk * T::NT + pass * NTP) * 32 + (i * RPI) % blk;   // compile-time part of the row
         bf16_t* pr = p + (int64_t)rowc * ld;
         if (inside) {
-          *(uint4*)pr = v[j];
+          *(u32x4_t*)pr = v[j];
         } else if (rowc + r0 < row_limit && nv > 0) {
-          if (nv >= 8) *(uint4*)pr = v[j];
+          if (nv >= 8) *(u32x4_t*)pr = v[j];
           else *(uint2*)pr = make_uint2(v[j].x, v[j].y);
         }
       }
     }
-    (void)q;
   }
 };
 
@@ -339,7 +335,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
   uint32_t idx = blockIdx.x >> 3;
   if (idx >= chunk_len) return;
 
-  struct Coord { int64_t t0; int n0; bool swap; };   // swap: V third of the fused QKV projection (tokens on registers)
+  struct Coord { int64_t t0; int n0; int swap; };   // swap: V third of the fused QKV projection (tokens on registers)
   auto decode = [&](uint32_t i) {
     const uint32_t logical = chunk_base + i;
     int tt = logical / a.tilesN, tn = logical - tt * a.tilesN;
@@ -358,44 +354,81 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
 
   float* sbias = (float*)(smem + T::SMEM_BYTES);
   int trace_tile = 0;
+#ifdef CONVDR_ENABLE_TRACE   // make TRACE=1: phase stamps for tools/gemm_trace.py
 #define CONVDR_TRACE(ph)                                                                                       \
   if (a.trace && threadIdx.x == 0 && trace_tile < 64)                                                          \
     a.trace[((size_t)blockIdx.x * 64 + trace_tile) * 16 + (ph)] = __builtin_amdgcn_s_memtime();
+#else
+#define CONVDR_TRACE(ph)
+#endif
+  // Bias handling is shaped by one compiler fact: while an LDS-DMA is in flight hipcc puts s_waitcnt vmcnt(0) in
+  // front of the next LDS read or global-load use it can see, which would drain the next tile's prefetch at the top
+  // of the epilogue.  So the epilogue of a bf16 tile touches LDS only through inline asm (CTile), and the bias never
+  // appears there: a tile's bias slice is fetched during the PREVIOUS tile's main loop, parked in LDS right after it
+  // (before the prefetch is issued), and folded into the accumulator initialisation at the tile's start -- where a
+  // wait for chunk 0 is due anyway.  (V-third tiles have the feature on the lane: their bias sits in registers.)
+  auto bias_slice = [&](const Coord& cc) {   // this thread's element of a tile's bias slice
+    const int f = cc.n0 + (int)threadIdx.x;
+    return (!cc.swap && a.bias && threadIdx.x < T::TR && f < a.N) ? a.bias[f] : 0.f;
+  };
   Coord c = decode(idx);
   int buf = 0;
   bool landed = false;   // chunk 0 of the current tile has been waited for
+  if (threadIdx.x < T::TR) sbias[threadIdx.x] = bias_slice(c);
   TileSrc<T> src = tile_src(c);
   gemm_issue_stage<T>(src, 0, smem + buf * T::STAGE_BYTES, w);
+  __syncthreads();
   for (;;) {
+    const uint32_t next = idx + stride;
+    const bool has_next = next < chunk_len;
+    const Coord cn = has_next ? decode(next) : c;
     GemmAcc<T> acc;
-    acc.zero();
-    // bias values are fetched BEFORE the main loop and parked in LDS after it: an ordinary global load issued while
-    // the next tile's LDS-DMA is in flight would make hipcc drain the whole vector-memory queue at its first use
-    float bias_pre[T::NT];
+    float bias_lane[T::NT];   // V third only
     if (c.swap) {
+      acc.zero();
 #pragma unroll
       for (int nt = 0; nt < T::NT; ++nt) {
-        const int f = c.n0 + w.l_index(nt);  // V third: feature on the lane
-        bias_pre[nt] = a.bias[f < a.N ? f : a.N - 1];
+        const int f = c.n0 + w.l_index(nt);  // feature on the lane
+        bias_lane[nt] = a.bias[f < a.N ? f : a.N - 1];
       }
     } else {
-      const int f = c.n0 + (int)threadIdx.x;
-      bias_pre[0] = (a.bias && threadIdx.x < T::TR && f < a.N) ? a.bias[f] : 0.f;
+#pragma unroll
+      for (int nt = 0; nt < T::NT; ++nt) bias_lane[nt] = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < T::MT; ++mt) {
+        u32x4_t bq[4];
+        const uint32_t sb = lds_off(sbias);
+        lds_read4_b128_hidden(sb + w.r_base(mt, 0) * 4, sb + w.r_base(mt, 1) * 4, sb + w.r_base(mt, 2) * 4,
+                              sb + w.r_base(mt, 3) * 4, bq[0], bq[1], bq[2], bq[3]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int nt = 0; nt < T::NT; ++nt) {
+            acc.c[mt][nt][4 * g + 0] = __uint_as_float(bq[g].x); acc.c[mt][nt][4 * g + 1] = __uint_as_float(bq[g].y);
+            acc.c[mt][nt][4 * g + 2] = __uint_as_float(bq[g].z); acc.c[mt][nt][4 * g + 3] = __uint_as_float(bq[g].w);
+          }
+      }
     }
+    float bias_next = has_next ? bias_slice(cn) : 0.f;
     CONVDR_TRACE(0)
     int idle;   // the stage the last K step did not read
     idle = gemm_nt_mainloop<T>(src, c.swap ? a.K : klen, smem, acc, w, buf, true, landed);
     landed = false;
-    CONVDR_TRACE(1)
-    const uint32_t next = idx + stride;
-    const bool has_next = next < chunk_len;
-    Coord cn = c;
+    // hipcc does not see the main loop's inline-asm waits: make it retire the bias loads HERE (a no-op wait, nothing
+    // is in flight), not at their first use further down
+    asm volatile("" : "+v"(bias_next));
+#pragma unroll
+    for (int i = 0; i < T::NT; ++i) asm volatile("" : "+v"(bias_lane[i]));
+    if (threadIdx.x < T::TR) sbias[threadIdx.x] = bias_next;   // (every wave has read this tile's slice before its
+    CONVDR_TRACE(1)                                             //  first main-loop barrier; nothing is in flight here)
     if (has_next) {
-      cn = decode(next);
       src = tile_src(cn);
       gemm_issue_stage<T>(src, 0, smem + idle * T::STAGE_BYTES, w);
     }
     char* sC = smem + (idle ^ 1) * T::STAGE_BYTES;   // epilogue scratch: the stage of the last K step
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));   // opaque: keeps the epilogue's lane-dependent addresses out of the main loop's registers
+    const WavePos<T> we(tid_e);
     const int64_t t0 = c.t0;
     const int n0 = c.n0;
 
@@ -417,7 +450,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
 #pragma unroll
         for (int ntl = 0; ntl < CT::NTP; ++ntl) {
           const int nt = pass * CT::NTP + ntl;
-          const float bv = bias_pre[nt];
+          const float bv = bias_lane[nt];
 #pragma unroll
           for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
@@ -426,7 +459,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
               uint2 o;
               o.x = pack_bf16x2(v[4 * g + 0] + bv, v[4 * g + 1] + bv);
               o.y = pack_bf16x2(v[4 * g + 2] + bv, v[4 * g + 3] + bv);
-              CT::put(sC, w, mt, nt, g, o);
+              CT::put(sC, we, mt, nt, g, o);
             }
         }
         lds_barrier();
@@ -434,14 +467,12 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
           lds_dma_wait_all();                        // BEFORE the last stores enter the (in-order) queue
           landed = true;
         }
-        CT::store(sC, pass, a.Vt + (int64_t)(n0 - 2 * a.H) * a.ldt + t0, a.ldt, a.N - n0, a.rows - t0);
+        CT::store(sC, pass, a.Vt + (int64_t)(n0 - 2 * a.H) * a.ldt + t0, a.ldt, a.N - n0, a.rows - t0, tid_e);
       }
     } else {
       // ---- epilogue: the tile's bias slice is parked in LDS behind the stages (no vmcnt round trip per register
       // quad), all residual loads of a 32-token column block are issued up front ----
-      // (the main loop's barriers separate this write from the previous tile's reads of sbias)
-      if (threadIdx.x < T::TR) sbias[threadIdx.x] = bias_pre[0];
-      lds_barrier();     // ... and every wave is done with the last K step's stage
+      lds_barrier();     // every wave is done with the last K step's stage (and the next tile's sbias is visible)
       CONVDR_TRACE(2)
       const bool full_n = n0 + T::TR <= a.N;  // workgroup-uniform: no per-quad feature bound checks on the fast path
       constexpr bool BF16_OUT = EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV || EPI == EPI_GELU_SAVE ||
@@ -455,7 +486,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
 #pragma unroll
           for (int ntl = 0; ntl < CT::NTP; ++ntl) {
             const int nt = pass * CT::NTP + ntl;
-            const int64_t t = t0 + w.l_index(nt);  // token on the lane
+            const int64_t t = t0 + we.l_index(nt);  // token on the lane
             const bool t_ok = t < a.rows;
             const int64_t tc = t_ok ? t : a.rows - 1;
             uint2 res[T::MT][4];
@@ -465,7 +496,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                 for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
                   for (int g = 0; g < 4; ++g) {
-                    int f = n0 + w.r_base(mt, g);
+                    int f = n0 + we.r_base(mt, g);
                     f = (full_n || f < a.N) ? f : a.N - 4;
                     res[mt][g] = *(const uint2*)(a.R + tc * a.N + f);
                   }
@@ -475,13 +506,10 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
             for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
-                const int fl = w.r_base(mt, g);      // 4 consecutive features (N % 4 == 0)
+                const int fl = we.r_base(mt, g);      // 4 consecutive features (N % 4 == 0)
                 const int f = n0 + fl;
                 const f32x16& v = acc.c[mt][nt];
-                const float4 bv = *(const float4*)(sbias + fl);
-                f32x2_t y01 = (f32x2_t){v[4 * g + 0], v[4 * g + 1]} + (f32x2_t){bv.x, bv.y};
-                f32x2_t y23 = (f32x2_t){v[4 * g + 2], v[4 * g + 3]} + (f32x2_t){bv.z, bv.w};
-                float y0 = y01.x, y1 = y01.y, y2 = y23.x, y3 = y23.y;
+                float y0 = v[4 * g + 0], y1 = v[4 * g + 1], y2 = v[4 * g + 2], y3 = v[4 * g + 3];   // bias included
                 if constexpr (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_SAVE) {
                   if (out == 0) {
                     y0 = gelu_sig(y0); y1 = gelu_sig(y1); y2 = gelu_sig(y2); y3 = gelu_sig(y3);
@@ -507,7 +535,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                   uint2 o;
                   o.x = pack_bf16x2(y0, y1);
                   o.y = pack_bf16x2(y2, y3);
-                  CT::put(sC, w, mt, nt, g, o);
+                  CT::put(sC, we, mt, nt, g, o);
                 } else if (t_ok && (full_n || f < a.N)) {
                   if constexpr (EPI == EPI_SLAB_F32) {
                     *(float4*)(a.Cf + ((int64_t)blockIdx.y * a.rows + t) * a.N + f) = make_float4(y0, y1, y2, y3);
@@ -529,9 +557,9 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
             if (a.dbg_skip_epi != 3) {
               if constexpr (EPI == EPI_QKV) {   // the tile lies inside the Q or the K third (H % TR == 0)
                 bf16_t* dst = n0 < a.H ? a.Qo + t0 * a.H + n0 : a.Ko + t0 * a.H + (n0 - a.H);
-                CT::store(sC, pass, dst, a.H, a.rows - t0, T::TR);
+                CT::store(sC, pass, dst, a.H, a.rows - t0, T::TR, tid_e);
               } else {
-                CT::store(sC, pass, (out ? a.Cb2 : a.Cb) + t0 * a.N + n0, a.N, a.rows - t0, a.N - n0);
+                CT::store(sC, pass, (out ? a.Cb2 : a.Cb) + t0 * a.N + n0, a.N, a.rows - t0, a.N - n0, tid_e);
               }
             }
             CONVDR_TRACE(6 + 4 * pass)

@@ -42,6 +42,27 @@ __device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmc
 // the next tile's prefetch.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// LDS accesses the compiler must not see.  While an LDS-DMA is in flight hipcc guards every LDS access it knows about
+// with s_waitcnt vmcnt(0) (it cannot prove the DMA targets another region), which serialises an epilogue that runs
+// under the next tile's prefetch.  These wrappers take 32-bit LDS byte addresses; reads wait for their own data.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_off(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void lds_write_b64_hidden(uint32_t addr, u32x2_t v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");   // retired by lds_barrier()'s lgkmcnt(0)
+}
+__device__ __forceinline__ void lds_read4_b128_hidden(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, u32x4_t& v0,
+                                                      u32x4_t& v1, u32x4_t& v2, u32x4_t& v3) {
+  asm volatile(
+      "ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+      : "memory");
+}
+
 template <int WR_, int WL_, int MT_, int NT_>
 struct TileCfg {
   static constexpr int WR = WR_, WL = WL_, MT = MT_, NT = NT_;
@@ -73,9 +94,12 @@ struct GemmAcc {
 template <class T>
 struct WavePos {
   int lane, wave, wr, wl, hi, li;
-  __device__ __forceinline__ WavePos() {
-    lane = threadIdx.x & 63;
-    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __device__ __forceinline__ WavePos() : WavePos((int)threadIdx.x) {}
+  // from an explicit thread index: epilogues pass an opaque copy (asm volatile("" : "+v"(tid))) so that the address
+  // arithmetic derived from it is NOT hoisted out of a persistent tile loop and kept in registers across the main loop
+  __device__ __forceinline__ explicit WavePos(int tid) {
+    lane = tid & 63;
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     wr = wave / T::WL;
     wl = wave - wr * T::WL;
     hi = lane >> 5;

@@ -1,5 +1,6 @@
 """Phase timing inside the FFN1 GEMM (k_gemm<EPI_GELU_BF16>): s_memtime stamps of wave 0 of every workgroup at the
-phase boundaries of each tile; prints mean microseconds per phase.  Experiment tool, not part of the product."""
+phase boundaries of each tile; prints median shader cycles per phase.  Needs a trace build
+(make -C convdr_amd/csrc clean all TRACE=1).  Experiment tool, not part of the product."""
 import os
 import sys
 
@@ -27,13 +28,10 @@ t = buf.cpu().numpy().reshape(512, 64, 16).astype(np.float64)[:256]
 ntile = int((t[0, :, 0] > 0).sum())
 print("tiles per workgroup:", ntile)
 t = t[:, :ntile]
-tick = 1e-2  # s_memtime ticks at 100 MHz on gfx9
 names = ["mainloop", "prefetch+bias+barrier", "pass0 compute", "pass0 barrier", "pass0 dma-wait", "pass0 store issue",
          "pass1 compute", "pass1 barrier", "pass1 dma-wait", "pass1 store issue"]
-ph = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10)]
-for n, (a, b) in zip(names, ph):
-    d = (t[:, :, b] - t[:, :, a]) * tick
-    print("%-24s mean %7.2f us   p10 %7.2f  p90 %7.2f" % (n, d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
-tile = (t[:, 1:, 0] - t[:, :-1, 0]) * tick
-print("tile period               mean %7.2f us" % tile.mean())
-print("first tile start spread   %.2f us" % ((t[:, 0, 0].max() - t[:, 0, 0].min()) * tick))
+for i, n in enumerate(names):
+    d = t[:, :, i + 1] - t[:, :, i]
+    print("%-24s median %8.0f cycles   p10 %8.0f  p90 %8.0f" % (n, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+tile = t[:, 1:, 0] - t[:, :-1, 0]
+print("tile period              median %8.0f cycles" % np.median(tile))
