@@ -31,10 +31,14 @@ def flop_per_passage(L):
 
 
 def random_rdot_model(seed=0):
+    import contextlib
     import torch
     from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
     torch.manual_seed(seed)
-    return MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig())
+    # the model constructor announces "Using mean: ..." on stdout like the reference (models.py:134); stdout of this
+    # script is reserved for the one JSON line
+    with contextlib.redirect_stdout(sys.stderr):
+        return MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig())
 
 
 def synthetic_tokens(n, L, seed, device):
