@@ -222,7 +222,9 @@ int convdr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, d
                       convdr_stream_t stream);
 
 /* Tuning / test knobs: "fused_ln_min_rows" = minimum packed rows for the fused GEMM + residual + LayerNorm kernel
- * (default 24576; tests lower it to exercise that kernel on small inputs). */
+ * (default 24576; tests lower it to exercise that kernel on small inputs); "fused_ln_max_k" = largest contraction
+ * length it is used for; "gemm_trace" / "gemm_trace_ln" = device buffer for the s_memtime phase stamps of a
+ * `make TRACE=1` build (tools/gemm_trace*.py; 0 = off). */
 int convdr_set_option(const char* name, int64_t value);
 
 /* Test aid: byte offsets of the activation buffers inside the encoder workspace, in the order tok_id, tok_pos, X, Q, K,

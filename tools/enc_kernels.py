@@ -15,6 +15,10 @@ def main():
     L = int(sys.argv[2]) if len(sys.argv) > 2 else 128
     steps = 6
     model = bench.random_rdot_model(0).cuda().eval()
+    for kv in os.environ.get("CONVDR_OPTIONS", "").split(","):   # e.g. CONVDR_OPTIONS=ln_stagger=2
+        if "=" in kv:
+            k, v = kv.split("=")
+            _lib.check(_lib.lib().convdr_set_option(k.encode(), int(v)), "convdr_set_option")
     import numpy as np
     ids = bench.synthetic_tokens(B, L, 0, "cuda")
     lens = np.full(B, L, np.int32)

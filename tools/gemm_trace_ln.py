@@ -30,5 +30,9 @@ names = ["mainloop", "barrier + stage LN params + barrier", "bias + residual + r
 for i, n in enumerate(names[:7]):
     d = t[:, i + 1] - t[:, i]
     print("%-42s median %8.0f cycles   p10 %8.0f  p90 %8.0f" % (n, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
+for n, (i, j) in (("half 0: DMA issue", (2, 8)), ("half 0: DMA wait", (8, 9)), ("half 0: barrier", (9, 10)), ("half 0: consume", (10, 11)),
+                  ("half 0: normalise + park", (6, 12)), ("half 0: barrier", (12, 13)), ("half 0: store issue", (13, 14))):
+    d = t[:, j] - t[:, i]
+    print("%-42s median %8.0f cycles   p10 %8.0f  p90 %8.0f" % (n, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
 d = t[:, 7] - t[:, 0]
 print("%-42s median %8.0f cycles" % ("whole workgroup", np.median(d)))
