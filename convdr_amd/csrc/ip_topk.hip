@@ -472,6 +472,56 @@ static int launch_scan(const ScanArgs& a, bool big, hipStream_t st) {
 
 using namespace convdr;
 
+// ---- two-way merge of sorted per-query lists (run_convdr_inference.py:213-229) -------------------------------------
+// One workgroup per query.  Every element computes its own output slot: its index in its list + the number of
+// elements of the other list that precede it (binary search on the descending scores held in LDS) -- A before B on
+// ties, so for a in A the B elements strictly greater count, for b in B the A elements greater or equal.
+namespace convdr {
+__global__ void __launch_bounds__(256) k_topk_merge(const float* __restrict__ Da, const int64_t* __restrict__ Ia, int na,
+                                                    int64_t lda, const float* __restrict__ Db,
+                                                    const int64_t* __restrict__ Ib, int nb, int64_t ldb, int n_out,
+                                                    float* __restrict__ Dout, int64_t* __restrict__ Iout, int64_t ldo) {
+  extern __shared__ float sm[];
+  float* sa = sm;
+  float* sb = sm + na;
+  const int q = blockIdx.x;
+  Da += q * lda; Ia += q * lda; Db += q * ldb; Ib += q * ldb; Dout += q * ldo; Iout += q * ldo;
+  for (int i = threadIdx.x; i < na; i += 256) sa[i] = Da[i];
+  for (int i = threadIdx.x; i < nb; i += 256) sb[i] = Db[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < na + nb; i += 256) {
+    const bool from_a = i < na;
+    const int j = from_a ? i : i - na;
+    const float v = from_a ? sa[j] : sb[j];
+    const float* other = from_a ? sb : sa;
+    int lo = 0, hi = from_a ? nb : na;       // first index of `other` that does NOT precede v
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      const bool precedes = from_a ? (other[mid] > v) : (other[mid] >= v);
+      if (precedes) lo = mid + 1; else hi = mid;
+    }
+    const int pos = j + lo;
+    if (pos < n_out) {
+      Dout[pos] = v;
+      Iout[pos] = from_a ? Ia[j] : Ib[j];
+    }
+  }
+}
+}  // namespace convdr
+
+extern "C" int convdr_topk_merge(const float* Da, const int64_t* Ia, int na, int64_t lda, const float* Db, const int64_t* Ib,
+                                 int nb, int64_t ldb, int nq, int n_out, float* Dout, int64_t* Iout, int64_t ldo,
+                                 convdr_stream_t stream) {
+  using namespace convdr;
+  CONVDR_REQUIRE(na >= 0 && nb >= 0 && na <= 4096 && nb <= 4096 && n_out >= 0 && n_out <= na + nb && nq >= 0,
+                 "convdr_topk_merge: bad sizes na=%d nb=%d n_out=%d nq=%d", na, nb, n_out, nq);
+  if (nq == 0 || n_out == 0) return 0;
+  hipLaunchKernelGGL(k_topk_merge, dim3(nq), dim3(256), (size_t)(na + nb) * 4, (hipStream_t)stream, Da, Ia, na, lda, Db, Ib,
+                     nb, ldb, n_out, Dout, Iout, ldo);
+  CONVDR_CHECK_LAUNCH("k_topk_merge");
+  return 0;
+}
+
 extern "C" int convdr_ip_column_mean(const float* p_f32, int64_t n, int d, float* scratch /* >= 64 * d floats */,
                                      float* mean, convdr_stream_t stream) {
   CONVDR_REQUIRE(n > 0 && d > 0, "convdr_ip_column_mean: empty block");

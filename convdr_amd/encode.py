@@ -27,9 +27,31 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
+def plan_batches(lens, batch_size, token_budget=None):
+    """Cut a shard's records, IN ORDER, into batches of at most `batch_size` records and -- when `token_budget` is given
+    -- at most `token_budget` real tokens (a single longer record still forms a batch).  Returns [(start, stop)].
+    The encoder computes packed rows, so its work per batch is the token count, not records x max length: a token
+    budget keeps every launch at the size the GEMM tiles are tuned for (262,144 rows = 1,024 row tiles of 256) whatever
+    the length mix of the corpus.  Embeddings do not depend on the batching (tests/test_encoder_gpu.py)."""
+    lens = np.asarray(lens, dtype=np.int64)
+    n = len(lens)
+    if token_budget is None:
+        return [(s, min(s + batch_size, n)) for s in range(0, n, batch_size)]
+    csum = np.concatenate([[0], np.cumsum(lens)])
+    out, s = [], 0
+    while s < n:
+        # largest e with csum[e] - csum[s] <= budget, at least one record, at most batch_size
+        e = int(np.searchsorted(csum, csum[s] + token_budget, side="right")) - 1
+        e = min(max(e, s + 1), s + batch_size, n)
+        out.append((s, e))
+        s = e
+    return out
+
+
 def encode_shard(model, cache, rank=0, world=1, batch_size=1024, is_query_inference=False, max_seq_length=None,
-                 progress=None):
-    """-> (embedding float32 [n, D] numpy, embedding2id int64 [n]) for this rank's records, in record order."""
+                 progress=None, token_budget=None):
+    """-> (embedding float32 [n, D] numpy, embedding2id int64 [n]) for this rank's records, in record order.
+    token_budget: see plan_batches (batch_size then only caps the record count and sizes the staging buffers)."""
     tower_call = _embed_fn(model, is_query_inference)
     dev = next(model.parameters()).device
     idx = blocks.shard_indices(len(cache), world, rank)
@@ -38,9 +60,9 @@ def encode_shard(model, cache, rank=0, world=1, batch_size=1024, is_query_infere
     out = None
     stage = [torch.empty((batch_size, L), dtype=torch.int32).pin_memory() for _ in range(2)]
     events = [None, None]
-    for bi, s in enumerate(range(0, len(idx), batch_size)):
-        sel = idx[s:s + batch_size]
-        lens = lens_all[s:s + batch_size]
+    for bi, (s, e) in enumerate(plan_batches(lens_all, batch_size, token_budget)):
+        sel = idx[s:e]
+        lens = lens_all[s:e]
         n, lmax = len(sel), int(lens.max())
         buf = stage[bi & 1]
         if events[bi & 1] is not None:

@@ -189,6 +189,11 @@ class FlatIPIndex:
 
     def search(self, q, k):
         """FAISS ``index.search``: numpy in, numpy (D, I) out; always the exact top-k or an exception."""
+        D, I = self.search_tensors(q, k)
+        return D.cpu().numpy(), I.cpu().numpy()
+
+    def search_tensors(self, q, k):
+        """``search`` with the certified result left on the device (torch fp32 [nq, k], int64 [nq, k])."""
         import torch
         qt = torch.as_tensor(q)
         if qt.dtype != torch.float32:
@@ -212,7 +217,7 @@ class FlatIPIndex:
         if len(bad):
             raise _lib.ConvdrError("convdr_ip_search: %d queries could not be certified (more than 8192 passages inside the "
                                    "error band of the k-th score even with the split-bf16 scan)" % len(bad))
-        return D.cpu().numpy(), I.cpu().numpy()
+        return D, I
 
 
 def load_block(path):
@@ -234,8 +239,28 @@ def merge_topk(merged, cand, topN):
     return np.take_along_axis(aD, order, 1), np.take_along_axis(aI, order, 1)
 
 
+def merge_topk_device(merged, cand, topN):
+    """``merge_topk`` on the device: (D fp32 [nq, na], I int64 [nq, na]) torch tensors in and out, same permutation
+    (convdr_topk_merge: A before B on equal scores, each list in its own order)."""
+    import torch
+    Da, Ia = merged[0][:, :topN], merged[1][:, :topN]
+    Db, Ib = cand[0][:, :topN], cand[1][:, :topN]
+    nq, na, nb = Da.shape[0], Da.shape[1], Db.shape[1]
+    Do = torch.empty((nq, na + nb), dtype=torch.float32, device=Da.device)
+    Io = torch.empty((nq, na + nb), dtype=torch.int64, device=Da.device)
+    with torch.cuda.device(Da.device):
+        _lib.check(_lib.lib().convdr_topk_merge(_lib.ptr(Da), _lib.ptr(Ia), na, Da.stride(0), _lib.ptr(Db), _lib.ptr(Ib), nb,
+                                                Db.stride(0), nq, na + nb, _lib.ptr(Do), _lib.ptr(Io), Do.stride(0),
+                                                _lib.stream_ptr()), "convdr_topk_merge")
+    return Do, Io
+
+
 def search_one_by_one(ann_data_dir, gpu_index, query_embedding, topN, max_blocks=8):
-    """Block-by-block search + merge; same contract as the reference function."""
+    """Block-by-block search + merge; same contract as the reference function (float64 scores, int64 offsets,
+    2 * topN columns once two blocks have been merged).  With a FlatIPIndex the per-block results, the offset lookup
+    ``embid[I]`` and the running merge stay on the device; any other index object (``.add/.search/.reset``) takes the
+    reference's host path."""
+    on_device = hasattr(gpu_index, "search_tensors")
     merged = None
     for block_id in range(max_blocks):
         try:
@@ -244,12 +269,22 @@ def search_one_by_one(ann_data_dir, gpu_index, query_embedding, topN, max_blocks
         except Exception:
             break
         gpu_index.add(passage_embedding)
-        D, I = gpu_index.search(query_embedding, topN)
+        if on_device:
+            import torch
+            D, I = gpu_index.search_tensors(query_embedding, topN)
+            embid = torch.as_tensor(np.asarray(passage_embedding2id, dtype=np.int64), device=D.device)
+            ids = torch.where(I >= 0, embid[I.clamp_min(0)], I) if embid.numel() else I   # -1 padding when n < topN
+            cand = (D, ids)
+            merged = cand if merged is None else merge_topk_device(merged, cand, topN)
+        else:
+            D, I = gpu_index.search(query_embedding, topN)
+            cand = (D.astype(np.float64), np.asarray(passage_embedding2id)[I])
+            merged = cand if merged is None else merge_topk(merged, cand, topN)
         gpu_index.reset()
-        cand = (D.astype(np.float64), np.asarray(passage_embedding2id)[I])
-        merged = cand if merged is None else merge_topk(merged, cand, topN)
     if merged is None:
         raise FileNotFoundError("no passage blocks under %s" % ann_data_dir)
+    if on_device:
+        return merged[0].double().cpu().numpy(), merged[1].cpu().numpy()
     return merged
 
 

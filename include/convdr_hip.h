@@ -90,6 +90,15 @@ int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, const void*
 const uint32_t* convdr_ip_debug_counts(const void* workspace, int nq, int64_t n, int d, int k, int cap);
 const uint32_t* convdr_ip_debug_band(const void* workspace, int nq, int64_t n, int d, int k, int cap);
 
+/* Two-way merge of per-query result lists: replaces the Python pointer walk of
+ *   /root/reference/drivers/run_convdr_inference.py:213-229
+ * Da/Ia [nq, na] is the running result (earlier blocks), Db/Ib [nq, nb] the new block's, every row sorted by score
+ * descending.  Writes the first n_out (<= na + nb) entries of the complete merge; on equal scores the entry of list
+ * A comes first (`>=`, :218) and each list keeps its own order -- the permutation a stable descending sort of the
+ * concatenation [A, B] produces.  lda / ldb / ldo: row pitches in elements.  na, nb <= 4096. */
+int convdr_topk_merge(const float* Da, const int64_t* Ia, int na, int64_t lda, const float* Db, const int64_t* Ib, int nb,
+                      int64_t ldb, int nq, int n_out, float* Dout, int64_t* Iout, int64_t ldo, convdr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dual-encoder forward: replaces the HuggingFace RobertaModel / BertModel forward + pooling + head
  * behind  /root/reference/model/models.py:140-148 (RobertaDot_NLL_LN.query_emb / body_emb) and

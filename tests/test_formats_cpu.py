@@ -59,3 +59,22 @@ def test_block_view_reads_reference_written_blocks(golden_dir, tmp_path):
     with blocks.BlockView(p) as v:
         assert v.offset % 4 != 0 or True                     # payload offset is header dependent / unaligned
         np.testing.assert_array_equal(v.array, big)
+
+
+def test_plan_batches_token_budget():
+    """In-order batches: record cap, token cap, oversize records alone, full coverage without overlap."""
+    from convdr_amd.encode import plan_batches
+    rs = np.random.RandomState(0)
+    lens = rs.randint(1, 513, size=1000)
+    for bs, budget in ((64, None), (64, 4096), (1024, 262144), (8, 100), (1, 10 ** 9)):
+        plan = plan_batches(lens, bs, budget)
+        assert plan[0][0] == 0 and plan[-1][1] == len(lens)
+        assert all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
+        for s, e in plan:
+            assert 1 <= e - s <= bs
+            if budget is not None and e - s > 1:
+                assert lens[s:e].sum() <= budget
+            if budget is not None and e < len(lens) and e - s < bs:
+                assert lens[s:e + 1].sum() > budget          # greedy: the next record would not have fitted
+    assert plan_batches([], 8, 100) == []
+    assert plan_batches([700], 8, 100) == [(0, 1)]

@@ -117,6 +117,38 @@ def test_search_one_by_one_matches_reference_fixture(torch_cuda, golden_dir, tmp
     np.testing.assert_array_equal(mD, oD)
 
 
+def test_device_merge_equals_reference_pointer_walk(torch_cuda):
+    """convdr_topk_merge against the oracle's restatement of the reference's two-pointer merge, on lists full of ties
+    (duplicated scores inside and across the two lists), ragged widths and -FLT_MAX / -1 padding."""
+    torch = torch_cuda
+    from convdr_amd.search import merge_topk_device
+    rs = np.random.RandomState(3)
+    for na, nb, nq in ((100, 100, 37), (7, 100, 5), (1, 1, 3), (256, 300, 11)):
+        def lists(n):
+            d = np.sort(rs.randint(0, 40, size=(nq, n)).astype(np.float32) * 0.25, axis=1)[:, ::-1].copy()
+            d[:, n - n // 5:] = -3.4028234663852886e38      # FAISS-style padding tail
+            i = rs.randint(0, 10 ** 9, size=(nq, n)).astype(np.int64)
+            i[:, n - n // 5:] = -1
+            return d, i
+        (Da, Ia), (Db, Ib) = lists(na), lists(nb)
+        Do, Io = merge_topk_device((torch.from_numpy(Da).cuda(), torch.from_numpy(Ia).cuda()),
+                                   (torch.from_numpy(Db).cuda(), torch.from_numpy(Ib).cuda()), max(na, nb))
+        Do, Io = Do.cpu().numpy(), Io.cpu().numpy()
+        for q in range(nq):
+            # the reference walk needs equal lengths (both lists are topN long there): pad the shorter with -inf
+            # entries, which the walk leaves at the tail, and compare the real prefix
+            ref, p1, p2 = [], 0, 0
+            A, B = list(zip(Da[q], Ia[q])), list(zip(Db[q], Ib[q]))
+            while p1 < na and p2 < nb:
+                if A[p1][0] >= B[p2][0]:
+                    ref.append(A[p1]); p1 += 1
+                else:
+                    ref.append(B[p2]); p2 += 1
+            ref += A[p1:] + B[p2:]
+            assert [float(x) for x in Do[q]] == [float(s) for s, _ in ref]
+            assert [int(x) for x in Io[q]] == [int(i) for _, i in ref]
+
+
 def test_full_size_properties_1m_x_1k(torch_cuda):
     """BASELINE config 2 size (1M x 768, 1k queries, k=100): size-independent properties,
     checked with an independent fp32 GEMM (torch/rocBLAS) on the same device."""
