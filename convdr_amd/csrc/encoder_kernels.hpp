@@ -412,7 +412,8 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
     float bias_next = has_next ? bias_slice(cn) : 0.f;
     CONVDR_TRACE(0)
     int idle;   // the stage the last K step did not read
-    idle = gemm_nt_mainloop<T>(src, c.swap ? a.K : klen, smem, acc, w, buf, true, landed);
+    idle = gemm_nt_mainloop<T>(src, c.swap ? a.K : klen, smem, acc, w, buf, true, landed,
+                               (a.trace && trace_tile == 8) ? a.trace + ((size_t)blockIdx.x * 64 + 56) * 16 : nullptr);
     landed = false;
     // hipcc does not see the main loop's inline-asm waits: make it retire the bias loads HERE (a no-op wait, nothing
     // is in flight), not at their first use further down

@@ -41,9 +41,13 @@ struct GemmLnArgs {
 
 // 32-wide K slices: 64-byte LDS rows, 16 rows per wave per round, rounds 128 rows apart (so the swizzle term
 // (row >> 2) & 3 does not depend on the round).  Same buffer-descriptor addressing as gemm_nt.hpp's gemm_stage.
+constexpr int LN_DMA_WAVES = CONVDR_DMA_YOUNG_HALF ? 4 : 8;   // issuing waves (the younger half, see TileCfg::DMA_WAVES)
+constexpr int LN_DMA_FIRST = 8 - LN_DMA_WAVES;
+
 __device__ __forceinline__ StageSrc ln_stage_src(const bf16_t* __restrict__ G, int64_t ld, int64_t row0, int64_t nrows,
                                                   int wave, int lane) {
   StageSrc s;
+  wave = wave >= LN_DMA_FIRST ? wave - LN_DMA_FIRST : 0;
   int64_t bytes = (nrows - row0) * ld * 2;
   bytes = bytes < 0 ? 0 : (bytes > 0xffffffffll ? 0xffffffffll : bytes);
   const uint64_t base = (uint64_t)(G + row0 * ld);
@@ -54,17 +58,19 @@ __device__ __forceinline__ StageSrc ln_stage_src(const bf16_t* __restrict__ G, i
   const int row = wave * 16 + (lane >> 2);
   const int gch = (lane & 3) ^ ((row >> 2) & 3);
   s.voff = (uint32_t)(row * ld * 2) + gch * 16;
-  s.round_pitch = __builtin_amdgcn_readfirstlane((uint32_t)(128 * ld * 2));
+  s.round_pitch = __builtin_amdgcn_readfirstlane((uint32_t)(16 * LN_DMA_WAVES * ld * 2));
   return s;
 }
 
 template <int ROWS>
 __device__ __forceinline__ void ln_stage32(const StageSrc& s, int ks, char* lds_tile, int wave) {
-  constexpr int ROUNDS = ROWS / (16 * 8);
-  static_assert(ROUNDS * 128 == ROWS, "rows must be a multiple of 128");
+  if (LN_DMA_FIRST > 0 && wave < LN_DMA_FIRST) return;   // wave-uniform
+  wave -= LN_DMA_FIRST;
+  constexpr int ROUNDS = ROWS / (16 * LN_DMA_WAVES);
+  static_assert(ROUNDS * 16 * LN_DMA_WAVES == ROWS, "rows must be a multiple of 16 x issuing waves");
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds_tile + (i * 8 + wave) * 16 * 64), 16, s.voff,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds_tile + (i * LN_DMA_WAVES + wave) * 16 * 64), 16, s.voff,
                                              i * s.round_pitch + ks * (LN_SLICE * 2), 0, 0);
 }
 

@@ -26,6 +26,12 @@
 namespace convdr {
 
 constexpr int GEMM_BK = 64;
+#ifndef CONVDR_FRAG_PIPELINE
+#define CONVDR_FRAG_PIPELINE 1
+#endif
+#ifndef CONVDR_DMA_YOUNG_HALF
+#define CONVDR_DMA_YOUNG_HALF 1
+#endif
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -68,6 +74,13 @@ struct TileCfg {
   static constexpr int WR = WR_, WL = WL_, MT = MT_, NT = NT_;
   static constexpr int TR = WR * MT * 32, TL = WL * NT * 32;   // tile extent on the R / L operand
   static constexpr int WAVES = WR * WL, THREADS = WAVES * 64;
+  // Waves that issue the LDS-DMA of a stage.  An 8-wave workgroup puts two waves on every SIMD; if all eight issue
+  // their share right after the barrier, the ~1.3 k cycles the 64 DMA instructions need to drain through the
+  // texture path pass with the matrix pipe idle (s_memtime: 544 cycles for the older wave of a SIMD, 1,590 for the
+  // younger, then both start their MFMAs).  With only the younger half (waves 4-7) issuing, the older wave of each
+  // SIMD runs its MFMAs under the younger's DMA issue and the younger follows.
+  static constexpr int DMA_WAVES = (WAVES == 8 && CONVDR_DMA_YOUNG_HALF) ? 4 : WAVES;
+  static constexpr int DMA_FIRST = WAVES - DMA_WAVES;
   static constexpr int R_BYTES = TR * 128, L_BYTES = TL * 128;  // one K step of each operand
   static constexpr int STAGE_BYTES = R_BYTES + L_BYTES;
   static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
@@ -122,12 +135,13 @@ typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
 struct StageSrc {
   __amdgpu_buffer_rsrc_t rsrc;   // window [tile row 0, end of operand)
   uint32_t voff;                 // this lane's byte offset inside a round
-  uint32_t round_pitch;          // bytes between rounds (8 * WAVES rows)
+  uint32_t round_pitch;          // bytes between rounds (8 * issuing waves rows)
 };
 
-template <int WAVES>
+template <int WAVES, int FIRST>   // WAVES issuing waves, the first of which is wave FIRST
 __device__ __forceinline__ StageSrc gemm_stage_src(const bf16_t* __restrict__ G, int64_t ld, int64_t row0, int64_t nrows,
                                                     int wave, int lane) {
+  wave = wave >= FIRST ? wave - FIRST : 0;
   StageSrc s;
   int64_t bytes = (nrows - row0) * ld * 2;
   bytes = bytes < 0 ? 0 : (bytes > 0xffffffffll ? 0xffffffffll : bytes);
@@ -144,8 +158,10 @@ __device__ __forceinline__ StageSrc gemm_stage_src(const bf16_t* __restrict__ G,
   return s;
 }
 
-template <int ROWS, int WAVES>
+template <int ROWS, int WAVES, int FIRST>
 __device__ __forceinline__ void gemm_stage(const StageSrc& s, int kt, char* lds_tile, int wave) {
+  if (FIRST > 0 && wave < FIRST) return;   // wave-uniform
+  wave -= FIRST;
   constexpr int ROUNDS = ROWS / (8 * WAVES);
   static_assert(ROUNDS * 8 * WAVES == ROWS, "tile rows must be a multiple of 8 * waves");
 #pragma unroll
@@ -161,14 +177,14 @@ struct TileSrc {
   StageSrc R, L;
   __device__ __forceinline__ TileSrc(const bf16_t* __restrict__ Rp, int64_t ldr, int64_t nR, const bf16_t* __restrict__ Lp,
                                      int64_t ldl, int64_t nL, int64_t r0, int64_t l0, const WavePos<T>& w)
-      : R(gemm_stage_src<T::WAVES>(Rp, ldr, r0, nR, w.wave, w.lane)),
-        L(gemm_stage_src<T::WAVES>(Lp, ldl, l0, nL, w.wave, w.lane)) {}
+      : R(gemm_stage_src<T::DMA_WAVES, T::DMA_FIRST>(Rp, ldr, r0, nR, w.wave, w.lane)),
+        L(gemm_stage_src<T::DMA_WAVES, T::DMA_FIRST>(Lp, ldl, l0, nL, w.wave, w.lane)) {}
 };
 
 template <class T>
 __device__ __forceinline__ void gemm_issue_stage(const TileSrc<T>& src, int kt, char* stage, const WavePos<T>& w) {
-  gemm_stage<T::TR, T::WAVES>(src.R, kt, stage, w.wave);
-  gemm_stage<T::TL, T::WAVES>(src.L, kt, stage + T::R_BYTES, w.wave);
+  gemm_stage<T::TR, T::DMA_WAVES, T::DMA_FIRST>(src.R, kt, stage, w.wave);
+  gemm_stage<T::TL, T::DMA_WAVES, T::DMA_FIRST>(src.L, kt, stage + T::R_BYTES, w.wave);
 }
 
 // acc += R[r0:r0+TR, :] * L[l0:l0+TL, :]^T   (K must be a multiple of 64)
@@ -179,7 +195,7 @@ __device__ __forceinline__ void gemm_issue_stage(const TileSrc<T>& src, int kt, 
 template <class T>
 __device__ __forceinline__ int gemm_nt_mainloop(const TileSrc<T>& src, int K, char* smem, GemmAcc<T>& acc,
                                                 const WavePos<T>& w, int first_buf = 0, bool stage0_in_flight = false,
-                                                bool stage0_landed = false) {
+                                                bool stage0_landed = false, unsigned long long* step_trace = nullptr) {
   const int nk = K / GEMM_BK;
   const int sw = (w.lane >> 1) & 7;
   const int offR = (w.wr * T::MT * 32 + w.li) * 128;
@@ -194,11 +210,47 @@ __device__ __forceinline__ int gemm_nt_mainloop(const TileSrc<T>& src, int K, ch
     // inlined copies of this loop -> rare stale operand rows), so drain explicitly.
     // (stage0_landed: the caller has already waited for chunk 0 -- before issuing its epilogue stores, so that this
     // wait, which is in issue order, does not sit behind their write acknowledgements)
+#ifdef CONVDR_ENABLE_TRACE   // stamps of K step 6 for lane 0 of every wave: [wave][0..4]
+#define CONVDR_STEP_TRACE(i) \
+  if (step_trace && kt == 6 + (i) / 5 && w.lane == 0) step_trace[w.wave * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define CONVDR_STEP_TRACE(i)
+#endif
+    CONVDR_STEP_TRACE(5)   // (top of step 7)
+    CONVDR_STEP_TRACE(0)
     if (kt > 0 || !stage0_landed) lds_dma_wait_all();
+    CONVDR_STEP_TRACE(1)
     lds_barrier();  // ... and every wave is done reading buffer buf^1 (step kt-1)
+    CONVDR_STEP_TRACE(2)
     if (kt + 1 < nk) gemm_issue_stage<T>(src, kt + 1, smem + (buf ^ 1) * T::STAGE_BYTES, w);
+    CONVDR_STEP_TRACE(3)
     const char* tR = smem + buf * T::STAGE_BYTES + offR;
     const char* tL = smem + buf * T::STAGE_BYTES + offL;
+#if CONVDR_FRAG_PIPELINE
+    // Fragments of 16-wide K sub-step s + 1 are read while the MFMAs of sub-step s run (two register sets).  Left to
+    // itself hipcc reuses one small set and parks an LDS round trip (s_waitcnt lgkmcnt(0..2)) in front of every
+    // second MFMA pair -- ~240 idle pipe cycles per sub-step per wave in the s_memtime trace.
+    bf16x8 fa[2][T::MT], fb[2][T::NT];
+    auto load_frags = [&](int s, int set) {
+      const int ch = ((2 * s + w.hi) ^ sw) * 16;
+#pragma unroll
+      for (int j = 0; j < T::NT; ++j) fb[set][j] = *(const bf16x8*)(tL + j * 32 * 128 + ch);
+#pragma unroll
+      for (int i = 0; i < T::MT; ++i) fa[set][i] = *(const bf16x8*)(tR + i * 32 * 128 + ch);
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s + 1 < 4) load_frags(s + 1, (s + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);   // the prefetch stays ahead of this sub-step's MFMAs
+#pragma unroll
+      for (int i = 0; i < T::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < T::NT; ++j)
+          acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc.c[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int ch = ((2 * s + w.hi) ^ sw) * 16;
@@ -213,6 +265,8 @@ __device__ __forceinline__ int gemm_nt_mainloop(const TileSrc<T>& src, int K, ch
         for (int j = 0; j < T::NT; ++j)
           acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc.c[i][j], 0, 0, 0);
     }
+#endif
+    CONVDR_STEP_TRACE(4)
   }
   return (nk + first_buf) & 1;
 }

@@ -135,6 +135,10 @@ def test_corpus_encode_loop_matches_reference_blocks(golden_dir, tmp_path):
             e, i = encode.encode_shard(model, cache, rank=r, world=2, batch_size=5)
             assert i.tolist() == list(range(r, N, 2))
             np.testing.assert_allclose(e, emb[r::2], atol=1e-5)
+        # token-budget batches (ragged record counts per launch): same embeddings
+        e, i = encode.encode_shard(model, cache, batch_size=64, token_budget=3 * L // 2)
+        assert i.tolist() == list(range(N))
+        np.testing.assert_allclose(e, emb, atol=1e-5)
 
 
 def test_forward_is_bitwise_deterministic():

@@ -35,3 +35,12 @@ for i, n in enumerate(names):
     print("%-24s median %8.0f cycles   p10 %8.0f  p90 %8.0f" % (n, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
 tile = t[:, 1:, 0] - t[:, :-1, 0]
 print("tile period              median %8.0f cycles" % np.median(tile))
+
+# K step 6 of tile 8, per wave (rows 56..59 of the workgroup's stamp block): [wave][0..5]
+raw = buf.cpu().numpy().reshape(512, 64, 16).astype(np.float64)[:256, 56:60].reshape(256, 8, 8)
+ok = raw[:, :, 5] > 0
+print("per-wave K step (cycles, median over workgroups): wave | dma-wait | barrier | dma-issue | reads+mfma issue | step period")
+for wv in range(8):
+    r = raw[ok[:, wv], wv]
+    print("  wave %d | %6.0f | %6.0f | %6.0f | %6.0f | %6.0f" % (wv, np.median(r[:, 1] - r[:, 0]), np.median(r[:, 2] - r[:, 1]),
+          np.median(r[:, 3] - r[:, 2]), np.median(r[:, 4] - r[:, 3]), np.median(r[:, 5] - r[:, 0])))
