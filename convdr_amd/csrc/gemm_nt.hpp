@@ -15,11 +15,12 @@
 //   Tile256: 2 x 4 waves, 4 x 2 tiles -> 256 x 256, 512 threads, 128 KB LDS, 1 workgroup per CU; halves the
 //            L2->LDS bytes per FLOP and makes one K step long enough (2048 MFMA cycles per SIMD) that the
 //            one-step-ahead LDS-DMA prefetch covers HBM latency without a second resident workgroup
-// Operand tiles are staged HBM/L2 -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4), double buffered, one
-// barrier per K step: the loads for step t+1 fly under the MFMAs of step t.  LDS rows are 128 B; the 16-byte
-// chunk index is XOR-swizzled with (row >> 1) & 7 so that the ds_read_b128 fragment reads (32 rows x one chunk)
-// are bank-conflict free.  LDS-DMA writes lane-linear, so the swizzle is applied to the per-lane GLOBAL source
-// address (it stays inside the row's 128-byte line, coalescing is unchanged).
+// Operand tiles are staged HBM/L2 -> LDS with 16-byte LDS-DMA through a buffer descriptor (buffer_load_dwordx4 ...
+// lds), double buffered, one barrier per K step: the loads for step t+1 fly under the MFMAs of step t; in 8-wave
+// tiles only the younger wave of each SIMD issues them (TileCfg::DMA_WAVES).  LDS rows are 128 B; the 16-byte chunk
+// index is XOR-swizzled with (row >> 1) & 7 so that the ds_read_b128 fragment reads (32 rows x one chunk) are
+// bank-conflict free.  LDS-DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE offset (it stays
+// inside the row's 128-byte line, coalescing is unchanged).
 #pragma once
 #include "common.hpp"
 
