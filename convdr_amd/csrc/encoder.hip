@@ -103,7 +103,7 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
   g.Qo = p.Q; g.Ko = p.K; g.Vt = p.Vt; g.H = H; g.ldt = p.ldt;
   if (int e = launch_gemm<EPI_QKV>(g, st, "gemm_qkv")) return e;
   {
-    AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, (int64_t)H, p.ctx, lse, 0.125f};
+    AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, (int64_t)H, p.ctx, lse, 0.125f, (unsigned long long*)g_attn_trace};
     ProfScope prof("attention", st);
     // cls_only: the first query block of every sequence is enough (it contains the CLS row)
     hipLaunchKernelGGL(k_attention_fwd, dim3(cls_only ? 1 : (max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st,
@@ -220,6 +220,10 @@ extern "C" int convdr_set_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "fused_ln_max_k") == 0) {
     g_fused_ln_max_k = value;
+    return 0;
+  }
+  if (strcmp(name, "attn_trace") == 0) {
+    g_attn_trace = (void*)(uintptr_t)value;
     return 0;
   }
   if (strcmp(name, "gemm_trace_ln") == 0) {   // same for k_gemm_resid_ln (the K = 768 launches)

@@ -596,7 +596,15 @@ struct AttnArgs {
   bf16_t* ctx;
   float* lse;       // [heads, ldt] or nullptr
   float scale;      // 1 / sqrt(head_dim)
+  unsigned long long* trace;   // TRACE builds: [workgroup][8] s_memtime stamps of thread 0 (or null)
 };
+#ifdef CONVDR_ENABLE_TRACE
+#define CONVDR_ATT_TRACE(i)                                                                                  \
+  if (a.trace && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x == 0 && blockIdx.z < 2048)                \
+    a.trace[blockIdx.z * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define CONVDR_ATT_TRACE(i)
+#endif
 
 constexpr int ATT_TILE_PAIR = 2 * 64 * 128;   // K tile + V^T tile, 8 KB each
 constexpr int ATT_SMEM_BYTES = 2 * ATT_TILE_PAIR;  // double buffered
@@ -607,13 +615,17 @@ static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs 
   const int len = a.lens[b];
   const int q0 = blockIdx.x * 128;
   if (q0 >= len) return;
+  CONVDR_ATT_TRACE(0)
   const int64_t base = a.cu[b];
+  const int plen = a.cu[b + 1] - (int)base;  // len rounded up to the row alignment (fetched with the other scalars: a
+                                             // scalar load issued in the epilogue costs a full ~4 k-cycle round trip)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5, li = lane & 31;
   const int q = q0 + wave * 32 + li;
   const int qc = q < len ? q : len - 1;
   const int H = a.H;
+  CONVDR_ATT_TRACE(1)
 
   bf16x8 qf[4];
   {
@@ -643,12 +655,18 @@ static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs 
              smem + buf * ATT_TILE_PAIR + 64 * 128 + r0 * 128);
     }
   };
+  // Both buffers are filled up front: the kernel is bound by memory latency x bytes in flight (a workgroup's whole
+  // working set is 64 KB and its arithmetic ~1 us), so the second tile's round trip must not start after the first's
+  // has completed -- for the 128-token passages of the corpus that is the entire K/V of the head.
   stage_tile(0, 0);
+  if (len > 64) stage_tile(64, 1);
   for (int kv0 = 0, it = 0; kv0 < len; kv0 += 64, ++it) {
     const int buf = it & 1;
     lds_dma_wait_all();  // explicit: hipcc's automatic vmcnt wait for LDS-DMA is not reliable (gemm_nt.hpp)
     __syncthreads();     // tile `it` landed for everyone; everyone finished reading tile it-1 (the other buffer)
-    if (kv0 + 64 < len) stage_tile(kv0 + 64, buf ^ 1);
+    if (it >= 1 && kv0 + 64 < len) stage_tile(kv0 + 64, buf ^ 1);
+    if (it == 0) { CONVDR_ATT_TRACE(2) }
+    if (it == 1) { CONVDR_ATT_TRACE(3) }
     const char* sK = smem + buf * ATT_TILE_PAIR;
     const char* sV = sK + 64 * 128;
 
@@ -713,8 +731,8 @@ static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs 
     }
   }
 
+  CONVDR_ATT_TRACE(4)
   l += __shfl_xor(l, 32, 64);
-  const int plen = a.cu[b + 1] - (int)base;  // len rounded up to the row alignment
   if (q < plen) {
     // alignment rows [len, plen) get zeros: they feed later GEMMs / V^T columns and must stay finite
     const float inv = q < len ? 1.f / l : 0.f;
@@ -730,6 +748,7 @@ static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs 
       }
     if (a.lse && hi == 0) a.lse[(int64_t)h * a.ldt + base + q] = q < len ? m * a.scale + logf(l) : 0.f;
   }
+  CONVDR_ATT_TRACE(5)
 }
 
 // fp32 rows -> bf16 rows (weight packing at load / after each optimizer step)

@@ -9,6 +9,7 @@ namespace convdr {
 // experiment hook: when set (convdr_set_option "gemm_trace" = device pointer), FFN1 launches record phase stamps
 inline void* g_gemm_trace = nullptr;
 inline void* g_gemm_trace_ln = nullptr;
+inline void* g_attn_trace = nullptr;
 
 template <int EPI, class T>
 inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {

@@ -279,9 +279,12 @@ def _flat_view(tensors):
     return torch.as_strided(base, (n,), (1,), base.storage_offset())
 
 
-def clip_grad_norm_(parameters, max_norm):
+def clip_grad_norm_(parameters, max_norm, defer_to=None):
     """torch.nn.utils.clip_grad_norm_ (run_convdr_train.py:188-189) in one or a few kernels.  Returns the total
-    norm as a device scalar (no host sync)."""
+    norm as a device scalar (no host sync).
+    defer_to: an ``AdamW`` of this module.  When the gradients form one flat arena the clip coefficient is then only
+    computed and handed to the optimizer, whose update kernel multiplies it into the gradient on the fly -- one pass over
+    the 125 M gradients less; the stored gradients stay unscaled (train_step zeroes them right after the update)."""
     grads = [p.grad for p in parameters if p.grad is not None]
     if not grads:
         return torch.zeros(())
@@ -292,8 +295,11 @@ def clip_grad_norm_(parameters, max_norm):
     with torch.cuda.device(dev):
         flat = _flat_view(grads)
         if flat is not None:
+            defer = defer_to is not None and defer_to.can_flat_step()
             _lib.check(L.convdr_grad_norm_clip(_lib.ptr(flat), flat.numel(), float(max_norm), _lib.ptr(scratch), _lib.ptr(out),
-                                               1, _lib.stream_ptr()), "convdr_grad_norm_clip")
+                                               0 if defer else 1, _lib.stream_ptr()), "convdr_grad_norm_clip")
+            if defer:
+                defer_to._pending_grad_scale = out[1:2]
             return out[0]
         norms = torch.empty((len(grads), 2), dtype=torch.float32, device=dev)
         for i, g in enumerate(grads):
@@ -322,24 +328,40 @@ class AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
 
-    def _try_flat_step(self):
-        """One launch for the whole model when parameters live in a flat arena (flatten_parameters), the gradients are
-        the matching arena written by the backward, and all groups share their hyper-parameters."""
+    def _flat_operands(self):
+        """(params, P, G) when one launch can update the whole model: parameters in a flat arena (flatten_parameters),
+        gradients in the matching arena written by the backward, all groups sharing their hyper-parameters."""
         g0 = self.param_groups[0]
         keys = ("lr", "betas", "eps", "weight_decay", "correct_bias")
         if any(g[k] != g0[k] for g in self.param_groups for k in keys):
-            return False
+            return None
         ps = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
         if not ps:
-            return True
+            return ps, None, None
         P = _flat_view([p.data for p in ps])
         G = _flat_view([p.grad for p in ps])
         if P is None or G is None or P.numel() != G.numel():
-            return False
+            return None
         order_p = sorted(ps, key=lambda p: p.data.data_ptr())
         order_g = sorted(ps, key=lambda p: p.grad.data_ptr())
         if any(a is not b for a, b in zip(order_p, order_g)):
+            return None
+        return ps, P, G
+
+    def can_flat_step(self):
+        ops = self._flat_operands()
+        return ops is not None and ops[1] is not None
+
+    def _try_flat_step(self):
+        ops = self._flat_operands()
+        scale = self.__dict__.pop("_pending_grad_scale", None)
+        if ops is None:
+            assert scale is None, "a deferred clip coefficient needs the flat update path"
             return False
+        ps, P, G = ops
+        if not ps:
+            return True
+        g0 = self.param_groups[0]
         st = self.__dict__.setdefault("_flat_state", {})
         if "m" not in st or st["m"].numel() != P.numel():
             st["step"], st["m"], st["v"] = 0, torch.zeros_like(P), torch.zeros_like(P)
@@ -348,7 +370,8 @@ class AdamW(torch.optim.Optimizer):
         with torch.cuda.device(P.device):
             _lib.check(_lib.lib().convdr_adamw_step(_lib.ptr(P), _lib.ptr(G), _lib.ptr(st["m"]), _lib.ptr(st["v"]), P.numel(),
                                                     g0["lr"], b1, b2, g0["eps"], g0["weight_decay"], st["step"],
-                                                    int(g0["correct_bias"]), None, _lib.stream_ptr()), "convdr_adamw_step")
+                                                    int(g0["correct_bias"]), _lib.ptr(scale), _lib.stream_ptr()),
+                       "convdr_adamw_step")
         for p in ps:
             _bump_version(p)
         return True
@@ -400,6 +423,16 @@ def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_st
     return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda, last_epoch)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=None, doc_mask=None, ddp=None, doc_embs=None):
     """One iteration of the reference loop body (run_convdr_train.py:101-193) with pre-tokenised ranking documents
     (`doc_ids` / `doc_mask` int64 [B * (num_negatives + 1), Ld], positive first within each group).
@@ -407,9 +440,16 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
     concat_ids, concat_id_mask, target_ids, target_id_mask = batch
     model.train()
     teacher_model.eval()
-    embs = model(concat_ids, concat_id_mask)
-    with torch.no_grad():
+    # The frozen teacher's forward is independent of the student's and, at 64 x 64 tokens, fills barely a third of the
+    # CUs: it runs on a side stream under the student's forward and is joined before the loss needs it.
+    main = torch.cuda.current_stream()
+    side = _side_stream(concat_ids.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side), torch.no_grad():
         teacher_embs = teacher_model(target_ids, target_id_mask).detach()
+    embs = model(concat_ids, concat_id_mask)
+    main.wait_stream(side)
+    teacher_embs.record_stream(main)
     loss1 = None if getattr(args, "no_mse", False) else mse_loss(embs, teacher_embs)
     loss, loss2 = loss1, None
     if getattr(args, "ranking_task", False):
@@ -431,7 +471,7 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
     loss.backward()
     if ddp is not None:
         ddp.allreduce_grads()          # one all-reduce of the flat gradient arena (parallel.py)
-    clip_grad_norm_(list(model.parameters()), args.max_grad_norm)
+    clip_grad_norm_(list(model.parameters()), args.max_grad_norm, defer_to=optimizer if isinstance(optimizer, AdamW) else None)
     optimizer.step()
     scheduler.step()
     model.zero_grad()

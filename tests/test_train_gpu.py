@@ -177,8 +177,8 @@ def test_train_steps_match_reference_run(golden_dir):
     norms = []
     orig = TR.clip_grad_norm_
 
-    def spy(params, max_norm):
-        n = orig(params, max_norm)
+    def spy(params, max_norm, **kw):
+        n = orig(params, max_norm, **kw)
         norms.append(float(n))
         return n
     TR.clip_grad_norm_ = spy
