@@ -21,6 +21,7 @@ struct TrainBufs {
   float *cls_y, *cls_f, *head_y;
   // backward scratch
   float *G0, *G1, *Drow, *slab, *part, *dcls_y, *dcls_f, *dhead_y;
+  bf16_t *dYb2;   // second buffer for the LayerNorm-1 side, so the weight-gradient branch of LayerNorm 2's is not overwritten
   bf16_t *dYb, *dYt, *dHpre, *dHpre_t, *dctx, *dctx_t, *dQKV, *dQKVt, *actT, *dhead_yb, *dhead_yt, *cls_bt, *dclsb;
   int64_t ldt, Tp;
   size_t slab_elems;
@@ -78,6 +79,7 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
   p.dcls_f = (float*)take(Bp * H * 4);
   p.dhead_y = (float*)take(Bp * E * 4);
   p.dYb = (bf16_t*)take(rs * H * 2);
+  p.dYb2 = (bf16_t*)take(rs * H * 2);
   p.dYt = (bf16_t*)take((size_t)H * p.ldt * 2);
   p.dHpre = (bf16_t*)take(rs * I * 2);
   p.dHpre_t = (bf16_t*)take((size_t)I * p.ldt * 2);
@@ -92,6 +94,49 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
   p.dclsb = (bf16_t*)take(Bp * H * 2);
   p.total = o;
 }
+
+// The weight-gradient branch of every projection -- bias column sums, the two operand transposes, the split-K GEMM and
+// its reduction -- has no consumer before the optimizer, and at training batch sizes each of its kernels (like each
+// kernel of the activation-gradient chain) fills only part of the chip.  The backward therefore forks it onto a private
+// stream: WgradFork::fork(k) makes the side stream wait for what the main stream has enqueued so far, done(k) marks the
+// end of branch k, wait(k) makes the main stream wait for it (called before the main chain overwrites a buffer the
+// branch reads; branches run in order on the side stream, so waiting for k covers all earlier ones).  Its scratch
+// (dYt, dHpre_t, dQKVt, actT, slab, the bias part of `part`) is touched by the side stream only.  join() at the end.
+// Waiting on an event that was never recorded is a no-op, which is what the first layer needs.
+struct WgradFork {
+  hipStream_t main, side;
+  hipEvent_t prod[4], fin[4];
+  bool ok;
+  static WgradFork& get() {
+    static WgradFork f{};
+    return f;
+  }
+  int init(hipStream_t st) {
+    main = st;
+    if (!ok) {
+      CONVDR_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      for (int i = 0; i < 4; ++i) {
+        CONVDR_CHECK_HIP(hipEventCreateWithFlags(&prod[i], hipEventDisableTiming));
+        CONVDR_CHECK_HIP(hipEventCreateWithFlags(&fin[i], hipEventDisableTiming));
+      }
+      ok = true;
+    }
+    return 0;
+  }
+  int fork(int k) {
+    CONVDR_CHECK_HIP(hipEventRecord(prod[k], main));
+    CONVDR_CHECK_HIP(hipStreamWaitEvent(side, prod[k], 0));
+    return 0;
+  }
+  int done(int k) {
+    CONVDR_CHECK_HIP(hipEventRecord(fin[k], side));
+    return 0;
+  }
+  int wait(int k) {
+    CONVDR_CHECK_HIP(hipStreamWaitEvent(main, fin[k], 0));
+    return 0;
+  }
+};
 
 static int check_train_config(const convdr_encoder_config* c) {
   CONVDR_REQUIRE(c->hidden % 128 == 0 && c->hidden <= 1024 && c->heads * 64 == c->hidden,
@@ -294,6 +339,10 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
   hipLaunchKernelGGL(k_scatter_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, p.dcls_y, p.G0);
   CONVDR_CHECK_LAUNCH("k_scatter_cls");
 
+  WgradFork& wf = WgradFork::get();
+  static const bool fork_wgrad = !(getenv("CONVDR_NO_WGRAD_FORK") && atoi(getenv("CONVDR_NO_WGRAD_FORK")));
+  if (int e = wf.init(st)) return e;
+  hipStream_t ss = fork_wgrad ? wf.side : st;   // stream of the weight-gradient branches
   float* A = p.G0;   // holds the gradient flowing down the residual stream
   float* Bf = p.G1;  // scratch
   for (int l = NL - 1; l >= 0; --l) {
@@ -304,6 +353,8 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     const bool last = l == NL - 1;
     // A = d(pre-LN2 sum Y2) for the last layer (CLS rows only), d(layer output) otherwise
     float *dY2, *dX1, *dY1, *dXin;
+    if (fork_wgrad)
+      if (int e = wf.wait(0)) return e;   // branch 0 of the layer above has read dYb
     if (!last) {
       if (int e = ln_bwd(A, s.Y2, rows, H, lw->ln2_g, cfg->ln_eps, Bf, p.dYb, p, lg->ln2_g, lg->ln2_b, st)) return e;
       dY2 = Bf; dX1 = A; dY1 = Bf; dXin = A;
@@ -313,36 +364,54 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       dY2 = A; dX1 = Bf; dY1 = A; dXin = Bf;
     }
     // ---- FFN2: Y2 = Hm W2^T + b2 + X1 ----
-    if (int e = bias_grad(p.dYb, rows, H, p, lg->b2, st)) return e;
-    if (int e = transpose(p.dYb, rows, H, H, p.dYt, p.ldt, st)) return e;
-    if (int e = transpose(s.Hm, rows, I, I, p.actT, p.ldt, st)) return e;
-    if (int e = wgrad(p.dYt, H, p.actT, I, p.Tp, p.ldt, p, lg->w2, st)) return e;
+    if (fork_wgrad)
+      if (int e = wf.fork(0)) return e;
+    if (int e = bias_grad(p.dYb, rows, H, p, lg->b2, ss)) return e;
+    if (int e = transpose(p.dYb, rows, H, H, p.dYt, p.ldt, ss)) return e;
+    if (int e = transpose(s.Hm, rows, I, I, p.actT, p.ldt, ss)) return e;
+    if (int e = wgrad(p.dYt, H, p.actT, I, p.Tp, p.ldt, p, lg->w2, ss)) return e;
+    if (fork_wgrad) {
+      if (int e = wf.done(0)) return e;
+      if (int e = wf.wait(1)) return e;   // branch 1 of the layer above has read dHpre
+    }
     GemmArgs g{};
     g.rows = rows; g.W = (const bf16_t*)lt->w2_t; g.X = p.dYb; g.N = I; g.K = H; g.Cb = p.dHpre; g.R = s.Hpre;
     if (int e = launch_gemm<EPI_DGELU_BF16>(g, st, "gemm_dgrad")) return e;   // dHpre = (dY2 W2) * gelu'(Hpre)
     // ---- FFN1: Hpre = X1 W1^T + b1;  dX1 = dHpre W1 + dY2 (residual branch, fp32) ----
-    if (int e = bias_grad(p.dHpre, rows, I, p, lg->b1, st)) return e;
-    if (int e = transpose(p.dHpre, rows, I, I, p.dHpre_t, p.ldt, st)) return e;
-    if (int e = transpose(s.X1, rows, H, H, p.actT, p.ldt, st)) return e;
-    if (int e = wgrad(p.dHpre_t, I, p.actT, H, p.Tp, p.ldt, p, lg->w1, st)) return e;
+    if (fork_wgrad)
+      if (int e = wf.fork(1)) return e;
+    if (int e = bias_grad(p.dHpre, rows, I, p, lg->b1, ss)) return e;
+    if (int e = transpose(p.dHpre, rows, I, I, p.dHpre_t, p.ldt, ss)) return e;
+    if (int e = transpose(s.X1, rows, H, H, p.actT, p.ldt, ss)) return e;
+    if (int e = wgrad(p.dHpre_t, I, p.actT, H, p.Tp, p.ldt, p, lg->w1, ss)) return e;
+    if (fork_wgrad) {
+      if (int e = wf.done(1)) return e;
+      if (int e = wf.wait(2)) return e;   // branch 2 of the layer above has read dYb2
+    }
     g = GemmArgs{};
     g.rows = rows; g.W = (const bf16_t*)lt->w1_t; g.X = p.dHpre; g.N = H; g.K = I; g.Cf = dX1; g.Rf = dY2;
     if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_dgrad")) return e;
     // ---- LayerNorm1 ----
-    if (int e = ln_bwd(dX1, s.Y1, rows, H, lw->ln1_g, cfg->ln_eps, dY1, p.dYb, p, lg->ln1_g, lg->ln1_b, st)) return e;
+    if (int e = ln_bwd(dX1, s.Y1, rows, H, lw->ln1_g, cfg->ln_eps, dY1, p.dYb2, p, lg->ln1_g, lg->ln1_b, st)) return e;
     // ---- attention output projection: Y1 = ctx Wo^T + bo + Xin ----
-    if (int e = bias_grad(p.dYb, rows, H, p, lg->bo, st)) return e;
-    if (int e = transpose(p.dYb, rows, H, H, p.dYt, p.ldt, st)) return e;
-    if (int e = transpose(s.ctx, rows, H, H, p.actT, p.ldt, st)) return e;
-    if (int e = wgrad(p.dYt, H, p.actT, H, p.Tp, p.ldt, p, lg->wo, st)) return e;
+    if (fork_wgrad)
+      if (int e = wf.fork(2)) return e;
+    if (int e = bias_grad(p.dYb2, rows, H, p, lg->bo, ss)) return e;
+    if (int e = transpose(p.dYb2, rows, H, H, p.dYt, p.ldt, ss)) return e;
+    if (int e = transpose(s.ctx, rows, H, H, p.actT, p.ldt, ss)) return e;
+    if (int e = wgrad(p.dYt, H, p.actT, H, p.Tp, p.ldt, p, lg->wo, ss)) return e;
+    if (fork_wgrad)
+      if (int e = wf.done(2)) return e;
     g = GemmArgs{};
-    g.rows = rows; g.W = (const bf16_t*)lt->wo_t; g.X = p.dYb; g.N = H; g.K = H; g.Cb = p.dctx;
+    g.rows = rows; g.W = (const bf16_t*)lt->wo_t; g.X = p.dYb2; g.N = H; g.K = H; g.Cb = p.dctx;
     if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
     // ---- attention ----
     if (int e = transpose(p.dctx, rows, H, H, p.dctx_t, p.ldt, st)) return e;
     hipLaunchKernelGGL(k_attn_rowdot, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.dctx, s.ctx, rows, H, p.Drow,
                        p.ldt);
     CONVDR_CHECK_LAUNCH("k_attn_rowdot");
+    if (fork_wgrad)
+      if (int e = wf.wait(3)) return e;   // branch 3 of the layer above has read dQKV
     {
       AttnBwdArgs a{s.QKV, s.QKVt, p.dctx, p.dctx_t, s.LSE, p.Drow, p.ldt, cu_seqlens, seq_lens, H, p.dQKV, 0.125f};
       static bool attr_done = false;
@@ -358,15 +427,21 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       CONVDR_CHECK_LAUNCH("k_attention_bwd");
     }
     // ---- QKV projection: QKV = Xin Wqkv^T + bqkv;  dXin = dQKV Wqkv + dY1 (residual branch, fp32) ----
-    if (int e = bias_grad(p.dQKV, rows, 3 * H, p, lg->bqkv, st)) return e;
-    if (int e = transpose(p.dQKV, rows, 3 * H, 3 * H, p.dQKVt, p.ldt, st)) return e;
-    if (int e = transpose(s.Xin, rows, H, H, p.actT, p.ldt, st)) return e;
-    if (int e = wgrad(p.dQKVt, 3 * H, p.actT, H, p.Tp, p.ldt, p, lg->wqkv, st)) return e;
+    if (fork_wgrad)
+      if (int e = wf.fork(3)) return e;
+    if (int e = bias_grad(p.dQKV, rows, 3 * H, p, lg->bqkv, ss)) return e;
+    if (int e = transpose(p.dQKV, rows, 3 * H, 3 * H, p.dQKVt, p.ldt, ss)) return e;
+    if (int e = transpose(s.Xin, rows, H, H, p.actT, p.ldt, ss)) return e;
+    if (int e = wgrad(p.dQKVt, 3 * H, p.actT, H, p.Tp, p.ldt, p, lg->wqkv, ss)) return e;
+    if (fork_wgrad)
+      if (int e = wf.done(3)) return e;
     g = GemmArgs{};
     g.rows = rows; g.W = (const bf16_t*)lt->wqkv_t; g.X = p.dQKV; g.N = H; g.K = 3 * H; g.Cf = dXin; g.Rf = dY1;
     if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_dgrad")) return e;
     if (dXin != A) { float* t = A; A = Bf; Bf = t; }   // A again holds the stream gradient (now d Xin = d output of layer l-1)
   }
+  if (fork_wgrad)
+    if (int e = wf.wait(3)) return e;   // join: every weight gradient is complete for whatever follows on `stream`
   // ---- embeddings ----
   {
     const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
