@@ -154,6 +154,14 @@ class _EncoderFn(torch.autograd.Function):
                                                        _lib.ptr(cu), _lib.ptr(seq_lens), rows, max_len, _lib.ptr(ws),
                                                        ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
                        "convdr_encoder_train_forward")
+            # the transposed weight copies are needed by the backward only: pack them on the side stream, under this
+            # forward (0.6 ms of small transposes per step that would otherwise sit in front of the backward)
+            main = torch.cuda.current_stream()
+            side = _side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ctx.packed_t = _packed_t(tower, head)
+                ctx.packed_t_ready = side.record_event()
         ctx.tower, ctx.head = tower, head
         ctx.saved = (cu, seq_lens, B, rows, max_len, ws)
         ctx.shapes = [p.shape for p in params]
@@ -174,7 +182,8 @@ class _EncoderFn(torch.autograd.Function):
         nl = len(tower.encoder.layer)
         with torch.cuda.device(dev):
             c, w, _keep = tower.packed(head)
-            wt, head_t = _packed_t(tower, head)
+            torch.cuda.current_stream().wait_event(ctx.packed_t_ready)
+            wt, head_t = ctx.packed_t
             lg = (_lib.LayerGrads * nl)()
             for i in range(nl):
                 b = 5 + 16 * i
