@@ -89,7 +89,7 @@ class EncoderConfig(C.Structure):
 
 class LayerWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2",
-                                          "ln2_g", "ln2_b")]
+                                          "ln2_g", "ln2_b", "wo_ks", "w2_ks")]
 
 
 class EncoderWeights(C.Structure):
@@ -99,6 +99,7 @@ class EncoderWeights(C.Structure):
 
 
 register("convdr_cast_f32_bf16", C.c_int, [_p, _p, C.c_int64, _p])
+register("convdr_pack_kslice", C.c_int, [_p, C.c_int, C.c_int, _p, _p])
 register("convdr_encoder_workspace_bytes", C.c_size_t, [C.POINTER(EncoderConfig), C.c_int64, C.c_int])
 register("convdr_encoder_forward", C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), _p, C.c_int, _p, C.c_int,
                                              C.c_int, _p, _p, C.c_int64, C.c_int, _p, C.c_size_t, _p, _p])

@@ -49,9 +49,9 @@ static int64_t g_fused_ln_min_rows = 128 * 192;   // below this the 128-token ti
 
 // Y = A W^T + bias + R, X = LayerNorm(Y): fused row-complete kernel for hidden size 768 and enough rows to fill the
 // chip, else GEMM (fp32 sums) + LayerNorm kernel.  `Yf` is the fp32 scratch of the unfused path.
-static int gemm_resid_ln(const bf16_t* W, const bf16_t* A, int64_t rows, int H, int K, const float* bias, const bf16_t* R,
-                         const float* gamma, const float* beta, float eps, float* Yf, bf16_t* X, const char* name,
-                         hipStream_t st) {
+static int gemm_resid_ln(const bf16_t* W, const bf16_t* Wks, const bf16_t* A, int64_t rows, int H, int K, const float* bias,
+                         const bf16_t* R, const float* gamma, const float* beta, float eps, float* Yf, bf16_t* X,
+                         const char* name, hipStream_t st) {
   // measured at 262k rows: K = 768: 0.52 ms fused vs 0.49 + 0.19 ms (GEMM + LayerNorm); K = 3072: 1.33 vs 1.17 + 0.19 ms
   if (H == 768 && rows >= g_fused_ln_min_rows && K % LN_SLICE == 0 && K <= g_fused_ln_max_k) {
     static bool attr_done = false;
@@ -61,7 +61,7 @@ static int gemm_resid_ln(const bf16_t* W, const bf16_t* A, int64_t rows, int H, 
       attr_done = true;
     }
     GemmLnArgs a{W, A, rows, K, bias, R, gamma, beta, eps, X,
-                 K == 768 ? (unsigned long long*)g_gemm_trace_ln : nullptr};
+                 K == 768 ? (unsigned long long*)g_gemm_trace_ln : nullptr, Wks};
     ProfScope prof(name, st);
     hipLaunchKernelGGL(k_gemm_resid_ln, dim3((unsigned)ceil_div64(rows, TileLN::TL)), dim3(512), LN_SMEM_BYTES, st, a);
     CONVDR_CHECK_LAUNCH("k_gemm_resid_ln");
@@ -122,7 +122,7 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
     xin = p.cls_x; ctx = p.cls_ctx; x1 = p.cls_x1; n = B;
   }
   // attention output dense + residual + LayerNorm -> X1
-  if (int e = gemm_resid_ln((const bf16_t*)w->wo, ctx, n, H, H, w->bo, xin, w->ln1_g, w->ln1_b, c->ln_eps, p.Y, x1,
+  if (int e = gemm_resid_ln((const bf16_t*)w->wo, (const bf16_t*)w->wo_ks, ctx, n, H, H, w->bo, xin, w->ln1_g, w->ln1_b, c->ln_eps, p.Y, x1,
                             "gemm_attn_out", st))
     return e;
   // FFN
@@ -134,7 +134,7 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
     g2.rows = n; g2.W = (const bf16_t*)w->w2; g2.X = p.Hm; g2.N = H; g2.K = I; g2.bias = w->b2; g2.Cf = p.Y; g2.R = x1;
     return launch_gemm<EPI_RESID_F32>(g2, st, "gemm_ffn2");
   }
-  return gemm_resid_ln((const bf16_t*)w->w2, p.Hm, n, H, I, w->b2, x1, w->ln2_g, w->ln2_b, c->ln_eps, p.Y, p.X, "gemm_ffn2", st);
+  return gemm_resid_ln((const bf16_t*)w->w2, (const bf16_t*)w->w2_ks, p.Hm, n, H, I, w->b2, x1, w->ln2_g, w->ln2_b, c->ln_eps, p.Y, p.X, "gemm_ffn2", st);
 }
 
 }  // namespace convdr
@@ -213,6 +213,28 @@ extern "C" int convdr_encoder_debug_layout(const convdr_encoder_config* cfg, int
 }
 
 // Tuning / test knobs.  "fused_ln_min_rows": minimum packed rows for the fused GEMM + LayerNorm kernel.
+namespace convdr {
+// 16 bytes per thread: chunk c (8 elements) of row r in slice s
+static __global__ void __launch_bounds__(256) k_pack_kslice(const bf16_t* __restrict__ w, int n, int k, bf16_t* __restrict__ out) {
+  const int64_t total = (int64_t)n * (k / 8);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i & 3);
+    const int64_t sr = i >> 2;                 // s * n + r
+    const int r = (int)(sr % n), s = (int)(sr / n);
+    *(uint4*)(out + i * 8) = *(const uint4*)(w + (int64_t)r * k + s * 32 + c * 8);
+  }
+}
+}  // namespace convdr
+
+extern "C" int convdr_pack_kslice(const void* w_bf16, int n, int k, void* out, convdr_stream_t stream) {
+  CONVDR_REQUIRE(n > 0 && k > 0 && k % 32 == 0, "convdr_pack_kslice: bad shape %d x %d", n, k);
+  const int64_t total = (int64_t)n * (k / 8);
+  hipLaunchKernelGGL(k_pack_kslice, dim3((unsigned)(ceil_div64(total, 256) < 4096 ? ceil_div64(total, 256) : 4096)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)w_bf16, n, k, (bf16_t*)out);
+  CONVDR_CHECK_LAUNCH("k_pack_kslice");
+  return 0;
+}
+
 extern "C" int convdr_set_option(const char* name, int64_t value) {
   if (strcmp(name, "fused_ln_min_rows") == 0) {
     g_fused_ln_min_rows = value;

@@ -31,6 +31,7 @@ struct GemmLnArgs {
   float eps;
   bf16_t* X;            // out [rows, 768] (may alias R: a workgroup reads its residual rows before it writes them)
   unsigned long long* trace;   // experiment: [workgroup][16] s_memtime stamps of thread 0 (or null)
+  const bf16_t* Wks;    // W in K-slice-major order [K / 32][768][32] (or null: stream the row-major W)
 };
 #ifdef CONVDR_ENABLE_TRACE   // make TRACE=1: phase stamps for tools/gemm_trace_ln.py
 #define CONVDR_LN_TRACE(ph) \
@@ -63,7 +64,8 @@ __device__ __forceinline__ StageSrc ln_stage_src(const bf16_t* __restrict__ G, i
 }
 
 template <int ROWS>
-__device__ __forceinline__ void ln_stage32(const StageSrc& s, int ks, char* lds_tile, int wave) {
+__device__ __forceinline__ void ln_stage32(const StageSrc& s, int ks, char* lds_tile, int wave,
+                                           uint32_t slice_stride = LN_SLICE * 2) {
   if (LN_DMA_FIRST > 0 && wave < LN_DMA_FIRST) return;   // wave-uniform
   wave -= LN_DMA_FIRST;
   constexpr int ROUNDS = ROWS / (16 * LN_DMA_WAVES);
@@ -71,7 +73,7 @@ __device__ __forceinline__ void ln_stage32(const StageSrc& s, int ks, char* lds_
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds_tile + (i * LN_DMA_WAVES + wave) * 16 * 64), 16, s.voff,
-                                             i * s.round_pitch + ks * (LN_SLICE * 2), 0, 0);
+                                             i * s.round_pitch + ks * slice_stride, 0, 0);
 }
 
 __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
@@ -89,18 +91,36 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
   const int offR = (w.wr * T::MT * 32 + w.li) * 64;
   const int offL = (w.wl * T::NT * 32 + w.li) * 64;
 
-  const StageSrc srcW = ln_stage_src(a.W, a.K, 0, T::TR, w.wave, w.lane);
+  // Weights come from the K-slice-major copy when there is one: a 32-wide slice of the row-major [768, K] matrix is
+  // 768 half cache lines, every line is fetched twice (once per slice) and the 112 KB that leaves L2 per CU per step
+  // made this kernel L2-bandwidth-bound (5.2 k cycles per 1,536-cycle step); in slice-major order a slice is 48 KB of
+  // whole lines.
+  StageSrc srcW = a.Wks ? ln_stage_src(a.Wks, LN_SLICE, 0, (int64_t)T::TR * (a.K / LN_SLICE), w.wave, w.lane)
+                        : ln_stage_src(a.W, a.K, 0, T::TR, w.wave, w.lane);
+  const uint32_t w_slice_stride = a.Wks ? T::TR * LN_SLICE * 2 : LN_SLICE * 2;
   const StageSrc srcA = ln_stage_src(a.A, a.K, t0, a.rows, w.wave, w.lane);
-  ln_stage32<T::TR>(srcW, 0, sR, w.wave);
+  ln_stage32<T::TR>(srcW, 0, sR, w.wave, w_slice_stride);
   ln_stage32<T::TL>(srcA, 0, sL, w.wave);
+#ifdef CONVDR_ENABLE_TRACE   // per-wave stamps of K step 8 (and the top of step 9): a.trace[2048 * 16 + wg * 64 + wave * 8 + i]
+#define CONVDR_LN_STEP(i)                                                                                     \
+  if (a.trace && kt == 8 + (i) / 5 && w.lane == 0 && blockIdx.x < 256)                                        \
+    a.trace[2048 * 16 + blockIdx.x * 64 + w.wave * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define CONVDR_LN_STEP(i)
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
+    CONVDR_LN_STEP(5)
+    CONVDR_LN_STEP(0)
     lds_dma_wait_all();
+    CONVDR_LN_STEP(1)
     __syncthreads();
+    CONVDR_LN_STEP(2)
     if (kt + 1 < nk) {
-      ln_stage32<T::TR>(srcW, kt + 1, sR + (buf ^ 1) * LN_R_BYTES, w.wave);
+      ln_stage32<T::TR>(srcW, kt + 1, sR + (buf ^ 1) * LN_R_BYTES, w.wave, w_slice_stride);
       ln_stage32<T::TL>(srcA, kt + 1, sL + (buf ^ 1) * LN_L_BYTES, w.wave);
     }
+    CONVDR_LN_STEP(3)
     const char* tR = sR + buf * LN_R_BYTES + offR;
     const char* tL = sL + buf * LN_L_BYTES + offL;
 #pragma unroll
@@ -117,6 +137,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
         for (int j = 0; j < T::NT; ++j)
           acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc.c[i][j], 0, 0, 0);
     }
+    CONVDR_LN_STEP(4)
   }
 
   // ---------------- epilogue: + bias + residual, LayerNorm over the 768 features of each token ----------------

@@ -142,6 +142,11 @@ class _Encoder(nn.Module):
         self.layer = nn.ModuleList([_Layer(cfg) for _ in range(cfg.num_hidden_layers)])
 
 
+# packed rows from which the inference forward runs the fused projection + LayerNorm kernel (the library's
+# "fused_ln_min_rows" option; tests lower both to reach that kernel with small inputs)
+KSLICE_MIN_ROWS = 24576
+
+
 class EncoderTower(nn.Module):
     """Parameters of one BERT/RoBERTa tower under HF's names (embeddings.*, encoder.layer.N.*, pooler.dense.*)
     plus the packed bf16 device copies the kernels read."""
@@ -273,6 +278,25 @@ class EncoderTower(nn.Module):
                                out_dim=out_dim, ln_eps=cfg.layer_norm_eps, head_ln_eps=head_eps)
         return (c, w, [layers, P, Pb])
 
+    def _ensure_kslice(self, c, w, keep, rows, dev):
+        """K-slice-major copies of wo / w2 for the fused projection + LayerNorm kernel (convdr_layer_weights.wo_ks):
+        built lazily, once per packing, and only for the shapes that kernel serves (the training forward never
+        reads them, so a training step does not pay for them)."""
+        if c.hidden != 768 or rows < KSLICE_MIN_ROWS or c.layers == 0 or w.layers[0].wo_ks:
+            return
+        L_ = _lib.lib()
+        H, I = c.hidden, c.intermediate
+        buf = torch.empty(c.layers * (H * H + H * I), dtype=torch.bfloat16, device=dev)
+        o = 0
+        for i in range(c.layers):
+            lw = w.layers[i]
+            for src, k, field in ((lw.wo, H, "wo_ks"), (lw.w2, I, "w2_ks")):
+                dst = buf.data_ptr() + 2 * o
+                _lib.check(L_.convdr_pack_kslice(C.c_void_p(src), H, k, C.c_void_p(dst), _lib.stream_ptr()), "convdr_pack_kslice")
+                setattr(lw, field, dst)
+                o += H * k
+        keep.append(buf)
+
     # ---- forward ------------------------------------------------------------------------------
     def embed(self, input_ids, attention_mask, head=None, seq_lens=None):
         """-> fp32 [B, out_dim or H] embeddings (CLS pooling, models.py:43).
@@ -303,6 +327,7 @@ class EncoderTower(nn.Module):
         cu = torch.as_tensor(cu_host, device=dev)
         with torch.cuda.device(dev):
             c, w, _keep = self.packed(head)
+            self._ensure_kslice(c, w, _keep, rows, dev)
             out = torch.empty((B, c.out_dim or c.hidden), dtype=torch.float32, device=dev)
             need = L_.convdr_encoder_workspace_bytes(C.byref(c), rows, B)
             if self._ws is None or self._ws.numel() < need or self._ws.device != dev:

@@ -124,6 +124,12 @@ typedef struct {       /* device pointers; w* are bf16 [out, in] row-major (nn.L
   const void* w2;      /* output.dense.weight [H, I] */
   const float* b2;
   const float *ln2_g, *ln2_b; /* output.LayerNorm */
+  /* Optional (NULL = absent): wo / w2 again in K-slice-major order [in / 32][H][32] (convdr_pack_kslice), read by the
+   * fused projection + residual + LayerNorm kernel of the inference forward (hidden == 768, >= 24576 packed rows):
+   * a 32-wide K slice of all H output rows is then one contiguous 48 KB run of whole cache lines.  Ignored by the
+   * training entry points. */
+  const void* wo_ks;
+  const void* w2_ks;
 } convdr_layer_weights;
 
 typedef struct {
@@ -136,6 +142,10 @@ typedef struct {
 
 /* fp32 -> bf16 (round to nearest even); n % 4 == 0.  Used to pack weights at load time / after an optimizer step. */
 int convdr_cast_f32_bf16(const float* x, void* y, int64_t n, convdr_stream_t stream);
+
+/* bf16 [n, k] row-major -> K-slice-major bf16 [k / 32][n][32]  (out[(s * n + r) * 32 + c] = w[r * k + 32 s + c]);
+ * k % 32 == 0.  See convdr_layer_weights.wo_ks / w2_ks. */
+int convdr_pack_kslice(const void* w_bf16, int n, int k, void* out, convdr_stream_t stream);
 
 size_t convdr_encoder_workspace_bytes(const convdr_encoder_config* cfg, int64_t rows, int B);
 

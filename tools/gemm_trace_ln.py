@@ -19,12 +19,13 @@ tower, head = model.roberta, (model.embeddingHead, model.norm)
 with torch.no_grad():
     for _ in range(2):
         tower.embed(ids, None, head=head, seq_lens=lens)
-    buf = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(4096 * 16 + 256 * 64, dtype=torch.int64, device="cuda")
     _lib.check(_lib.lib().convdr_set_option(b"gemm_trace_ln", buf.data_ptr()), "set_option")
     tower.embed(ids, None, head=head, seq_lens=lens)
     torch.cuda.synchronize()
     _lib.lib().convdr_set_option(b"gemm_trace_ln", 0)
-t = buf.cpu().numpy().reshape(4096, 16).astype(np.float64)[:2048]
+raw = buf.cpu().numpy().astype(np.float64)
+t = raw[:4096 * 16].reshape(4096, 16)[:2048]
 names = ["mainloop", "barrier + stage LN params + barrier", "bias + residual + row sums", "barrier",
          "mean reduce + barrier + centred squares", "var reduce + 2 barriers", "normalise + store"]
 for i, n in enumerate(names[:7]):
@@ -36,3 +37,10 @@ for n, (i, j) in (("half 0: DMA issue", (2, 8)), ("half 0: DMA wait", (8, 9)), (
     print("%-42s median %8.0f cycles   p10 %8.0f  p90 %8.0f" % (n, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
 d = t[:, 7] - t[:, 0]
 print("%-42s median %8.0f cycles" % ("whole workgroup", np.median(d)))
+
+st = raw[2048 * 16:2048 * 16 + 256 * 64].reshape(256, 8, 8)
+print("per-wave K step (cycles, median over workgroups): wave | dma-wait | barrier | dma-issue | reads+mfma issue | step period")
+for wv in range(8):
+    r = st[st[:, wv, 5] > 0, wv]
+    print("  wave %d | %6.0f | %6.0f | %6.0f | %6.0f | %6.0f" % (wv, np.median(r[:, 1] - r[:, 0]), np.median(r[:, 2] - r[:, 1]),
+          np.median(r[:, 3] - r[:, 2]), np.median(r[:, 4] - r[:, 3]), np.median(r[:, 5] - r[:, 0])))
