@@ -18,7 +18,7 @@ namespace convdr {
 using TileLN = TileCfg<4, 2, 6, 2>;   // TR = 768 features, TL = 128 tokens
 constexpr int LN_SLICE = 32;
 constexpr int LN_R_BYTES = TileLN::TR * 64, LN_L_BYTES = TileLN::TL * 64;
-constexpr int LN_SMEM_BYTES = 2 * (LN_R_BYTES + LN_L_BYTES);   // 112 KB
+constexpr int LN_SMEM_BYTES = 3 * LN_R_BYTES + 2 * LN_L_BYTES;   // 160 KB: three weight slots + two activation slots
 
 struct GemmLnArgs {
   const bf16_t* W;      // [768, K]
@@ -76,13 +76,23 @@ __device__ __forceinline__ void ln_stage32(const StageSrc& s, int ks, char* lds_
                                              i * s.round_pitch + ks * slice_stride, 0, 0);
 }
 
+// one DMA instruction (round i) of ln_stage32
+template <int ROWS>
+__device__ __forceinline__ void ln_stage32_round(const StageSrc& s, int ks, char* lds_tile, int wave, int i,
+                                                 uint32_t slice_stride) {
+  if (LN_DMA_FIRST > 0 && wave < LN_DMA_FIRST) return;   // wave-uniform
+  wave -= LN_DMA_FIRST;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds_tile + (i * LN_DMA_WAVES + wave) * 16 * 64), 16, s.voff,
+                                           i * s.round_pitch + ks * slice_stride, 0, 0);
+}
+
 __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
   using T = TileLN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const WavePos<T> w;
   const int64_t t0 = (int64_t)blockIdx.x * T::TL;
-  char* sR = smem;
-  char* sL = smem + 2 * LN_R_BYTES;
+  char* sW = smem;                       // 3 weight slots
+  char* sA = smem + 3 * LN_R_BYTES;      // 2 activation slots
   GemmAcc<T> acc;
   acc.zero();
   CONVDR_LN_TRACE(0)
@@ -99,8 +109,15 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
                         : ln_stage_src(a.W, a.K, 0, T::TR, w.wave, w.lane);
   const uint32_t w_slice_stride = a.Wks ? T::TR * LN_SLICE * 2 : LN_SLICE * 2;
   const StageSrc srcA = ln_stage_src(a.A, a.K, t0, a.rows, w.wave, w.lane);
-  ln_stage32<T::TR>(srcW, 0, sR, w.wave, w_slice_stride);
-  ln_stage32<T::TL>(srcA, 0, sL, w.wave);
+  // Three weight slots, two activation slots: the weight slice of step t + 2 is issued at step t.  With one slice in
+  // flight (two stages) the stream was bound by bytes in flight / latency -- 56 KB per CU over a ~2 us loaded L2 round
+  // trip = 28 GB/s per CU, 4.5 k cycles per 1,536-cycle step -- so the 48 KB of LDS this kernel left unused buy a
+  // second weight slice in flight.  Issue order per step: A(t+1), then W(t+2); completion is in issue order, so
+  // "W(t), A(t) landed" = all but the newest weight group (LN_W_DPW instructions per issuing wave) retired.
+  constexpr int LN_W_DPW = T::TR / (16 * LN_DMA_WAVES);   // weight DMA instructions per issuing wave per slice
+  ln_stage32<T::TR>(srcW, 0, sW, w.wave, w_slice_stride);
+  ln_stage32<T::TL>(srcA, 0, sA, w.wave);
+  if (nk > 1) ln_stage32<T::TR>(srcW, 1, sW + LN_R_BYTES, w.wave, w_slice_stride);
 #ifdef CONVDR_ENABLE_TRACE   // per-wave stamps of K step 8 (and the top of step 9): a.trace[2048 * 16 + wg * 64 + wave * 8 + i]
 #define CONVDR_LN_STEP(i)                                                                                     \
   if (a.trace && kt == 8 + (i) / 5 && w.lane == 0 && blockIdx.x < 256)                                        \
@@ -108,21 +125,26 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
 #else
 #define CONVDR_LN_STEP(i)
 #endif
+  int wslot = 0;   // kt % 3
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
     CONVDR_LN_STEP(5)
     CONVDR_LN_STEP(0)
-    lds_dma_wait_all();
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LN_W_DPW) : "memory");
+    else lds_dma_wait_all();
     CONVDR_LN_STEP(1)
-    __syncthreads();
+    lds_barrier();   // NOT __syncthreads(): its fence would add vmcnt(0) and drain the slice that must stay in flight
     CONVDR_LN_STEP(2)
-    if (kt + 1 < nk) {
-      ln_stage32<T::TR>(srcW, kt + 1, sR + (buf ^ 1) * LN_R_BYTES, w.wave, w_slice_stride);
-      ln_stage32<T::TL>(srcA, kt + 1, sL + (buf ^ 1) * LN_L_BYTES, w.wave);
-    }
+    if (kt + 1 < nk) ln_stage32<T::TL>(srcA, kt + 1, sA + ((kt + 1) & 1) * LN_L_BYTES, w.wave);
+    // The 12 weight DMA instructions of slice t + 2 are issued one per MFMA pair below, not in a block here: an
+    // issuing wave stalls ~70 cycles on each, and in a block those ~950 cycles come before its first MFMA (the wave
+    // was the critical path of the step: 950 + 1,250 cycles); interleaved, its already-issued MFMAs run under the
+    // stalls.  (Only affordable with the slice two steps ahead: the later issue delays the landing.)
+    const bool issue_w = kt + 2 < nk;
+    char* w_dst = sW + (wslot == 0 ? 2 : wslot - 1) * LN_R_BYTES;   // slot (kt + 2) % 3
     CONVDR_LN_STEP(3)
-    const char* tR = sR + buf * LN_R_BYTES + offR;
-    const char* tL = sL + buf * LN_L_BYTES + offL;
+    const char* tR = sW + wslot * LN_R_BYTES + offR;
+    const char* tL = sA + (kt & 1) * LN_L_BYTES + offL;
+    wslot = wslot == 2 ? 0 : wslot + 1;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int ch = ((2 * s + w.hi) ^ sw) * 16;
@@ -132,10 +154,13 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
 #pragma unroll
       for (int i = 0; i < T::MT; ++i) fa[i] = *(const bf16x8*)(tR + i * 32 * 64 + ch);
 #pragma unroll
-      for (int i = 0; i < T::MT; ++i)
+      for (int i = 0; i < T::MT; ++i) {
 #pragma unroll
         for (int j = 0; j < T::NT; ++j)
           acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc.c[i][j], 0, 0, 0);
+        static_assert(2 * T::MT == LN_W_DPW, "one weight DMA instruction per MFMA pair");
+        if (issue_w) ln_stage32_round<T::TR>(srcW, kt + 2, w_dst, w.wave, s * T::MT + i, w_slice_stride);
+      }
     }
     CONVDR_LN_STEP(4)
   }
