@@ -103,6 +103,39 @@ def test_roberta_base_shape_matches_oracle():
     _check(emb2, ref2, "second call")
 
 
+def test_bench_size_batch_matches_oracle_on_a_sample():
+    """BASELINE configs[1] encode batch (2048 x 128 tokens = 262,144 packed rows: the persistent 256 x 256 tiles, the
+    fused projection + LayerNorm kernel with K-slice-major weights -- the kernels bench.py times).  The fp32 CPU oracle
+    re-computes a sample of the batch; and, as a size-independent property, an embedding must not depend on what else
+    is in the batch (same passages alone -> the small-batch kernels, 128 x 128 tiles and the unfused LayerNorm)."""
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    torch.manual_seed(1)
+    model = MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig())
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.02)
+            elif "LayerNorm.weight" in n or n == "norm.weight":
+                p.add_(torch.randn_like(p) * 0.05)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda().eval()
+    B, L = 2048, 128
+    g = torch.Generator(device="cuda").manual_seed(7)
+    ids = torch.randint(3, 50000, (B, L), generator=g, device="cuda", dtype=torch.int64)
+    ids[:, 0] = 0
+    mask = torch.ones_like(ids)
+    with torch.no_grad():
+        emb = model.body_emb(ids, mask)
+    assert emb.shape == (B, 768) and bool(torch.isfinite(emb).all())
+    sample = [0, 1, 777, 1024, 2046, 2047]           # first / last rows of the tile walk and two from the middle
+    ref = OE.rdot_nll_emb(sd, ids[sample].cpu(), mask[sample].cpu(), num_layers=12, num_heads=12).numpy()
+    _check(emb[sample], ref, "bench-size batch vs oracle")
+    with torch.no_grad():
+        alone = model.body_emb(ids[sample], mask[sample])
+    cs = cosine(emb[sample].cpu().numpy(), alone.cpu().numpy())
+    assert cs.min() > 1 - 1e-4, cs
+
+
 def test_corpus_encode_loop_matches_reference_blocks(golden_dir, tmp_path):
     """Token cache -> blocks, against the files the reference's own StreamInferenceDoc wrote."""
     import json
