@@ -42,7 +42,12 @@ struct GemmLnArgs {
 
 // 32-wide K slices: 64-byte LDS rows, 16 rows per wave per round, rounds 128 rows apart (so the swizzle term
 // (row >> 2) & 3 does not depend on the round).  Same buffer-descriptor addressing as gemm_nt.hpp's gemm_stage.
-constexpr int LN_DMA_WAVES = CONVDR_DMA_YOUNG_HALF ? 4 : 8;   // issuing waves (the younger half, see TileCfg::DMA_WAVES)
+#ifndef CONVDR_LN_DMA_LATE
+#define CONVDR_LN_DMA_LATE 1
+#endif
+// issuing waves: with the weight slice two steps ahead every wave issues its share AFTER its MFMAs (CONVDR_LN_DMA_LATE);
+// otherwise the younger half issues everything up front (TileCfg::DMA_WAVES)
+constexpr int LN_DMA_WAVES = (CONVDR_LN_DMA_LATE || !CONVDR_DMA_YOUNG_HALF) ? 8 : 4;
 constexpr int LN_DMA_FIRST = 8 - LN_DMA_WAVES;
 
 __device__ __forceinline__ StageSrc ln_stage_src(const bf16_t* __restrict__ G, int64_t ld, int64_t row0, int64_t nrows,
@@ -158,10 +163,18 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
 #pragma unroll
         for (int j = 0; j < T::NT; ++j)
           acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc.c[i][j], 0, 0, 0);
+#if !CONVDR_LN_DMA_LATE
         static_assert(2 * T::MT == LN_W_DPW, "one weight DMA instruction per MFMA pair");
         if (issue_w) ln_stage32_round<T::TR>(srcW, kt + 2, w_dst, w.wave, s * T::MT + i, w_slice_stride);
+#endif
       }
     }
+#if CONVDR_LN_DMA_LATE
+    // every wave issues its share of slice t + 2 once its MFMAs of this step are in the pipe: the ~60-cycle issue
+    // stalls then cost no matrix-pipe time (two steps of slack for the landing), and no wave has more DMA work than
+    // another
+    if (issue_w) ln_stage32<T::TR>(srcW, kt + 2, w_dst, w.wave, w_slice_stride);
+#endif
     CONVDR_LN_STEP(4)
   }
 
