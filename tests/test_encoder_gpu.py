@@ -240,6 +240,18 @@ def test_fused_gemm_layernorm_kernel_matches_oracle():
     assert cosine(a.cpu().numpy(), c.cpu().numpy()).min() > 1 - 1e-4
 
 
+def test_pack_kslice_layout():
+    """convdr_pack_kslice: out[(s * n + r) * 32 + c] == w[r, 32 s + c] (bit-exact copy, the layout k_gemm_resid_ln streams)."""
+    import ctypes as C
+    from convdr_amd import _lib
+    for n, k in ((768, 768), (768, 3072), (5, 64)):
+        w = torch.randn(n, k, device="cuda").to(torch.bfloat16).contiguous()
+        out = torch.empty(n * k, dtype=torch.bfloat16, device="cuda")
+        _lib.check(_lib.lib().convdr_pack_kslice(_lib.ptr(w), n, k, _lib.ptr(out), _lib.stream_ptr()), "convdr_pack_kslice")
+        ref = w.view(n, k // 32, 32).permute(1, 0, 2).contiguous().view(-1)
+        assert torch.equal(out, ref), (n, k)
+
+
 def test_multi_chunk_matches_reference_fixture(golden_dir):
     from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
     z = np.load(os.path.join(golden_dir, "encoder_rdot_nll.npz"))
