@@ -107,9 +107,11 @@ struct WgradFork {
   hipStream_t main, side;
   hipEvent_t prod[4], fin[4];
   bool ok;
-  static WgradFork& get() {
-    static WgradFork f{};
-    return f;
+  static WgradFork& get() {   // one per device (the side stream belongs to the device that is current at creation)
+    static WgradFork f[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    return f[dev];
   }
   int init(hipStream_t st) {
     main = st;
