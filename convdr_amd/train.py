@@ -468,10 +468,14 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
             # ranking file carries doc ids; looking them up replaces 10 x 512-token encodes per sample per step
             docs = doc_embs.view(bs, args.num_negatives + 1, -1)
         else:
+            # The reference encodes the B x (K + 1) documents 8 at a time (doc_batch_size = 8, :139 -- a memory
+            # measure for 16-32 GB GPUs).  Embeddings do not depend on the batching, and 8 x 512 tokens leave the chip
+            # two thirds idle (640 documents: 164 ms in eights, 68 ms in chunks of 64, tools/dbg/doc_enc.py).
+            step = int(getattr(args, "doc_batch_size", 128))
             outs = []
             with torch.no_grad():
-                for i in range(0, doc_ids.shape[0], 8):                       # doc_batch_size = 8 (:139)
-                    outs.append(teacher_model(doc_ids[i:i + 8], doc_mask[i:i + 8], is_query=False).detach())
+                for i in range(0, doc_ids.shape[0], step):
+                    outs.append(teacher_model(doc_ids[i:i + step], doc_mask[i:i + step], is_query=False).detach())
             docs = torch.cat(outs, 0).view(bs, args.num_negatives + 1, -1)
         loss2 = ranking_loss(embs, docs)
         loss = loss1 + loss2 if loss1 is not None else loss2
