@@ -485,6 +485,21 @@ extern "C" int convdr_rank_ce_fwd_bwd(const float* embs, const float* docs, int 
   return 0;
 }
 
+extern "C" int convdr_inbatch_ce_fwd_bwd(const float* embs, const float* docs, int B, int N, int E, const int32_t* pos,
+                                         float grad_scale, float* loss_per_query, float* d_embs, int accumulate,
+                                         convdr_stream_t stream) {
+  CONVDR_REQUIRE(B > 0 && N > 0 && N <= 16384 && E > 0, "convdr_inbatch_ce_fwd_bwd: bad sizes B=%d N=%d E=%d", B, N, E);
+  static bool attr_done = false;
+  if (!attr_done) {
+    CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_inbatch_ce_fwd_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_inbatch_ce_fwd_bwd, dim3(B), dim3(256), (size_t)N * 4, (hipStream_t)stream, embs, docs, B, N, E, pos,
+                     grad_scale, loss_per_query, d_embs, accumulate);
+  CONVDR_CHECK_LAUNCH("k_inbatch_ce_fwd_bwd");
+  return 0;
+}
+
 extern "C" int convdr_grad_norm_clip(float* grads, int64_t n, float max_norm, float* scratch /* >= 1024 floats */,
                                      float* norm_and_coef /* [2] */, int apply, convdr_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;

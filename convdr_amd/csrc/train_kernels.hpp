@@ -624,6 +624,62 @@ __global__ void __launch_bounds__(256) k_rank_ce_fwd_bwd(const float* __restrict
   }
 }
 
+// In-batch-negative ranking loss (BASELINE configs[4]; not in the reference -- oracle/train.py:inbatch_rank_loss is the
+// definition): every query scores ALL N gathered documents, the target is the index of its own positive.
+//   logits[n] = <e_b, docs[n]>,  loss_b = logsumexp(logits) - logits[pos_b],
+//   de_b = gscale / B * sum_n (softmax_n - [n == pos_b]) docs[n]
+// One workgroup per query; logits live in LDS (dynamic, N floats).  Summation orders are fixed (deterministic).
+__global__ void __launch_bounds__(256) k_inbatch_ce_fwd_bwd(const float* __restrict__ e, const float* __restrict__ docs,
+                                                            int B, int N, int E, const int32_t* __restrict__ pos,
+                                                            float gscale, float* __restrict__ loss_per_b,
+                                                            float* __restrict__ de, int accumulate) {
+  extern __shared__ float lg[];          // [N] logits, then probabilities
+  __shared__ float red[8];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* eb = e + (int64_t)b * E;
+  for (int n0 = wave * 4; n0 < N; n0 += 16) {   // four documents per wave per round: independent loads in flight
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = lane; i < E; i += 64) {
+      const float q = eb[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += q * docs[(int64_t)(n0 + j < N ? n0 + j : N - 1) * E + i];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float t = wave_sum(s[j]);
+      if (lane == 0 && n0 + j < N) lg[n0 + j] = t;
+    }
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int n = threadIdx.x; n < N; n += 256) mx = fmaxf(mx, lg[n]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float z = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) z += expf(lg[n] - mx);
+  z = wave_sum(z);
+  if (lane == 0) red[4 + wave] = z;
+  __syncthreads();
+  const float lz = logf((red[4] + red[5]) + (red[6] + red[7])) + mx;
+  const int p = pos[b];
+  if (threadIdx.x == 0) loss_per_b[b] = lz - lg[p];
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += 256) lg[n] = expf(lg[n] - lz) - (n == p ? 1.f : 0.f);
+  __syncthreads();
+  if (de) {
+    const float sc = gscale / (float)B;
+    for (int i = threadIdx.x; i < E; i += 256) {
+      float g = 0.f;
+#pragma unroll 8
+      for (int n = 0; n < N; ++n) g += lg[n] * docs[(int64_t)n * E + i];   // fixed order: deterministic
+      g *= sc;
+      de[(int64_t)b * E + i] = accumulate ? de[(int64_t)b * E + i] + g : g;
+    }
+  }
+}
+
 // sum of squares, two stages (deterministic): part[block]
 __global__ void __launch_bounds__(256) k_sumsq_partial(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
   __shared__ float red[4];

@@ -268,6 +268,48 @@ def ranking_loss(embs, pos_and_negs_embeddings):
     return _RankCE.apply(embs, pos_and_negs_embeddings.detach())
 
 
+class _InBatchCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, embs, docs_all, pos):
+        e32, d32 = embs.float().contiguous(), docs_all.float().contiguous()
+        B, (N, E) = e32.shape[0], d32.shape
+        p32 = pos.to(torch.int32).contiguous()
+        per = torch.empty(B, dtype=torch.float32, device=embs.device)
+        de = torch.empty_like(e32)
+        with torch.cuda.device(embs.device):
+            _lib.check(_lib.lib().convdr_inbatch_ce_fwd_bwd(_lib.ptr(e32), _lib.ptr(d32), B, N, E, _lib.ptr(p32), 1.0,
+                                                            _lib.ptr(per), _lib.ptr(de), 0, _lib.stream_ptr()),
+                       "convdr_inbatch_ce_fwd_bwd")
+        ctx.save_for_backward(de)
+        return per.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (de,) = ctx.saved_tensors
+        return de * g, None, None
+
+
+def gather_inbatch_docs(docs, group=None):
+    """docs [B, K, E] (this rank's teacher document embeddings, positive first) -> (docs_all [W * B * K, E] in rank
+    order, pos int64 [B] = row of each LOCAL query's positive inside docs_all).  One all-gather over the ranks
+    (RCCL on GPUs; 512 x 10 x 768 fp32 = 15.7 MB at the configs[4] size); identity on one process."""
+    from . import parallel
+    B, K, E = docs.shape
+    flat = docs.reshape(B * K, E).contiguous()
+    allv = parallel.all_gather_rows(flat, group)
+    import torch.distributed as dist
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    pos = rank * B * K + torch.arange(B, device=docs.device, dtype=torch.int64) * K
+    return allv, pos
+
+
+def ranking_loss_inbatch(embs, docs_all, pos):
+    """In-batch-negative ranking loss (BASELINE configs[4]; oracle/train.py:inbatch_rank_loss): CrossEntropy over the
+    scores of every gathered document, target = the query's own positive.  The mean is over the LOCAL queries; with the
+    gradient all-reduce averaging over ranks (DataParallelStudent) that is the global mean."""
+    return _InBatchCE.apply(embs, docs_all.detach(), pos)
+
+
 # --------------------------------------------------------------------------------------------
 # clip + optimizer + schedule
 # --------------------------------------------------------------------------------------------
@@ -477,7 +519,12 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
                 for i in range(0, doc_ids.shape[0], step):
                     outs.append(teacher_model(doc_ids[i:i + step], doc_mask[i:i + step], is_query=False).detach())
             docs = torch.cat(outs, 0).view(bs, args.num_negatives + 1, -1)
-        loss2 = ranking_loss(embs, docs)
+        if getattr(args, "in_batch_negatives", False):
+            # configs[4] variant, off by default (the reference scores a query against its own K + 1 documents only)
+            docs_all, pos = gather_inbatch_docs(docs, getattr(ddp, "group", None))
+            loss2 = ranking_loss_inbatch(embs, docs_all, pos)
+        else:
+            loss2 = ranking_loss(embs, docs)
         loss = loss1 + loss2 if loss1 is not None else loss2
     if getattr(args, "gradient_accumulation_steps", 1) > 1:
         loss = loss / args.gradient_accumulation_steps

@@ -224,6 +224,16 @@ int convdr_mse_fwd_bwd(const float* s, const float* t, int64_t n, float grad_sca
 int convdr_rank_ce_fwd_bwd(const float* embs, const float* docs, int B, int K, int E, float grad_scale,
                            float* loss_per_query, float* d_embs, int accumulate, convdr_stream_t stream);
 
+/* In-batch-negative form of the ranking loss (BASELINE configs[4]: the B x K teacher document embeddings of every rank
+ * are all-gathered; NOT in the reference, whose formula above stays the default -- defined by
+ * oracle/train.py:inbatch_rank_loss): logits[b, n] = <embs[b], docs[n]> over ALL N gathered documents,
+ * loss_per_query[b] = -log_softmax(logits[b])[pos[b]] with pos[b] the row of query b's own positive document;
+ * d_embs (nullable) (+)= grad_scale / B * sum_n (softmax - onehot(pos[b])) docs[n].  embs [B, E], docs [N, E] fp32,
+ * pos device int32 [B], N <= 16384. */
+int convdr_inbatch_ce_fwd_bwd(const float* embs, const float* docs, int B, int N, int E, const int32_t* pos,
+                              float grad_scale, float* loss_per_query, float* d_embs, int accumulate,
+                              convdr_stream_t stream);
+
 /* torch.nn.utils.clip_grad_norm_ over one flat fp32 gradient buffer: norm_and_coef[0] = ||g||_2,
  * norm_and_coef[1] = min(1, max_norm / (norm + 1e-6)); apply != 0 scales the gradients in place.
  * scratch: >= 1024 floats. */

@@ -55,3 +55,12 @@ def kd_losses(sd_student, sd_teacher, batch, *, num_layers, num_heads, docs=None
         logits = (embs.unsqueeze(1) * d).sum(-1)
         loss2 = F.cross_entropy(logits, torch.zeros(embs.shape[0], dtype=torch.long))
     return embs, loss1, loss2
+
+
+def inbatch_rank_loss(embs, docs_all, pos):
+    """In-batch-negative ranking loss -- NOT in the reference ("parity unpinned by the
+    reference"); this function is its definition for convdr_inbatch_ce_fwd_bwd.  It generalises
+    run_convdr_train.py:160-170 (logits = <q, own docs>, CrossEntropy against index 0) to logits over every document
+    gathered from all ranks, target = row of the query's own positive.  embs [B, E], docs_all [N, E], pos int64 [B]."""
+    logits = embs @ docs_all.t()
+    return F.cross_entropy(logits, pos.long())

@@ -89,3 +89,29 @@ def _gather_job(rank, world):
 def test_all_gather_rows_is_rank_ordered():
     for r in _run(_gather_job, 2, 29613):
         assert r == [0.0] * 3 + [1.0] * 3
+
+
+def _inbatch_job(rank, world):
+    """Every rank holds B queries and B x K teacher documents; the gathered matrix and the positive rows must be such
+    that the mean of the per-rank in-batch losses equals the loss of the whole batch on one process."""
+    from convdr_amd import train as TR
+    from oracle import train as OT
+    B, K, E = 3, 4, 16
+    g = torch.Generator().manual_seed(5)
+    embs_all = torch.randn(world * B, E, generator=g)
+    docs_full = torch.randn(world * B, K, E, generator=g)
+    docs_all, pos = TR.gather_inbatch_docs(docs_full[rank * B:(rank + 1) * B])
+    assert docs_all.shape == (world * B * K, E)
+    assert torch.equal(docs_all, docs_full.reshape(-1, E))                       # rank order
+    assert torch.equal(docs_all[pos], docs_full[rank * B:(rank + 1) * B, 0])     # own positives
+    local = OT.inbatch_rank_loss(embs_all[rank * B:(rank + 1) * B], docs_all, pos)
+    t = local.clone()
+    dist.all_reduce(t)
+    pos_global = torch.arange(world * B) * K
+    whole = OT.inbatch_rank_loss(embs_all, docs_full.reshape(-1, E), pos_global)
+    return float(t / world), float(whole)
+
+
+def test_inbatch_negative_gather_is_global_batch_loss():
+    for mean_of_ranks, whole in _run(_inbatch_job, port=29641):
+        assert abs(mean_of_ranks - whole) < 1e-5

@@ -298,3 +298,27 @@ def test_dpr_tower_backward_matches_autograd():
         elif n.startswith("ctx_model"):
             assert p.grad is None
     assert seen > 20
+
+
+def test_inbatch_negative_loss_matches_oracle():
+    """convdr_inbatch_ce_fwd_bwd (BASELINE configs[4] loss; defined by oracle/train.py:inbatch_rank_loss, the reference
+    has no such term): loss and d loss / d embs against torch autograd on CPU, at the per-GPU size of configs[4]
+    (64 queries x 5,120 gathered documents) and at small ragged sizes."""
+    from convdr_amd import train as TR
+    for B, N, E in ((64, 5120, 768), (3, 7, 64), (1, 1, 128)):
+        g = torch.Generator().manual_seed(B)
+        embs = torch.randn(B, E, generator=g)
+        docs = torch.randn(N, E, generator=g) * 0.3
+        pos = torch.randint(0, N, (B,), generator=g)
+        e_ref = embs.clone().requires_grad_(True)
+        ref = OT.inbatch_rank_loss(e_ref, docs, pos)
+        ref.backward()
+        e = embs.cuda().requires_grad_(True)
+        loss = TR.ranking_loss_inbatch(e, docs.cuda(), pos.cuda())
+        loss.backward()
+        assert abs(loss.item() - ref.item()) < 1e-4 * max(1.0, abs(ref.item())), (B, N, loss.item(), ref.item())
+        np.testing.assert_allclose(e.grad.cpu().numpy(), e_ref.grad.numpy(), rtol=2e-4, atol=2e-6)
+    # one-process gather: identity + positives at rows b * K
+    d3 = torch.randn(4, 3, 8).cuda()
+    allv, p = TR.gather_inbatch_docs(d3)
+    assert torch.equal(allv, d3.reshape(12, 8)) and p.tolist() == [0, 3, 6, 9]
