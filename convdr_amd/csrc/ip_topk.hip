@@ -109,6 +109,11 @@ __global__ void k_fill_f32(float* p, int n, float v) {
 // Grid: 1-D, nPt * nQt blocks, XCD-remapped so the nQt query tiles of one passage tile run
 // back-to-back on one XCD (the passage tile is fetched from HBM once, then hits that XCD's L2).
 // ------------------------------------------------------------------------------------------
+// One hit counter per 128-byte line.  The returning atomics that reserve candidate slots execute at the memory side and
+// serialise per LINE: with the counters packed 32 to a line, 1,000 queries shared 32 lines and the ~1.6 M reservations of
+// a 1 M-passage scan were 30 % of its time; one line per query spreads them over every channel.
+constexpr int IP_COUNT_STRIDE = 32;
+
 struct ScanArgs {
   const bf16_t* P;   // [n, d]
   const bf16_t* Qb;  // [nq_pad, d] (rows >= nq are zero)
@@ -119,7 +124,7 @@ struct ScanArgs {
   int nPt, nQt;      // tiles actually visited / query tiles
   int pt_stride;     // visited passage tile t -> tile t * pt_stride
   const float* tau;  // EMIT: [nq_pad]
-  uint32_t* counts;  // EMIT: [nq]
+  uint32_t* counts;  // EMIT: [nq_pad * IP_COUNT_STRIDE], counter of query q at q * IP_COUNT_STRIDE
   uint32_t* cand_id; // EMIT: [nq, cap]
   float* cand_s;     // EMIT: [nq, cap]
   int cap;
@@ -127,46 +132,64 @@ struct ScanArgs {
 };
 
 template <int MODE, class T>
-__global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan(const ScanArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const uint32_t logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int ts = logical / a.nQt, qt = logical - ts * a.nQt;
-  const int64_t m0 = (int64_t)ts * a.pt_stride * T::TR;
-  const int64_t n0 = (int64_t)qt * T::TL;
-
-  const WavePos<T> w;
-  GemmAcc<T> acc;
-  acc.zero();
-  gemm_nt_mainloop<T>(a.P, a.d, a.n, a.Qb, a.d, a.nq_pad, a.d, m0, n0, smem, acc, w);
-  if (a.Plo) {  // S~ = Ph Qh + Ph Ql + Pl Qh: fp32-class scores from three bf16 passes into the same accumulators
-    __syncthreads();
-    gemm_nt_mainloop<T>(a.P, a.d, a.n, a.Qlo, a.d, a.nq_pad, a.d, m0, n0, smem, acc, w);
-    __syncthreads();
-    gemm_nt_mainloop<T>(a.Plo, a.d, a.n, a.Qb, a.d, a.nq_pad, a.d, m0, n0, smem, acc, w);
-  }
-
+__device__ __forceinline__ void scan_epilogue(const ScanArgs& a, GemmAcc<T>& acc, const WavePos<T>& w, int ts, int64_t m0,
+                                              int64_t n0, const float (&tau_lane)[T::NT]) {
   if constexpr (MODE == IP_MODE_EMIT) {
+    // A lane owns one query per 32-column tile and MT*16 of the tile's passages.  It counts its hits, reserves that
+    // many slots of the query's candidate list with ONE atomic (a device-scope returning atomic is a ~1-2 us round
+    // trip to the memory side; one per hit -- ~100 per tile, serialised by the branches around them -- was 30 % of
+    // the scan), then writes the hits into consecutive slots.  The list order differs from run to run either way;
+    // k_ip_cut sorts it.
+    const int rows_left = (int)(a.n - m0 < (int64_t)T::TR ? a.n - m0 : (int64_t)T::TR);
+    if (rows_left < T::TR) {   // the last passage tile: rows past n scored 0 (zero-filled operand) and must never hit
+#pragma unroll
+      for (int nt = 0; nt < T::NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < T::MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (w.r_index(mt, r) >= rows_left) acc.c[mt][nt][r] = -INFINITY;
+    }
+    uint32_t cnt[T::NT], slot[T::NT];
+#pragma unroll
+    for (int nt = 0; nt < T::NT; ++nt) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int mt = 0; mt < T::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c += acc.c[mt][nt][r] >= tau_lane[nt] ? 1u : 0u;
+      cnt[nt] = c;
+    }
 #pragma unroll
     for (int nt = 0; nt < T::NT; ++nt) {
       const int q = (int)n0 + w.l_index(nt);
-      const float tau = q < a.nq ? a.tau[q] : INFINITY;
+      slot[nt] = cnt[nt] ? atomicAdd(&a.counts[(int64_t)q * IP_COUNT_STRIDE], cnt[nt]) : 0u;
+    }
+    // hipcc: retire the reservations HERE, once.  Left to the compiler, every hit below starts with s_waitcnt vmcnt(0)
+    // (the slot might still be pending on the path that skipped the previous hit), which on gfx9 also waits for the
+    // previous hit's STORES: a dozen serialised write round trips per wave per tile.
+#pragma unroll
+    for (int nt = 0; nt < T::NT; ++nt) asm volatile("" : "+v"(slot[nt]));
+#pragma unroll
+    for (int nt = 0; nt < T::NT; ++nt) {
+      if (cnt[nt] == 0) continue;
+      const int q = (int)n0 + w.l_index(nt);
+      const float tau = tau_lane[nt];
+      uint32_t* ids = a.cand_id + (int64_t)q * a.cap;
+      float* sc = a.cand_s + (int64_t)q * a.cap;
+      uint32_t sl = slot[nt];
+      const uint32_t row0 = (uint32_t)m0;
 #pragma unroll
       for (int mt = 0; mt < T::MT; ++mt) {
         const f32x16 v = acc.c[mt][nt];
-        float mx = v[0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, v[r]);
-        if (mx >= tau) {  // rare: ~rank_target hits per query in the whole block
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int64_t row = m0 + w.r_index(mt, r);
-            if (v[r] >= tau && row < a.n) {
-              const uint32_t slot = atomicAdd(&a.counts[q], 1u);
-              if (slot < (uint32_t)a.cap) {
-                a.cand_id[(int64_t)q * a.cap + slot] = (uint32_t)row;
-                a.cand_s[(int64_t)q * a.cap + slot] = v[r];
-              }
+        for (int r = 0; r < 16; ++r) {
+          if (v[r] >= tau) {
+            if (sl < (uint32_t)a.cap) {
+              ids[sl] = row0 + (uint32_t)w.r_index(mt, r);
+              sc[sl] = v[r];
             }
+            ++sl;
           }
         }
       }
@@ -205,28 +228,153 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan(const ScanArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// LDS bitonic sorts (block-wide)
-// ------------------------------------------------------------------------------------------
-__device__ void bitonic_desc_f32(float* s, int n) {
-  for (int k2 = 2; k2 <= n; k2 <<= 1)
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int p = i ^ j;
-        if (p > i) {
-          const float x = s[i], y = s[p];
-          const bool desc = (i & k2) == 0;
-          if (desc ? (x < y) : (x > y)) { s[i] = y; s[p] = x; }
-        }
-      }
-      __syncthreads();
+// Persistent: one workgroup per resident slot walks a strided sequence of tiles (XCD x owns a contiguous chunk of the
+// tile order, query tile fastest); the first K chunk of the next tile streams into the idle operand stage while the
+// epilogue of this one runs, so neither the workgroup dispatch gap nor the cold HBM round trip for a fresh passage
+// tile is exposed (they were ~40 % of a 12-step tile).
+template <int MODE, class T, bool X3>
+__global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan(const ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t ntiles = (uint32_t)a.nPt * (uint32_t)a.nQt;
+  const uint32_t xcd = blockIdx.x & 7u, q8 = ntiles >> 3, r8 = ntiles & 7u;
+  const uint32_t chunk_base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const uint32_t chunk_len = q8 + (xcd < r8 ? 1u : 0u);
+  const uint32_t stride = (gridDim.x + 7u) >> 3;
+  uint32_t idx = blockIdx.x >> 3;
+  if (idx >= chunk_len) return;
+  const WavePos<T> w;
+  auto coords = [&](uint32_t i, int& ts, int64_t& m0, int64_t& n0) {
+    const uint32_t logical = chunk_base + i;
+    ts = (int)(logical / a.nQt);
+    const int qt = (int)(logical - (uint32_t)ts * a.nQt);
+    m0 = (int64_t)ts * a.pt_stride * T::TR;
+    n0 = (int64_t)qt * T::TL;
+  };
+  int ts;
+  int64_t m0, n0;
+  coords(idx, ts, m0, n0);
+  TileSrc<T> src(a.P, a.d, a.n, a.Qb, a.d, a.nq_pad, m0, n0, w);
+  int buf = 0;
+  gemm_issue_stage<T>(src, 0, smem + buf * T::STAGE_BYTES, w);
+  // A tile's thresholds are loaded one tile ahead (loop-carried, so the load cannot be sunk to its use after the main
+  // loop, where its full latency would be exposed) and are retired by the main loop's own waits; an ordinary load used
+  // while the next tile's LDS-DMA is in flight would drain that too.
+  float tau_next[T::NT];
+  auto load_tau = [&](int64_t n0_) {
+#pragma unroll
+    for (int nt = 0; nt < T::NT; ++nt) {
+      const int q = (int)n0_ + w.l_index(nt);
+      tau_next[nt] = (MODE == IP_MODE_EMIT && q < a.nq) ? a.tau[q] : INFINITY;
     }
+  };
+  load_tau(n0);
+  for (;;) {
+    GemmAcc<T> acc;
+    acc.zero();
+    float tau_lane[T::NT];
+#pragma unroll
+    for (int nt = 0; nt < T::NT; ++nt) tau_lane[nt] = tau_next[nt];
+    int idle = gemm_nt_mainloop<T>(src, a.d, smem, acc, w, buf, true);
+    if constexpr (X3) {  // S~ = Ph Qh + Ph Ql + Pl Qh: fp32-class scores from three bf16 passes into the same accumulators
+      __syncthreads();
+      const TileSrc<T> s2(a.P, a.d, a.n, a.Qlo, a.d, a.nq_pad, m0, n0, w);
+      idle = gemm_nt_mainloop<T>(s2, a.d, smem, acc, w, idle);
+      __syncthreads();
+      const TileSrc<T> s3(a.Plo, a.d, a.n, a.Qb, a.d, a.nq_pad, m0, n0, w);
+      idle = gemm_nt_mainloop<T>(s3, a.d, smem, acc, w, idle);
+    }
+#pragma unroll
+    for (int nt = 0; nt < T::NT; ++nt) asm volatile("" : "+v"(tau_lane[nt]));   // hipcc: the loads are retired HERE
+    const uint32_t next = idx + stride;
+    const bool has_next = next < chunk_len;
+    const int ts_cur = ts;
+    const int64_t m0_cur = m0, n0_cur = n0;
+    if (has_next) {
+      coords(next, ts, m0, n0);
+      load_tau(n0);
+      src = TileSrc<T>(a.P, a.d, a.n, a.Qb, a.d, a.nq_pad, m0, n0, w);
+      gemm_issue_stage<T>(src, 0, smem + idle * T::STAGE_BYTES, w);
+    }
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));   // opaque: the epilogue's lane-dependent addresses stay out of the main loop's registers
+    const WavePos<T> we(tid_e);
+    scan_epilogue<MODE, T>(a, acc, we, ts_cur, m0_cur, n0_cur, tau_lane);
+    if (!has_next) break;
+    idx = next;
+    buf = idle;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Block-wide order statistics in LDS.  The search needs three of them per query -- the r-th largest sample score (the
+// threshold), the k-th largest candidate score (the band cut) and the k best re-scored candidates -- and none needs
+// the whole list ordered: an MSB-first radix select (one 256-bin histogram per key byte) finds the k-th largest key
+// in a handful of barriers where the full bitonic sorts these replaced took 55-78 barrier-separated stages.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f32_order_key(float f) {   // a > b  <=>  key(a) > key(b)   (-0 orders below +0)
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_order_key(uint32_t key) {
+  return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+}
+__device__ __forceinline__ uint64_t f64_order_key(double f) {
+  const uint64_t u = (uint64_t)__double_as_longlong(f);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+struct SelectScratch {   // static LDS of a selecting kernel
+  uint32_t hist[256];
+  uint32_t wave_sum[4];
+  uint32_t bin, rem;
+};
+
+// kth-largest (kth = 1: the maximum; 1 <= kth <= c) of key_at(0..c-1); NBITS = significant key bits (32 or 64).
+// Every thread returns the key.  blockDim.x >= 256.
+template <int NBITS, class KeyAt>
+__device__ uint64_t block_kth_largest(KeyAt key_at, int c, uint32_t kth, SelectScratch& sc) {
+  uint64_t prefix = 0, mask = 0;
+  uint32_t rem = kth;
+  for (int shift = NBITS - 8; shift >= 0; shift -= 8) {
+    if (threadIdx.x < 256) sc.hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += blockDim.x) {
+      const uint64_t x = key_at(i);
+      if ((x & mask) == prefix) atomicAdd(&sc.hist[(uint32_t)(x >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    // the bin holding the rem-th largest of the keys that match the prefix: suffix sums of the histogram, one bin
+    // per thread of the first four waves (shuffle scan inside a wave, the four wave totals through LDS)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t here = 0, incl = 0;
+    if (threadIdx.x < 256) {
+      here = incl = sc.hist[threadIdx.x];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_down(incl, o, 64);
+        if (lane + o < 64) incl += v;
+      }
+      if (lane == 0) sc.wave_sum[wave] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      uint32_t above = incl - here;
+      for (int v = wave + 1; v < 4; ++v) above += sc.wave_sum[v];
+      if (above < rem && rem <= above + here) { sc.bin = threadIdx.x; sc.rem = rem - above; }
+    }
+    __syncthreads();
+    prefix |= (uint64_t)sc.bin << shift;
+    mask |= (uint64_t)255 << shift;
+    rem = sc.rem;
+  }
+  return prefix;
 }
 
 __device__ __forceinline__ bool cand_before(double sa, uint32_t ia, double sb, uint32_t ib) {
   return sa > sb || (sa == sb && ia < ib);
 }
 
+// LDS bitonic sort by (score desc, index asc); n a power of two
 __device__ void bitonic_cand(double* s, uint32_t* id, int n) {
   for (int k2 = 2; k2 <= n; k2 <<= 1)
     for (int j = k2 >> 1; j > 0; j >>= 1) {
@@ -245,15 +393,20 @@ __device__ void bitonic_cand(double* s, uint32_t* id, int n) {
 }
 
 // tau[q] = r-th largest of T[0..nvals) for query q (column q of T, leading dim nq_pad)
-__global__ void __launch_bounds__(1024) k_tau_select(const float* __restrict__ T, int64_t nvals, int nq_pad,
-                                                     int npow2, int r, float* __restrict__ tau) {
+__global__ void __launch_bounds__(1024) k_tau_select(const float* __restrict__ T, int64_t nvals, int nq_pad, int r,
+                                                     float* __restrict__ tau) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s = (float*)smem;
+  __shared__ SelectScratch sc;
+  uint32_t* key = (uint32_t*)smem;
   const int q = blockIdx.x;
-  for (int i = threadIdx.x; i < npow2; i += blockDim.x) s[i] = i < nvals ? T[(int64_t)i * nq_pad + q] : -INFINITY;
+  for (int i = threadIdx.x; i < nvals; i += blockDim.x) key[i] = f32_order_key(T[(int64_t)i * nq_pad + q]);
   __syncthreads();
-  bitonic_desc_f32(s, npow2);
-  if (threadIdx.x == 0) tau[q] = (r >= 1 && r <= nvals) ? s[r - 1] : -INFINITY;
+  if (r < 1 || r > nvals) {
+    if (threadIdx.x == 0) tau[q] = -INFINITY;
+    return;
+  }
+  const uint32_t kk = (uint32_t)block_kth_largest<32>([&](int i) { return (uint64_t)key[i]; }, (int)nvals, (uint32_t)r, sc);
+  if (threadIdx.x == 0) tau[q] = f32_from_order_key(kk);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -265,54 +418,46 @@ __global__ void __launch_bounds__(1024) k_tau_select(const float* __restrict__ T
 // {s~ >= cut} yields the exact top-k, PROVIDED the candidate list is complete down to cut, i.e.
 // cut >= tau and the list did not overflow.  Otherwise the query is flagged for a retry with a
 // threshold that makes the next pass complete.
-// Sorts the query's candidates by (s~ desc, index asc) in place and writes m[q] = band size.
+// Moves the band to the front of the query's candidate list (in no particular order: k_ip_select orders the
+// re-scored band by (exact score, index), which does not depend on it) and writes m[q] = band size.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ip_cut(int64_t n, int k, int cap, const uint32_t* __restrict__ counts,
+__global__ void __launch_bounds__(1024) k_ip_cut(int64_t n, int k, int cap, const uint32_t* __restrict__ counts,
+                                                uint32_t* __restrict__ counts_packed,
                                                 uint32_t* __restrict__ cand_id, float* __restrict__ cand_s,
                                                 const float* __restrict__ tau, const float* __restrict__ qnorm,
                                                 const float* __restrict__ p_max_norm, float eps_coef,
                                                 uint32_t* __restrict__ m_out, int32_t* __restrict__ status,
                                                 float* __restrict__ tau_retry) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int sh_m;
+  __shared__ SelectScratch sc;
+  __shared__ uint32_t sh_m;
   const int q = blockIdx.x;
-  const uint32_t cnt = counts[q];
+  const uint32_t cnt = counts[(int64_t)q * IP_COUNT_STRIDE];
+  if (threadIdx.x == 0) counts_packed[q] = cnt;   // [nq] copy for convdr_ip_debug_counts
   const int c = cnt < (uint32_t)cap ? (int)cnt : cap;
-  int np2 = 2;
-  while (np2 < c) np2 <<= 1;
-  float* s = (float*)smem;
-  uint32_t* id = (uint32_t*)(smem + (size_t)np2 * 4);
-  for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-    s[i] = i < c ? cand_s[(int64_t)q * cap + i] : -INFINITY;
-    id[i] = i < c ? cand_id[(int64_t)q * cap + i] : 0xffffffffu;
+  uint32_t* key = (uint32_t*)smem;
+  uint32_t* id = (uint32_t*)(smem + (size_t)cap * 4);
+  for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    key[i] = f32_order_key(cand_s[(int64_t)q * cap + i]);
+    id[i] = cand_id[(int64_t)q * cap + i];
   }
   if (threadIdx.x == 0) sh_m = 0;
   __syncthreads();
-  for (int k2 = 2; k2 <= np2; k2 <<= 1)
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-        const int p = i ^ j;
-        if (p > i) {
-          const float x = s[i], y = s[p];
-          const uint32_t ix = id[i], iy = id[p];
-          const bool fwd = (i & k2) == 0;
-          const bool y_first = y > x || (y == x && iy < ix);
-          const bool x_first = x > y || (x == y && ix < iy);
-          if (fwd ? y_first : x_first) { s[i] = y; s[p] = x; id[i] = iy; id[p] = ix; }
-        }
-      }
-      __syncthreads();
-    }
   const int need = (int64_t)k < n ? k : (int)n;
   const float t = tau[q];
   const float eps = eps_coef * qnorm[q] * p_max_norm[0] * 1.001f + 1e-30f;
   const bool have_k = need > 0 && c >= need;
-  const float cut = have_k ? s[need - 1] - 2.f * eps : -INFINITY;
-  for (int i = threadIdx.x; i < c; i += blockDim.x)
-    if (s[i] >= cut && (i + 1 == c || !(s[i + 1] >= cut))) sh_m = i + 1;
+  float cut = -INFINITY;
+  if (have_k)
+    cut = f32_from_order_key((uint32_t)block_kth_largest<32>([&](int i) { return (uint64_t)key[i]; }, c, (uint32_t)need, sc)) -
+          2.f * eps;
   for (int i = threadIdx.x; i < c; i += blockDim.x) {
-    cand_id[(int64_t)q * cap + i] = id[i];
-    cand_s[(int64_t)q * cap + i] = s[i];
+    const float v = f32_from_order_key(key[i]);
+    if (v >= cut) {
+      const uint32_t slot = atomicAdd(&sh_m, 1u);
+      cand_id[(int64_t)q * cap + slot] = id[i];
+      cand_s[(int64_t)q * cap + slot] = v;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -331,7 +476,7 @@ __global__ void __launch_bounds__(256) k_ip_cut(int64_t n, int k, int cap, const
       st = CONVDR_IP_UNCERTAIN;  // band reaches below tau: list incomplete in [cut, tau)
       retry = nextafterf(cut, -INFINITY);
     }
-    m_out[q] = (uint32_t)sh_m;
+    m_out[q] = sh_m;
     status[q] = st;
     tau_retry[q] = retry;
   }
@@ -367,28 +512,66 @@ __global__ void __launch_bounds__(256) k_ip_rescore(const float* __restrict__ Q,
 }
 
 // ------------------------------------------------------------------------------------------
-// per-query final sort of the re-scored band by (exact score desc, index asc) -> top-k
+// per-query top-k of the re-scored band by (exact score desc, index asc): select the k-th largest exact score, keep
+// the candidates at or above it (more than k only when scores tie exactly at the boundary -- duplicate passages), and
+// sort just those.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ip_select(int k, int cap, const uint32_t* __restrict__ m_in,
-                                                   const uint32_t* __restrict__ cand_id,
-                                                   const double* __restrict__ cand_x, float* __restrict__ D,
-                                                   int64_t* __restrict__ I) {
+constexpr int IP_SELECT_THREADS = 1024;
+constexpr int IP_SELECT_PER_THREAD = 8192 / IP_SELECT_THREADS;   // cap <= 8192
+__global__ void __launch_bounds__(IP_SELECT_THREADS) k_ip_select(int k, int cap, const uint32_t* __restrict__ m_in,
+                                                                 const uint32_t* __restrict__ cand_id,
+                                                                 const double* __restrict__ cand_x,
+                                                                 float* __restrict__ D, int64_t* __restrict__ I) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ SelectScratch sc;
+  __shared__ uint32_t sh_g;
   const int q = blockIdx.x;
   const int c = (int)m_in[q];
-  int np2 = 2;
-  while (np2 < c) np2 <<= 1;
   double* s = (double*)smem;
-  uint32_t* id = (uint32_t*)(smem + (size_t)np2 * 8);
-  for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-    s[i] = i < c ? cand_x[(int64_t)q * cap + i] : -INFINITY;
-    id[i] = i < c ? cand_id[(int64_t)q * cap + i] : 0xffffffffu;
+  uint32_t* id = (uint32_t*)(smem + (size_t)cap * 8);
+  for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    s[i] = cand_x[(int64_t)q * cap + i];
+    id[i] = cand_id[(int64_t)q * cap + i];
   }
+  if (threadIdx.x == 0) sh_g = 0;
+  __syncthreads();
+  int g = c;
+  if (c > k) {
+    // Select on the high 32 key bits only (sign, exponent, 20 mantissa bits): a candidate whose high word is below the
+    // k-th largest high word is below at least k candidates in the full order too, so the top k all survive; the few
+    // extra survivors that share the boundary word are ordered exactly by the sort.
+    const uint64_t kth =
+        block_kth_largest<32>([&](int i) { return f64_order_key(s[i]) >> 32; }, c, (uint32_t)k, sc);
+    // compact {high word >= kth} to the front: every thread lifts its elements into registers first
+    double ms[IP_SELECT_PER_THREAD];
+    uint32_t mi[IP_SELECT_PER_THREAD];
+#pragma unroll
+    for (int e = 0; e < IP_SELECT_PER_THREAD; ++e) {
+      const int i = threadIdx.x + e * IP_SELECT_THREADS;
+      ms[e] = i < c ? s[i] : 0.0;
+      mi[e] = i < c ? id[i] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < IP_SELECT_PER_THREAD; ++e) {
+      const int i = threadIdx.x + e * IP_SELECT_THREADS;
+      if (i < c && (f64_order_key(ms[e]) >> 32) >= kth) {
+        const uint32_t slot = atomicAdd(&sh_g, 1u);
+        s[slot] = ms[e];
+        id[slot] = mi[e];
+      }
+    }
+    __syncthreads();
+    g = (int)sh_g;
+  }
+  int np2 = 2;
+  while (np2 < g) np2 <<= 1;
+  for (int i = g + threadIdx.x; i < np2; i += blockDim.x) { s[i] = -INFINITY; id[i] = 0xffffffffu; }
   __syncthreads();
   bitonic_cand(s, id, np2);
   for (int j = threadIdx.x; j < k; j += blockDim.x) {
-    D[(int64_t)q * k + j] = j < c ? (float)s[j] : -FLT_MAX;
-    I[(int64_t)q * k + j] = j < c ? (int64_t)id[j] : -1;
+    D[(int64_t)q * k + j] = j < g ? (float)s[j] : -FLT_MAX;
+    I[(int64_t)q * k + j] = j < g ? (int64_t)id[j] : -1;
   }
 }
 
@@ -403,12 +586,13 @@ struct IpPlan {
   int nSt, stride;   // sampled passage tiles / tile stride
   int64_t nvals;     // values per query handed to k_tau_select
   int npow2;
-  size_t o_qb, o_qlo, o_qnorm, o_tau, o_counts, o_m, o_T, o_id, o_s, o_x, total;
+  size_t o_qb, o_qlo, o_qnorm, o_tau, o_counts, o_counts_packed, o_m, o_T, o_id, o_s, o_x, total;
 };
 
 static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
   IpPlan p;
-  p.big = nq > 128;
+  static const bool dbg_small = getenv("CONVDR_DBG_SCAN_TILE128") != nullptr;
+  p.big = nq > 128 && !dbg_small;
   p.tr = p.big ? Tile256::TR : Tile128::TR;
   p.tl = p.big ? Tile256::TL : Tile128::TL;
   p.nq_pad = (nq + p.tl - 1) / p.tl * p.tl;
@@ -436,7 +620,8 @@ static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
   p.o_qlo = take((size_t)p.nq_pad * d * 2);
   p.o_qnorm = take((size_t)p.nq_pad * 4);
   p.o_tau = take((size_t)p.nq_pad * 4);
-  p.o_counts = take((size_t)p.nq_pad * 4);
+  p.o_counts = take((size_t)p.nq_pad * IP_COUNT_STRIDE * 4);
+  p.o_counts_packed = take((size_t)p.nq_pad * 4);
   p.o_m = take((size_t)p.nq_pad * 4);
   const size_t t_rows = p.mode == IP_MODE_FULL ? (size_t)p.nPt * p.tr : (size_t)p.nvals;
   p.o_T = take(t_rows * p.nq_pad * 4);
@@ -448,19 +633,30 @@ static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
   return p;
 }
 
-template <int MODE, class T>
-static int launch_scan_t(const ScanArgs& a, hipStream_t st) {
+template <int MODE, class T, bool X3>
+static int launch_scan_x(const ScanArgs& a, hipStream_t st) {
   static bool attr_done = false;  // > 48 KB dynamic LDS needs the opt-in once per kernel
   if (!attr_done) {
-    CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_scan<MODE, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_scan<MODE, T, X3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          T::SMEM_BYTES));
     attr_done = true;
   }
-  const unsigned grid = (unsigned)a.nPt * (unsigned)a.nQt;
+  const unsigned tiles = (unsigned)a.nPt * (unsigned)a.nQt;
+  static const bool one_tile_per_wg = getenv("CONVDR_DBG_SCAN_NONPERSISTENT") != nullptr;   // A/B switch for the walk
+  const unsigned slots = (unsigned)device_cu_count() * (T::SMEM_BYTES > 80 * 1024 ? 1u : 2u);
+  const unsigned grid = one_tile_per_wg ? tiles : std::min(tiles, slots);
   ProfScope prof(MODE == IP_MODE_EMIT ? "ip_scan_emit" : "ip_scan_sample", st);
-  hipLaunchKernelGGL((k_ip_scan<MODE, T>), dim3(grid), dim3(T::THREADS), T::SMEM_BYTES, st, a);
+  ScanArgs b = a;
+  static const bool no_emit = getenv("CONVDR_DBG_SCAN_NOEMIT") != nullptr;   // timing only: every threshold = +inf
+  if (no_emit) b.nq = 0;
+  hipLaunchKernelGGL((k_ip_scan<MODE, T, X3>), dim3(grid), dim3(T::THREADS), T::SMEM_BYTES, st, b);
   CONVDR_CHECK_LAUNCH("k_ip_scan");
   return 0;
+}
+
+template <int MODE, class T>
+static int launch_scan_t(const ScanArgs& a, hipStream_t st) {
+  return a.Plo ? launch_scan_x<MODE, T, true>(a, st) : launch_scan_x<MODE, T, false>(a, st);
 }
 
 template <int MODE>
@@ -551,7 +747,7 @@ extern "C" size_t convdr_ip_workspace_bytes(int nq, int64_t n, int d, int k, int
 }
 
 extern "C" const uint32_t* convdr_ip_debug_counts(const void* workspace, int nq, int64_t n, int d, int k, int cap) {
-  return (const uint32_t*)((const char*)workspace + ip_plan(nq, n, d, k, cap).o_counts);
+  return (const uint32_t*)((const char*)workspace + ip_plan(nq, n, d, k, cap).o_counts_packed);
 }
 
 extern "C" const uint32_t* convdr_ip_debug_band(const void* workspace, int nq, int64_t n, int d, int k, int cap) {
@@ -586,7 +782,7 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
 
   // queries -> bf16 (+ norms); padded rows stay zero
   CONVDR_CHECK_HIP(hipMemsetAsync(qb, 0, (size_t)p.nq_pad * d * 2, st));
-  CONVDR_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)p.nq_pad * 4, st));
+  CONVDR_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)p.nq_pad * IP_COUNT_STRIDE * 4, st));
   bf16_t* qlo = p_bf16_lo ? (bf16_t*)(ws + p.o_qlo) : nullptr;
   if (qlo) CONVDR_CHECK_HIP(hipMemsetAsync(qlo, 0, (size_t)p.nq_pad * d * 2, st));
   hipLaunchKernelGGL(k_rows_to_bf16, dim3((nq + 3) / 4), dim3(256), 0, st, q_f32, (int64_t)nq, d, (const float*)nullptr, qb,
@@ -625,8 +821,7 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
                                              IP_FULL_MAX_N * 4));
         attr_done = true;
       }
-      hipLaunchKernelGGL(k_tau_select, dim3(nq), dim3(1024), (size_t)p.npow2 * 4, st, T, p.nvals, p.nq_pad, p.npow2,
-                         r, tau);
+      hipLaunchKernelGGL(k_tau_select, dim3(nq), dim3(1024), (size_t)p.npow2 * 4, st, T, p.nvals, p.nq_pad, r, tau);
       CONVDR_CHECK_LAUNCH("k_tau_select");
     }
     a.nPt = p.nPt; a.pt_stride = 1;
@@ -639,15 +834,20 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
         hipFuncSetAttribute((const void*)k_ip_select, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12));
     attr_done2 = true;
   }
-  hipLaunchKernelGGL(k_ip_cut, dim3(nq), dim3(256), (size_t)cap * 8, st, n, k, cap, counts, cand_id, cand_s, tau, qnorm,
+  {
+  ProfScope prof("ip_cut", st);
+  hipLaunchKernelGGL(k_ip_cut, dim3(nq), dim3(1024), (size_t)cap * 8, st, n, k, cap, counts,
+                     (uint32_t*)(ws + p.o_counts_packed), cand_id, cand_s, tau, qnorm,
                      p_max_norm, p_bf16_lo ? IP_EPS_COEF_X3 : IP_EPS_COEF, band, status, tau_retry);
   CONVDR_CHECK_LAUNCH("k_ip_cut");
+  }
   if (n > 0) {
     ProfScope prof("ip_rescore", st);
     hipLaunchKernelGGL(k_ip_rescore, dim3(nq, 16), dim3(256), 0, st, q_f32, p_f32, d, cap, band, cand_id, cand_x);
     CONVDR_CHECK_LAUNCH("k_ip_rescore");
   }
-  hipLaunchKernelGGL(k_ip_select, dim3(nq), dim3(256), (size_t)cap * 12, st, k, cap, band, cand_id, cand_x, D, I);
+  ProfScope prof("ip_select", st);
+  hipLaunchKernelGGL(k_ip_select, dim3(nq), dim3(IP_SELECT_THREADS), (size_t)cap * 12, st, k, cap, band, cand_id, cand_x, D, I);
   CONVDR_CHECK_LAUNCH("k_ip_select");
   return 0;
 }
