@@ -44,15 +44,15 @@ int prof_begin(const char* name, hipStream_t st) {
   if (!g_prof) return -1;
   ProfSpan s{name, nullptr, nullptr};
   if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return -1;
-  hipEventRecord(s.a, st);
+  (void)hipEventRecord(s.a, st);
   g_spans.push_back(s);
   return (int)g_spans.size() - 1;
 }
 void prof_end(int idx, hipStream_t st) {
-  if (idx >= 0) hipEventRecord(g_spans[idx].b, st);
+  if (idx >= 0) (void)hipEventRecord(g_spans[idx].b, st);
 }
 static void prof_clear() {
-  for (auto& s : g_spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+  for (auto& s : g_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   g_spans.clear();
 }
 
