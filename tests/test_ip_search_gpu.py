@@ -57,6 +57,35 @@ def test_exact_ties_lower_index_first(torch_cuda):
             assert I[j, :3].tolist() == [r, 200 + r - 50, 210 + r - 50]
 
 
+def test_tie_group_straddles_k(torch_cuda):
+    """A block of identical passages ties exactly across the k-th place (k_ip_select keeps the whole boundary group and
+    orders it by index), both when every passage is a candidate and behind the threshold scan."""
+    base = synth_corpus(33, 6000, 768)
+    for n in (1500, 6000):
+        P = base[:n].copy()
+        P[100:160] = P[100]                    # 60 identical rows
+        Q = np.stack([P[100] * 3.0, P[100] * 3.0 + base[7] * 0.01, base[5]]).astype(np.float32)
+        idx = _index()
+        idx.add(P)
+        for k in (10, 37, 100):
+            D, I = idx.search(Q, k)
+            Dr, Ir = OS.flat_ip_search(Q, P, k)
+            np.testing.assert_array_equal(I, Ir)
+            np.testing.assert_array_equal(D, Dr)
+        assert I[0, :60].tolist() == list(range(100, 160))
+
+
+def test_all_scores_equal(torch_cuda):
+    P = np.repeat(synth_corpus(34, 1, 768), 2000, axis=0)
+    Q = synth_corpus(35, 4, 768)
+    idx = _index()
+    idx.add(P)
+    D, I = idx.search(Q, 100)
+    assert (I == np.arange(100)[None, :]).all()
+    Dr, Ir = OS.flat_ip_search(Q, P, 100)
+    np.testing.assert_array_equal(D, Dr)
+
+
 def test_fewer_passages_than_k_and_empty(torch_cuda):
     P, Q = synth_corpus(3, 37, 768), synth_corpus(4, 3, 768)
     idx = _index()
