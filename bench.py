@@ -78,7 +78,8 @@ def cpu_baseline(nq, d, k, L, budget_s=12.0):
         torch.topk(Q @ P.T, k, dim=1)
         r2 += 1
     ip_rate = nq * n * r2 / (time.perf_counter() - t0)
-    return {"value": enc_rate, "unit": "passages/s", "cores": cores, "threads": threads, "kind": "port",
+    # "cores" = the threads the timed port actually ran on (the contract's meaning); the host's core count beside it
+    return {"value": enc_rate, "unit": "passages/s", "cores": threads, "host_cores": cores, "kind": "port",
             "ip_pairs_per_s": ip_rate,
             "sample": "encode: %d x %d-token passages x %d reps, fp32 torch oracle of RobertaDot_NLL_LN (12 x 768); "
                       "search: %d queries x %d passages x %d reps, fp32 SGEMM + topk(%d)" % (B, L, reps, nq, n, r2, k)}
