@@ -219,6 +219,8 @@ def main():
     index = FlatIPIndex(d, device=dev)
     index.add(P)
     del P
+    from convdr_amd import parallel
+    embid = torch.arange(rank, rank + world * n, world, device=dev, dtype=torch.int64)   # records i % W == rank
     # freshly encoded embeddings go to the block under construction (searched once complete, like the reference's
     # encode-all-then-search flow); a ring of 32 batches stands in for it
     slots = 32
@@ -235,7 +237,10 @@ def main():
             if timers:
                 timers[1].record()
             building.update_rows((i % slots) * EB, emb)
-            out = index.search_device(Q, k)
+            if world > 1:   # the corpus is sharded by block = rank: local exact top-k, two all-gathers, device merge
+                out = parallel.search_sharded_device(index, Q, k, embid)
+            else:
+                out = index.search_device(Q, k)
             if timers:
                 timers[2].record()
         return out
@@ -292,7 +297,8 @@ def main():
         "config": {"workload": "configs[1]: encode %d x %d-token passages per step into a resident %d x 768 block + "
                                "%d-query exact IP top-%d over the block" % (EB, SL, n, nq, k),
                    "passages_per_gpu": n, "queries": nq, "topk": k, "encode_batch": EB, "seq_len": SL,
-                   "parallelism": "replica + corpus shard per GPU x%d" % world},
+                   "parallelism": "encoder replica + corpus shard (block = rank) per GPU x%d%s" % (
+                       world, "; per-rank top-k all-gathered and merged on device" if world > 1 else "")},
         "encode": {"passages_per_s_per_gpu": enc_rate, "ms_per_batch": enc_ms,
                    "TFLOPs_dense_count": enc_rate * flop_per_passage(SL) / 1e12,
                    "frac_of_bf16_mfma_peak": enc_rate * flop_per_passage(SL) / 1e12 / MFMA_BF16_PEAK_TFLOPS},

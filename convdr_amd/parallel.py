@@ -59,6 +59,24 @@ def search_sharded(index, queries, k, embid, group=None):
     return Dm.cpu().numpy(), Im.cpu().numpy()
 
 
+def search_sharded_device(index, queries, k, embid, group=None):
+    """search_sharded without the host round trip: `queries` and `embid` are tensors on the index's device, the
+    per-rank (scores, record offsets) are exchanged with two all-gathers ([W, nq, k] fp32 + int64: 9.6 MB at W = 8,
+    k = 100, nq = 1000) and merged on the device.  Returns device tensors (D [nq, k] fp32, offsets [nq, k] int64,
+    status [nq] int32 of the LOCAL search -- non-zero entries are the queries FlatIPIndex.search would re-run)."""
+    D, I, status = index.search_device(queries, k)[:3]
+    ids = torch.where(I >= 0, embid[I.clamp(min=0)], torch.full_like(I, -1))
+    W = _world()
+    if W == 1:
+        return D, ids, status
+    Dl = [torch.empty_like(D) for _ in range(W)]
+    Il = [torch.empty_like(ids) for _ in range(W)]
+    dist.all_gather(Dl, D.contiguous(), group=group)
+    dist.all_gather(Il, ids.contiguous(), group=group)
+    Dm, Im = merge_rank_topk(torch.stack(Dl), torch.stack(Il), k)
+    return Dm, Im, status
+
+
 class DataParallelStudent:
     """Gradient synchronisation for one-process-per-GPU training of the student."""
 

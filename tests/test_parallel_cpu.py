@@ -55,6 +55,31 @@ def test_sharded_search_merge_matches_search_one_by_one():
     assert all(_run(_search_job, 2, 29611))
 
 
+def _search_device_job(rank, world):
+    """The tensor-in / tensor-out form bench.py uses at N > 1 (device = CPU here, search played by the oracle)."""
+    from convdr_amd import blocks, parallel
+    from oracle import search as OS
+    rs = np.random.RandomState(1)
+    N, d, k = 433, 64, 15
+    P = rs.randn(N, d).astype(np.float32)
+    P[200] = P[3]
+    Q = rs.randn(7, d).astype(np.float32)
+    mine = blocks.shard_indices(N, world, rank)
+
+    class OracleIndex:
+        def search_device(self, q, kk):
+            D, I = OS.flat_ip_search(q.numpy(), P[mine], kk)
+            return torch.from_numpy(D), torch.from_numpy(I), torch.zeros(len(D), dtype=torch.int32), None
+    D, I, st = parallel.search_sharded_device(OracleIndex(), torch.from_numpy(Q), k, torch.from_numpy(mine))
+    blocks_all = [(P[blocks.shard_indices(N, world, r)], blocks.shard_indices(N, world, r)) for r in range(world)]
+    mD, mI = OS.search_one_by_one(blocks_all, Q, k)
+    return bool(np.array_equal(I.numpy(), mI[:, :k]) and np.allclose(D.numpy(), mD[:, :k]) and int(st.sum()) == 0)
+
+
+def test_sharded_search_device_tensors():
+    assert all(_run(_search_device_job, 2, 29613))
+
+
 def _ddp_job(rank, world):
     from convdr_amd import parallel
     torch.manual_seed(0)
