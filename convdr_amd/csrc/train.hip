@@ -106,6 +106,9 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
 struct WgradFork {
   hipStream_t main, side;
   hipEvent_t prod[4], fin[4];
+  // "every gradient of layer l is written": one event on each stream (convdr_backward_wait_layer)
+  hipEvent_t layer_main[TRAIN_MAX_LAYERS], layer_side[TRAIN_MAX_LAYERS];
+  int layers_recorded;
   bool ok;
   static WgradFork& get() {   // one per device (the side stream belongs to the device that is current at creation)
     static WgradFork f[16] = {};
@@ -120,6 +123,10 @@ struct WgradFork {
       for (int i = 0; i < 4; ++i) {
         CONVDR_CHECK_HIP(hipEventCreateWithFlags(&prod[i], hipEventDisableTiming));
         CONVDR_CHECK_HIP(hipEventCreateWithFlags(&fin[i], hipEventDisableTiming));
+      }
+      for (int i = 0; i < TRAIN_MAX_LAYERS; ++i) {
+        CONVDR_CHECK_HIP(hipEventCreateWithFlags(&layer_main[i], hipEventDisableTiming));
+        CONVDR_CHECK_HIP(hipEventCreateWithFlags(&layer_side[i], hipEventDisableTiming));
       }
       ok = true;
     }
@@ -136,6 +143,11 @@ struct WgradFork {
   }
   int wait(int k) {
     CONVDR_CHECK_HIP(hipStreamWaitEvent(main, fin[k], 0));
+    return 0;
+  }
+  int layer_done(int l, hipStream_t side_or_main) {   // both chains have enqueued the last gradient writes of layer l
+    CONVDR_CHECK_HIP(hipEventRecord(layer_main[l], main));
+    CONVDR_CHECK_HIP(hipEventRecord(layer_side[l], side_or_main));
     return 0;
   }
 };
@@ -441,7 +453,9 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     g.rows = rows; g.W = (const bf16_t*)lt->wqkv_t; g.X = p.dQKV; g.N = H; g.K = 3 * H; g.Cf = dXin; g.Rf = dY1;
     if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_dgrad")) return e;
     if (dXin != A) { float* t = A; A = Bf; Bf = t; }   // A again holds the stream gradient (now d Xin = d output of layer l-1)
+    if (int e = wf.layer_done(l, ss)) return e;
   }
+  wf.layers_recorded = NL;
   if (fork_wgrad)
     if (int e = wf.wait(3)) return e;   // join: every weight gradient is complete for whatever follows on `stream`
   // ---- embeddings ----
@@ -461,6 +475,16 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
 }
 
 // fp32 [n, k] row-major -> bf16 [k, n]
+extern "C" int convdr_backward_wait_layer(int layer, convdr_stream_t stream) {
+  WgradFork& wf = WgradFork::get();
+  CONVDR_REQUIRE(wf.ok && layer >= 0 && layer < wf.layers_recorded,
+                 "convdr_backward_wait_layer: layer %d of a backward with %d layers (none enqueued yet?)", layer,
+                 wf.ok ? wf.layers_recorded : 0);
+  CONVDR_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, wf.layer_main[layer], 0));
+  CONVDR_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, wf.layer_side[layer], 0));
+  return 0;
+}
+
 extern "C" int convdr_transpose_f32_bf16(const float* x, int n, int k, void* y, convdr_stream_t stream) {
   hipLaunchKernelGGL(k_transpose_f32_bf16, dim3((k + 63) / 64, (n + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, n, k,
                      (bf16_t*)y);

@@ -86,14 +86,60 @@ class DataParallelStudent:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, 0, group=group)
 
-    def allreduce_grads(self):
+    def _layer_buckets(self, n_flat):
+        """[(begin, end)] of each encoder layer's gradients in the flat arena (train._tower_params order: 5 embedding
+        tensors, 16 per layer, 4 of the head), or None when the model has no arena of exactly n_flat elements."""
+        m = self.model.module if hasattr(self.model, "module") else self.model
+        tower = getattr(m, "roberta", None)
+        info = getattr(tower, "_flat", None)
+        if info is None:
+            return None
+        offs = [0]
+        for p in info["params"]:
+            offs.append(offs[-1] + p.numel())
+        if offs[-1] != n_flat:
+            return None
+        nl = len(tower.encoder.layer)
+        return [(offs[5 + 16 * l], offs[5 + 16 * (l + 1)]) for l in range(nl)]
+
+    def allreduce_grads(self, force_overlap=False):
+        """Average the gradients over the ranks.  With the flat arena on a GPU the all-reduce runs UNDER the backward:
+        convdr_encoder_backward has only been enqueued when this is called, so one collective per encoder layer
+        (28 MB of fp32 for roberta-base: large enough for the xGMI ring, 12 of them in flight behind each other) is
+        queued on a communication stream behind that layer's completion events (convdr_backward_wait_layer), last
+        layer first; embeddings + head follow the whole backward.  The compute stream waits for all of them at the
+        end.  (force_overlap: run this path at world size 1 too -- the single-GPU test of the stream logic.)"""
         W = _world()
-        if W == 1:
+        if W == 1 and not force_overlap:
             return
         from .train import _flat_view
         grads = [p.grad for p in self.model.parameters() if p.grad is not None]
         flat = _flat_view(grads)
-        if flat is not None:                       # the usual case: one arena written by convdr_encoder_backward
+        buckets = self._layer_buckets(flat.numel()) if (flat is not None and flat.is_cuda) else None
+        if buckets:
+            from . import _lib
+            L = _lib.lib()
+            cur = torch.cuda.current_stream(flat.device)
+            if getattr(self, "_comm", None) is None:
+                self._comm = torch.cuda.Stream(device=flat.device)
+            comm, works = self._comm, []
+            with torch.cuda.device(flat.device), torch.cuda.stream(comm):
+                for l in reversed(range(len(buckets))):
+                    _lib.check(L.convdr_backward_wait_layer(l, comm.cuda_stream), "convdr_backward_wait_layer")
+                    b, e = buckets[l]
+                    works.append(dist.all_reduce(flat[b:e], group=self.group, async_op=True))
+                comm.wait_stream(cur)              # embeddings and head: complete only with the whole backward
+                works.append(dist.all_reduce(flat[:buckets[0][0]], group=self.group, async_op=True))
+                works.append(dist.all_reduce(flat[buckets[-1][1]:], group=self.group, async_op=True))
+            for wk in works:
+                wk.wait()                          # the compute stream waits; the host does not
+            cur.wait_stream(comm)
+            if W > 1:
+                flat.div_(W)
+            return
+        if W == 1:
+            return
+        if flat is not None:                       # one arena, but not on a GPU (gloo tests): a single collective
             dist.all_reduce(flat, group=self.group)
             flat.div_(W)
             return

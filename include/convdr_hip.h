@@ -206,6 +206,13 @@ int convdr_encoder_backward(const convdr_encoder_config* cfg, const convdr_encod
                             size_t workspace_bytes, const float* d_out, const convdr_encoder_grads* grads,
                             convdr_stream_t stream);
 
+/* Gradient all-reduce under the backward (replaces what DistributedDataParallel's bucket hooks do for
+ * /root/reference/drivers/run_convdr_train.py:52,178): makes `stream` wait until every gradient of encoder layer
+ * `layer` written by the most recent convdr_encoder_backward on the current device is complete (the layers finish in
+ * the order layers-1 .. 0; embeddings and head only with the whole call).  The caller then enqueues the collective for
+ * that layer's slice of the gradient arena on `stream` while the backward of the layers below is still running. */
+int convdr_backward_wait_layer(int layer, convdr_stream_t stream);
+
 /* fp32 [n, k] row-major -> bf16 [k, n] (packing of the transposed weights) */
 int convdr_transpose_f32_bf16(const float* x, int n, int k, void* y, convdr_stream_t stream);
 

@@ -322,3 +322,75 @@ def test_inbatch_negative_loss_matches_oracle():
     d3 = torch.randn(4, 3, 8).cuda()
     allv, p = TR.gather_inbatch_docs(d3)
     assert torch.equal(allv, d3.reshape(12, 8)) and p.tolist() == [0, 3, 6, 9]
+
+
+def test_layer_completion_events_and_overlapped_allreduce():
+    """convdr_backward_wait_layer: a stream that waits for layer l's events sees layer l's final gradients (snapshots
+    taken behind the events while the backward is still running equal the gradients after a full sync), and the
+    bucketed all-reduce that DataParallelStudent queues behind those events (run here over a 1-rank RCCL group, where
+    every collective is the identity) leaves the gradients intact and the streams joined."""
+    import torch.distributed as dist
+    from convdr_amd import _lib, parallel, train as TR
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    rs = np.random.RandomState(9)
+    nb = 128
+    lens = [rs.randint(64, 129) for _ in range(nb)]
+    ids, mask = _batch(rs, nb, 128, lens)
+    ids, mask = ids.cuda(), mask.cuda()
+    G = torch.from_numpy(rs.randn(nb, 768).astype(np.float32)).cuda()
+    # roberta-base-wide layers: the backward of a layer (~1 ms of GPU time at 12 k rows) must outlast the host's enqueue
+    # of it (and the GPU is kept busy beforehand, below), so that the snapshots are queued while the backward is
+    # still pending.  (A functional check: on this runtime the snapshot stream may share a hardware queue with the
+    # compute stream, in which case a premature event would go unnoticed.)
+    torch.manual_seed(6)
+    cfg = RobertaConfig(vocab_size=200, hidden_size=768, num_hidden_layers=4, num_attention_heads=12,
+                        intermediate_size=3072, max_position_embeddings=140, hidden_dropout_prob=0.0,
+                        attention_probs_dropout_prob=0.0)
+    student = MSMarcoConfigDict["rdot_nll"].model_class(cfg).cuda().train()
+    assert TR.flatten_parameters(student) is not None
+    ddp = parallel.DataParallelStudent(student, broadcast=False)
+
+    def backward():
+        student.zero_grad()
+        (student(ids, mask) * G).sum().backward()
+    backward()
+    torch.cuda.synchronize()
+    flat = TR._flat_view([p.grad for p in student.parameters() if p.grad is not None])
+    buckets = ddp._layer_buckets(flat.numel())
+    assert buckets is not None and len(buckets) == 4 and buckets[0][0] > 0 and buckets[-1][1] < flat.numel()
+    ref = flat.clone()
+
+    # (a) snapshots behind the per-layer events
+    flat.zero_()
+    side = torch.cuda.Stream()
+    busy = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+    for _ in range(40):                             # ~50 ms of queued work: the host gets ahead of the GPU, so the
+        busy = (busy @ busy) * 1e-2                 # snapshots below are queued before the backward has even started
+    (student(ids, mask) * G).sum().backward()       # enqueued, not waited for
+    snaps = {}
+    with torch.cuda.stream(side):
+        for l in reversed(range(4)):
+            _lib.check(_lib.lib().convdr_backward_wait_layer(l, side.cuda_stream), "convdr_backward_wait_layer")
+            b, e = buckets[l]
+            snaps[l] = flat[b:e].clone()
+    torch.cuda.synchronize()
+    flat2 = TR._flat_view([p.grad for p in student.parameters() if p.grad is not None])
+    for l, (b, e) in enumerate(buckets):
+        assert torch.equal(snaps[l], flat2[b:e]), l            # complete when the events fired
+        assert torch.equal(flat2[b:e], ref[b:e]), l            # (layer gradients are bit-reproducible)
+
+    # (b) the overlapped all-reduce path on a 1-rank process group
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29677")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        backward()
+        ddp.allreduce_grads(force_overlap=True)
+        out = TR._flat_view([p.grad for p in student.parameters() if p.grad is not None]).clone()   # on the compute stream: must be ordered
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    for b, e in buckets:
+        assert torch.equal(out[b:e], ref[b:e])
+    # embedding tables: fp32 atomics (sums of ~100 cancelling terms per row: compare on the scale of the terms)
+    assert (out - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
