@@ -27,13 +27,16 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
-def plan_batches(lens, batch_size, token_budget=None):
+def plan_batches(lens, batch_size, token_budget=None, align=1):
     """Cut a shard's records, IN ORDER, into batches of at most `batch_size` records and -- when `token_budget` is given
-    -- at most `token_budget` real tokens (a single longer record still forms a batch).  Returns [(start, stop)].
+    -- at most `token_budget` tokens, each record counted as its length rounded up to `align` (a single longer record
+    still forms a batch).  Returns [(start, stop)].
     The encoder computes packed rows, so its work per batch is the token count, not records x max length: a token
     budget keeps every launch at the size the GEMM tiles are tuned for (262,144 rows = 1,024 row tiles of 256) whatever
     the length mix of the corpus.  Embeddings do not depend on the batching (tests/test_encoder_gpu.py)."""
     lens = np.asarray(lens, dtype=np.int64)
+    if align > 1:   # the encoder packs every sequence to a multiple of `align` rows: budget the rows it will compute
+        lens = (lens + align - 1) // align * align
     n = len(lens)
     if token_budget is None:
         return [(s, min(s + batch_size, n)) for s in range(0, n, batch_size)]
@@ -60,7 +63,7 @@ def encode_shard(model, cache, rank=0, world=1, batch_size=1024, is_query_infere
     out = None
     stage = [torch.empty((batch_size, L), dtype=torch.int32).pin_memory() for _ in range(2)]
     events = [None, None]
-    for bi, (s, e) in enumerate(plan_batches(lens_all, batch_size, token_budget)):
+    for bi, (s, e) in enumerate(plan_batches(lens_all, batch_size, token_budget, align=8)):
         sel = idx[s:e]
         lens = lens_all[s:e]
         n, lmax = len(sel), int(lens.max())

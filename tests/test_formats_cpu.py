@@ -76,5 +76,11 @@ def test_plan_batches_token_budget():
                 assert lens[s:e].sum() <= budget
             if budget is not None and e < len(lens) and e - s < bs:
                 assert lens[s:e + 1].sum() > budget          # greedy: the next record would not have fitted
+    plan = plan_batches(lens, 1024, 4096, align=8)           # budget in packed rows: lengths rounded up to 8
+    al = (lens + 7) // 8 * 8
+    assert plan[0][0] == 0 and plan[-1][1] == len(lens)
+    for s, e in plan:
+        assert e - s == 1 or al[s:e].sum() <= 4096
+        assert e == len(lens) or al[s:e + 1].sum() > 4096
     assert plan_batches([], 8, 100) == []
     assert plan_batches([700], 8, 100) == [(0, 1)]
