@@ -89,7 +89,8 @@ static int check_config(const convdr_encoder_config* c) {
 // One transformer layer on packed rows; buffers may be shared across layers (inference).
 // cls_only (last layer): only the CLS rows of the output are live (models.py:43), so after attention the CLS rows of
 // ctx and of the layer input are gathered into compact [B, H] buffers and the output projection, LayerNorm and FFN run
-// on B rows instead of `rows` (K and V still need every token): saves 9/12 of the last layer's GEMM work.
+// on B rows instead of `rows`; K and V still need every token, but Q only the CLS rows (a B-row GEMM) and the attention
+// runs its CLS_Q form: saves ~10/12 of the last layer's GEMM work and half of its attention traffic.
 // On return: p.X holds the layer output (LayerNorm2 applied); when cls_only, p.Y[0..B) holds the pre-LayerNorm2 sums of
 // the B CLS rows instead.
 int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_weights* w, const EncBufs& p,
@@ -101,24 +102,30 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
   // fused QKV projection: Q, K token-major, V feature-major
   g.W = (const bf16_t*)w->wqkv; g.X = p.X; g.N = 3 * H; g.K = H; g.bias = w->bqkv;
   g.Qo = p.Q; g.Ko = p.K; g.Vt = p.Vt; g.H = H; g.ldt = p.ldt;
-  if (int e = launch_gemm<EPI_QKV>(g, st, "gemm_qkv")) return e;
-  {
-    AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, (int64_t)H, p.ctx, lse, 0.125f, (unsigned long long*)g_attn_trace};
-    ProfScope prof("attention", st);
-    // cls_only: the first query block of every sequence is enough (it contains the CLS row)
-    hipLaunchKernelGGL(k_attention_fwd, dim3(cls_only ? 1 : (max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st,
-                       a);
-    CONVDR_CHECK_LAUNCH("k_attention_fwd");
-  }
   const bf16_t *xin = p.X, *ctx = p.ctx;
   bf16_t* x1 = p.X;
   int64_t n = rows;
-  if (cls_only) {
-    hipLaunchKernelGGL(k_gather_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu, B, H, p.ctx, (const float*)nullptr, p.cls_ctx,
-                       (float*)nullptr);
+  if (!cls_only) {
+    if (int e = launch_gemm<EPI_QKV>(g, st, "gemm_qkv")) return e;
+    AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, (int64_t)H, p.ctx, lse, 0.125f, (unsigned long long*)g_attn_trace};
+    ProfScope prof("attention", st);
+    hipLaunchKernelGGL(k_attention_fwd<false>, dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
+    CONVDR_CHECK_LAUNCH("k_attention_fwd");
+  } else {
+    // K and V of every token, Q of the B CLS rows only (a third of the projection and the Q / ctx traffic of the
+    // attention saved); the CLS queries land at the head of the otherwise unused Q buffer
     hipLaunchKernelGGL(k_gather_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu, B, H, p.X, (const float*)nullptr, p.cls_x,
                        (float*)nullptr);
     CONVDR_CHECK_LAUNCH("k_gather_cls");
+    g.W = (const bf16_t*)w->wqkv + (size_t)H * H; g.bias = w->bqkv + H; g.N = 2 * H; g.third0 = 1;
+    if (int e = launch_gemm<EPI_QKV>(g, st, "gemm_qkv")) return e;
+    GemmArgs gq{};
+    gq.rows = B; gq.W = (const bf16_t*)w->wqkv; gq.X = p.cls_x; gq.N = H; gq.K = H; gq.bias = w->bqkv; gq.Cb = p.Q;
+    if (int e = launch_gemm<EPI_BF16>(gq, st, "gemm_qkv")) return e;
+    AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, (int64_t)H, p.cls_ctx, nullptr, 0.125f, nullptr};
+    ProfScope prof("attention", st);
+    hipLaunchKernelGGL(k_attention_fwd<true>, dim3(1, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
+    CONVDR_CHECK_LAUNCH("k_attention_fwd<cls>");
     xin = p.cls_x; ctx = p.cls_ctx; x1 = p.cls_x1; n = B;
   }
   // attention output dense + residual + LayerNorm -> X1

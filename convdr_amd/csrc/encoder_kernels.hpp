@@ -211,6 +211,7 @@ struct GemmArgs {
   const bf16_t* R;    // EPI_RESID_F32: residual [rows, N] bf16 (EPI_DGELU_BF16: the pre-activation)
   const float* Rf;    // EPI_RESID_F32: fp32 residual instead of R when non-null (gradient residual stream)
   bf16_t *Qo, *Ko, *Vt;  // EPI_QKV (N = 3H): Q [rows, H], K [rows, H], Vt [H, ldt]
+  int third0;            // EPI_QKV: 1 = W / bias start at the K third and N = 2H (last layer: Q is needed for the CLS rows only)
   int H;
   int64_t ldt;
   int tilesN, tilesT;
@@ -344,7 +345,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
     c.t0 = (int64_t)tt * T::TL;      // the launcher lays tiles out as [tilesT][tilesN] with TR == TL
     c.n0 = tn * T::TR;
     c.swap = false;
-    if constexpr (EPI == EPI_QKV) c.swap = c.n0 >= 2 * a.H;   // H % TR == 0 (checked by the launcher)
+    if constexpr (EPI == EPI_QKV) c.swap = c.n0 + a.third0 * a.H >= 2 * a.H;   // H % TR == 0 (checked by the launcher)
     return c;
   };
   auto tile_src = [&](const Coord& c) {
@@ -468,7 +469,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
           lds_dma_wait_all();                        // BEFORE the last stores enter the (in-order) queue
           landed = true;
         }
-        CT::store(sC, pass, a.Vt + (int64_t)(n0 - 2 * a.H) * a.ldt + t0, a.ldt, a.N - n0, a.rows - t0, tid_e);
+        CT::store(sC, pass, a.Vt + (int64_t)(n0 + (a.third0 - 2) * a.H) * a.ldt + t0, a.ldt, a.N - n0, a.rows - t0, tid_e);
       }
     } else {
       // ---- epilogue: the tile's bias slice is parked in LDS behind the stages (no vmcnt round trip per register
@@ -557,7 +558,8 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
             CONVDR_TRACE(5 + 4 * pass)
             if (a.dbg_skip_epi != 3) {
               if constexpr (EPI == EPI_QKV) {   // the tile lies inside the Q or the K third (H % TR == 0)
-                bf16_t* dst = n0 < a.H ? a.Qo + t0 * a.H + n0 : a.Ko + t0 * a.H + (n0 - a.H);
+                const int na = n0 + a.third0 * a.H;
+                bf16_t* dst = na < a.H ? a.Qo + t0 * a.H + na : a.Ko + t0 * a.H + (na - a.H);
                 CT::store(sC, pass, dst, a.H, a.rows - t0, T::TR, tid_e);
               } else {
                 CT::store(sC, pass, (out ? a.Cb2 : a.Cb) + t0 * a.N + n0, a.N, a.rows - t0, a.N - n0, tid_e);
@@ -609,6 +611,10 @@ struct AttnArgs {
 constexpr int ATT_TILE_PAIR = 2 * 64 * 128;   // K tile + V^T tile, 8 KB each
 constexpr int ATT_SMEM_BYTES = 2 * ATT_TILE_PAIR;  // double buffered
 
+// CLS_Q (last layer of an inference pass): only the CLS row of every sequence is needed downstream.  Q is then a
+// [B, H] matrix of CLS queries (row b), the workgroup still streams the sequence's K / V^T tiles, wave 0 alone does the
+// arithmetic (all of its 32 query columns carry the same query) and one lane pair stores ctx[b] ([B, H]).
+template <bool CLS_Q>
 static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.z, h = blockIdx.y;
@@ -622,14 +628,14 @@ static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5, li = lane & 31;
-  const int q = q0 + wave * 32 + li;
+  const int q = CLS_Q ? 0 : q0 + wave * 32 + li;
   const int qc = q < len ? q : len - 1;
   const int H = a.H;
   CONVDR_ATT_TRACE(1)
 
   bf16x8 qf[4];
   {
-    const bf16_t* qp = a.Q + (base + qc) * a.ldq + h * 64 + 8 * hi;
+    const bf16_t* qp = CLS_Q ? a.Q + (int64_t)b * a.ldq + h * 64 + 8 * hi : a.Q + (base + qc) * a.ldq + h * 64 + 8 * hi;
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
   }
@@ -667,6 +673,7 @@ static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs 
     if (it >= 1 && kv0 + 64 < len) stage_tile(kv0 + 64, buf ^ 1);
     if (it == 0) { CONVDR_ATT_TRACE(2) }
     if (it == 1) { CONVDR_ATT_TRACE(3) }
+    if (CLS_Q && wave != 0) continue;   // (has staged its share and passed the barrier)
     const char* sK = smem + buf * ATT_TILE_PAIR;
     const char* sV = sK + 64 * 128;
 
@@ -733,6 +740,22 @@ static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs 
 
   CONVDR_ATT_TRACE(4)
   l += __shfl_xor(l, 32, 64);
+  if constexpr (CLS_Q) {
+    if (wave == 0 && li == 0) {
+      const float inv = 1.f / l;
+      bf16_t* dst = a.ctx + (int64_t)b * H + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 ov;
+          ov.x = pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+          ov.y = pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+          *(uint2*)(dst + dt * 32 + 8 * g + 4 * hi) = ov;
+        }
+    }
+    return;
+  }
   if (q < plen) {
     // alignment rows [len, plen) get zeros: they feed later GEMMs / V^T columns and must stay finite
     const float inv = q < len ? 1.f / l : 0.f;

@@ -272,7 +272,7 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
       AttnArgs a{s.QKV, s.QKV + H, s.QKVt + (size_t)2 * H * p.ldt, p.ldt, cu_seqlens, seq_lens, H, (int64_t)3 * H, s.ctx,
                  s.LSE, 0.125f, nullptr};
       ProfScope prof("attention", st);
-      hipLaunchKernelGGL(k_attention_fwd, dim3((max_len + 127) / 128, cfg->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
+      hipLaunchKernelGGL(k_attention_fwd<false>, dim3((max_len + 127) / 128, cfg->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
       CONVDR_CHECK_LAUNCH("k_attention_fwd");
     }
     g = GemmArgs{};
