@@ -221,6 +221,9 @@ def main():
     del P
     from convdr_amd import parallel
     embid = torch.arange(rank, rank + world * n, world, device=dev, dtype=torch.int64)   # records i % W == rank
+    per = (nq + world - 1) // world
+    Q_local = torch.zeros(per, d, device=dev)
+    Q_local[:max(0, min(per, nq - rank * per))] = Q[rank * per:(rank + 1) * per]
     # freshly encoded embeddings go to the block under construction (searched once complete, like the reference's
     # encode-all-then-search flow); a ring of 32 batches stands in for it
     slots = 32
@@ -237,8 +240,11 @@ def main():
             if timers:
                 timers[1].record()
             building.update_rows((i % slots) * EB, emb)
-            if world > 1:   # the corpus is sharded by block = rank: local exact top-k, two all-gathers, device merge
-                out = parallel.search_sharded_device(index, Q, k, embid)
+            if world > 1:
+                # configs[3]: every rank holds (has encoded) a slice of the queries -> all-gather of the query embeddings;
+                # the corpus is sharded by block = rank: local exact top-k, two all-gathers, device merge
+                Qall = parallel.all_gather_rows(Q_local)[:nq]
+                out = parallel.search_sharded_device(index, Qall, k, embid)
             else:
                 out = index.search_device(Q, k)
             if timers:
@@ -298,7 +304,7 @@ def main():
                                "%d-query exact IP top-%d over the block" % (EB, SL, n, nq, k),
                    "passages_per_gpu": n, "queries": nq, "topk": k, "encode_batch": EB, "seq_len": SL,
                    "parallelism": "encoder replica + corpus shard (block = rank) per GPU x%d%s" % (
-                       world, "; per-rank top-k all-gathered and merged on device" if world > 1 else "")},
+                       world, "; query embeddings all-gathered, per-rank top-k all-gathered and merged on device" if world > 1 else "")},
         "encode": {"passages_per_s_per_gpu": enc_rate, "ms_per_batch": enc_ms,
                    "TFLOPs_dense_count": enc_rate * flop_per_passage(SL) / 1e12,
                    "frac_of_bf16_mfma_peak": enc_rate * flop_per_passage(SL) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
