@@ -6,12 +6,16 @@
 // Design (see DESIGN.md §"IP scan"): never materialise [nq, n].
 //   prepare   fp32 block -> bf16 scan copy + max row norm                      (HBM-bound, once per .add)
 //   sample    bf16 MFMA GEMM over ~1/32 of the block, epilogue keeps per-(query, 32 passages) top-2,
-//             per-query LDS bitonic sort -> tau[q] ~ score of rank `rank_target` in the whole block
-//   scan      bf16 MFMA GEMM  P_bf16[n,d] * Q_bf16[nq,d]^T  (gemm_nt.hpp), epilogue compares each fp32
-//             accumulator with tau[q] and appends (index, score) of the rare hits to a per-query list
-//   rescore   one wave per candidate: fp64 dot of the fp32 originals, canonical order (oracle/search.py)
-//   select    per query LDS bitonic sort by (exact score desc, index asc), top-k out, certificate:
-//             OK iff  kth_exact >= tau + eps,  eps = 0.0079 * |q| * max|p|   (bf16 rounding bound)
+//             per-query radix select in LDS -> tau[q] ~ score of rank `rank_target` in the whole block
+//   scan      persistent bf16 MFMA GEMM  P_bf16[n,d] * Q_bf16[nq,d]^T  (gemm_nt.hpp); epilogue: each lane (= query)
+//             counts the accumulators >= tau[q], reserves that many slots of the query's candidate list with one
+//             atomic and writes (index, score) of its hits
+//   cut       per query: k-th largest scan score by radix select, band {S~ >= S~(k) - 2 eps} moved to the front,
+//             certificate OK iff the list is complete down to the cut (cut >= tau, no overflow),
+//             eps = 0.0079 * |q| * max|p - centre|   (bf16 rounding bound)
+//   rescore   one wave per band candidate: fp64 dot of the fp32 originals, canonical order (oracle/search.py)
+//   select    per query: the k best exact scores (radix select + bitonic sort of the survivors by
+//             (exact score desc, index asc))
 #include "gemm_nt.hpp"
 
 #include <float.h>
@@ -139,7 +143,7 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, GemmAcc<T>& acc
     // many slots of the query's candidate list with ONE atomic (a device-scope returning atomic is a ~1-2 us round
     // trip to the memory side; one per hit -- ~100 per tile, serialised by the branches around them -- was 30 % of
     // the scan), then writes the hits into consecutive slots.  The list order differs from run to run either way;
-    // k_ip_cut sorts it.
+    // the downstream kernels do not depend on it.
     const int rows_left = (int)(a.n - m0 < (int64_t)T::TR ? a.n - m0 : (int64_t)T::TR);
     if (rows_left < T::TR) {   // the last passage tile: rows past n scored 0 (zero-filled operand) and must never hit
 #pragma unroll
