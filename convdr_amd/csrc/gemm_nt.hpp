@@ -272,6 +272,111 @@ __device__ __forceinline__ int gemm_nt_mainloop(const TileSrc<T>& src, int K, ch
   return (nk + first_buf) & 1;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The "R3" K step: THREE R slots and TWO L slots (3 x 32 KB + 2 x 32 KB = the whole 160 KB for 256 x 256 tiles).  Every
+// wave issues its share of the L chunk of step t + 1 right after its first fragment reads (the issue stalls pass under
+// the LDS round trip) and its share of the R chunk of step t + 2 AFTER its MFMAs of step t; counted vmcnt as in
+// gemm_ln.hpp.  No wave has a block of DMA issue in front of its MFMAs any more (in the two-stage loop the issuing wave of
+// a SIMD is the critical path of the step: 1.15 k cycles of issue, then its MFMAs, while its partner idles), and the two
+// waves of a SIMD run their MFMA phases together.  Measured on the scan (same box, A/B): 1.600 -> 1.502 ms emitting,
+// 1.327 -> 1.266 ms with +inf thresholds; the variants that ride the DMA instructions between the MFMA rows
+// (CONVDR_R3_VARIANT 1 / 2) are 1-2 % behind the two blocks.
+#ifndef CONVDR_R3_VARIANT
+#define CONVDR_R3_VARIANT 0
+#endif
+template <class T>
+struct TileSrcAll {   // all waves issue
+  StageSrc R, L;
+  __device__ __forceinline__ TileSrcAll(const bf16_t* __restrict__ Rp, int64_t ldr, int64_t nR, const bf16_t* __restrict__ Lp,
+                                        int64_t ldl, int64_t nL, int64_t r0, int64_t l0, const WavePos<T>& w)
+      : R(gemm_stage_src<T::WAVES, 0>(Rp, ldr, r0, nR, w.wave, w.lane)),
+        L(gemm_stage_src<T::WAVES, 0>(Lp, ldl, l0, nL, w.wave, w.lane)) {}
+};
+// Slot state of the R3 loop: R chunk 0 of a tile goes to R slot `rs`, chunk 1 to rs + 1 (mod 3), L chunk 0 to L slot `ls`.
+struct R3Slots { int rs, ls; };
+// the first three DMA groups of a tile (R chunk 0, L chunk 0, R chunk 1 -- in this order: the counted waits rely on it)
+template <class T>
+__device__ __forceinline__ void gemm_r3_prologue(const TileSrcAll<T>& src, int K, char* smem, const WavePos<T>& w, R3Slots s) {
+  char* sR = smem;
+  char* sL = smem + 3 * T::R_BYTES;
+  gemm_stage<T::TR, T::WAVES, 0>(src.R, 0, sR + s.rs * T::R_BYTES, w.wave);
+  gemm_stage<T::TL, T::WAVES, 0>(src.L, 0, sL + s.ls * T::L_BYTES, w.wave);
+  if (K > GEMM_BK) gemm_stage<T::TR, T::WAVES, 0>(src.R, 1, sR + (s.rs == 2 ? 0 : s.rs + 1) * T::R_BYTES, w.wave);
+}
+// Returns the slot state for the NEXT tile: once a wave is back from this call, the R slots `rs`, rs + 1 and the L slot
+// `ls` of the returned state are free (the last step read the other ones), so the next tile's prologue may be issued
+// at once -- under this tile's epilogue (prologue_in_flight on the next call).
+template <class T>
+__device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src, int K, char* smem, GemmAcc<T>& acc,
+                                                       const WavePos<T>& w, R3Slots st = R3Slots{0, 0},
+                                                       bool prologue_in_flight = false) {
+  constexpr int R_DPW = T::TR / (8 * T::WAVES);   // DMA instructions per wave per R chunk
+  const int nk = K / GEMM_BK;
+  const int sw = (w.lane >> 1) & 7;
+  const int offR = (w.wr * T::MT * 32 + w.li) * 128;
+  const int offL = (w.wl * T::NT * 32 + w.li) * 128;
+  char* sR = smem;
+  char* sL = smem + 3 * T::R_BYTES;
+  if (!prologue_in_flight) gemm_r3_prologue<T>(src, K, smem, w, st);
+  int rs = st.rs, ls = st.ls;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R_DPW) : "memory");
+    else lds_dma_wait_all();
+    lds_barrier();
+    const char* tR = sR + rs * T::R_BYTES + offR;
+    const char* tL = sL + ls * T::L_BYTES + offL;
+    bf16x8 fa[2][T::MT], fb[2][T::NT];
+    auto load_frags = [&](int s, int set) {
+      const int ch = ((2 * s + w.hi) ^ sw) * 16;
+#pragma unroll
+      for (int j = 0; j < T::NT; ++j) fb[set][j] = *(const bf16x8*)(tL + j * 32 * 128 + ch);
+#pragma unroll
+      for (int i = 0; i < T::MT; ++i) fa[set][i] = *(const bf16x8*)(tR + i * 32 * 128 + ch);
+    };
+    load_frags(0, 0);
+    constexpr int L_DPW = T::TL / (8 * T::WAVES);
+    static_assert(L_DPW <= T::MT && R_DPW <= T::MT, "one DMA instruction per MFMA row of a sub-step");
+    const bool issue_l = kt + 1 < nk, issue_r = kt + 2 < nk;
+    char* l_dst = sL + (ls ^ 1) * T::L_BYTES;
+    const int rnext = rs == 0 ? 2 : rs - 1;   // (kt + 2) % 3
+    char* r_dst = sR + rnext * T::R_BYTES;
+    // CONVDR_R3_VARIANT: 0 = L chunk as a block under the first fragments' LDS round trip, R chunk as a block after the
+    // MFMAs; 1 = both ride between the MFMA rows (L in sub-step 0, R in sub-step 3); 2 = L block, R between the rows
+#if CONVDR_R3_VARIANT != 1
+    __builtin_amdgcn_sched_barrier(0);
+    if (issue_l) gemm_stage<T::TL, T::WAVES, 0>(src.L, kt + 1, l_dst, w.wave);
+#endif
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s + 1 < 4) load_frags(s + 1, (s + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < T::MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < T::NT; ++j)
+          acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc.c[i][j], 0, 0, 0);
+#if CONVDR_R3_VARIANT == 1
+        if (s == 0 && issue_l && i < L_DPW)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(src.L.rsrc, (lptr_t)(l_dst + (i * T::WAVES + w.wave) * 8 * 128), 16, src.L.voff,
+                                                   i * src.L.round_pitch + (kt + 1) * (GEMM_BK * 2), 0, 0);
+#endif
+#if CONVDR_R3_VARIANT >= 1
+        if (s == 3 && issue_r && i < R_DPW)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(src.R.rsrc, (lptr_t)(r_dst + (i * T::WAVES + w.wave) * 8 * 128), 16, src.R.voff,
+                                                   i * src.R.round_pitch + (kt + 2) * (GEMM_BK * 2), 0, 0);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#if CONVDR_R3_VARIANT == 0
+    if (issue_r) gemm_stage<T::TR, T::WAVES, 0>(src.R, kt + 2, r_dst, w.wave);
+#endif
+    rs = rs == 2 ? 0 : rs + 1;
+    ls ^= 1;
+  }
+  return R3Slots{rs, ls};
+}
+
 // convenience form: contraction range [k_begin, k_begin + K) of R[r0.., :] and L[l0.., :]
 template <class T>
 __device__ __forceinline__ int gemm_nt_mainloop(const bf16_t* __restrict__ R, int64_t ldr, int64_t nR,

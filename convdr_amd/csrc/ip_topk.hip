@@ -309,6 +309,70 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan(const ScanArgs a) {
   }
 }
 
+// The emitting scan of 256 x 256 tiles on the 3 R-slot / 2 L-slot main loop (gemm_nt_mainloop_r3); same persistent walk,
+// next-tile prologue under the epilogue and one-tile-ahead thresholds as k_ip_scan.  (The split-bf16 scan and the
+// sampling modes stay on the two-stage loop.)
+template <class T>
+__global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan_r3(const ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t ntiles = (uint32_t)a.nPt * (uint32_t)a.nQt;
+  const uint32_t xcd = blockIdx.x & 7u, q8 = ntiles >> 3, r8 = ntiles & 7u;
+  const uint32_t chunk_base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const uint32_t chunk_len = q8 + (xcd < r8 ? 1u : 0u);
+  const uint32_t stride = (gridDim.x + 7u) >> 3;
+  uint32_t idx = blockIdx.x >> 3;
+  if (idx >= chunk_len) return;
+  const WavePos<T> w;
+  auto coords = [&](uint32_t i, int& ts, int64_t& m0, int64_t& n0) {
+    const uint32_t logical = chunk_base + i;
+    ts = (int)(logical / a.nQt);
+    const int qt = (int)(logical - (uint32_t)ts * a.nQt);
+    m0 = (int64_t)ts * a.pt_stride * T::TR;
+    n0 = (int64_t)qt * T::TL;
+  };
+  int ts;
+  int64_t m0, n0;
+  coords(idx, ts, m0, n0);
+  TileSrcAll<T> src(a.P, a.d, a.n, a.Qb, a.d, a.nq_pad, m0, n0, w);
+  R3Slots slots{0, 0};
+  gemm_r3_prologue<T>(src, a.d, smem, w, slots);
+  float tau_next[T::NT];
+  auto load_tau = [&](int64_t n0_) {
+#pragma unroll
+    for (int nt = 0; nt < T::NT; ++nt) {
+      const int q = (int)n0_ + w.l_index(nt);
+      tau_next[nt] = q < a.nq ? a.tau[q] : INFINITY;
+    }
+  };
+  load_tau(n0);
+  for (;;) {
+    GemmAcc<T> acc;
+    acc.zero();
+    float tau_lane[T::NT];
+#pragma unroll
+    for (int nt = 0; nt < T::NT; ++nt) tau_lane[nt] = tau_next[nt];
+    slots = gemm_nt_mainloop_r3<T>(src, a.d, smem, acc, w, slots, true);
+#pragma unroll
+    for (int nt = 0; nt < T::NT; ++nt) asm volatile("" : "+v"(tau_lane[nt]));
+    const uint32_t next = idx + stride;
+    const bool has_next = next < chunk_len;
+    const int ts_cur = ts;
+    const int64_t m0_cur = m0, n0_cur = n0;
+    if (has_next) {
+      coords(next, ts, m0, n0);
+      load_tau(n0);
+      src = TileSrcAll<T>(a.P, a.d, a.n, a.Qb, a.d, a.nq_pad, m0, n0, w);
+      gemm_r3_prologue<T>(src, a.d, smem, w, slots);
+    }
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const WavePos<T> we(tid_e);
+    scan_epilogue<IP_MODE_EMIT, T>(a, acc, we, ts_cur, m0_cur, n0_cur, tau_lane);
+    if (!has_next) break;
+    idx = next;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Block-wide order statistics in LDS.  The search needs three of them per query -- the r-th largest sample score (the
 // threshold), the k-th largest candidate score (the band cut) and the k best re-scored candidates -- and none needs
@@ -646,6 +710,23 @@ static int launch_scan_x(const ScanArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const unsigned tiles = (unsigned)a.nPt * (unsigned)a.nQt;
+  static const bool r3 = getenv("CONVDR_DBG_SCAN_NO_R3") == nullptr;   // A/B switch: the two-stage loop
+  if constexpr (MODE == IP_MODE_EMIT && !X3 && T::TR == 256) {
+    if (r3) {
+      constexpr int R3_SMEM = 3 * T::R_BYTES + 2 * T::L_BYTES;
+      static bool attr3 = false;
+      if (!attr3) {
+        CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_scan_r3<T>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_SMEM));
+        attr3 = true;
+      }
+      ScanArgs b = a;
+      if (getenv("CONVDR_DBG_SCAN_NOEMIT")) b.nq = 0;
+      ProfScope prof("ip_scan_emit", st);
+      hipLaunchKernelGGL((k_ip_scan_r3<T>), dim3(std::min(tiles, (unsigned)device_cu_count())), dim3(T::THREADS), R3_SMEM, st, b);
+      CONVDR_CHECK_LAUNCH("k_ip_scan_r3");
+      return 0;
+    }
+  }
   static const bool one_tile_per_wg = getenv("CONVDR_DBG_SCAN_NONPERSISTENT") != nullptr;   // A/B switch for the walk
   const unsigned slots = (unsigned)device_cu_count() * (T::SMEM_BYTES > 80 * 1024 ? 1u : 2u);
   const unsigned grid = one_tile_per_wg ? tiles : std::min(tiles, slots);
