@@ -264,24 +264,31 @@ struct CTile {
   static constexpr int ROWS = T::TL / PASSES;
   static constexpr int STORES_PER_WAVE = ROWS * CH / T::THREADS;         // global store instructions per pass
   static_assert(PASSES >= 1 && PASSES * NTP == T::NT && ROWS * T::TR * 2 <= T::STAGE_BYTES, "C tile must fit a stage");
-  __device__ static __forceinline__ int addr(int row, int chunk) {
-    return row * (T::TR * 2) + ((chunk ^ ((row ^ (row / CH)) & (CH - 1))) << 4);
+  // The parked pass lives in two half regions (rows [0, HALF) and [HALF, ROWS)): one contiguous stage in the
+  // two-stage kernels (hi = lo + HALF_BYTES), two separate dead operand slots in the R3 form.
+  static constexpr int HALF = ROWS / 2, HALF_BYTES = HALF * T::TR * 2;
+  struct Base { uint32_t lo, hi; };
+  __device__ static __forceinline__ Base contiguous(const char* sC) { return Base{lds_off(sC), lds_off(sC) + HALF_BYTES}; }
+  __device__ static __forceinline__ int addr(int row, int chunk) {   // row relative to its half; the swizzle term only
+    return row * (T::TR * 2) + ((chunk ^ ((row ^ (row / CH)) & (CH - 1))) << 4);   // needs put and store to agree
   }
   // registers 4g..4g+3 of MFMA tile (mt, nt) of this lane, packed to bf16
-  __device__ static __forceinline__ void put(char* sC, const WavePos<T>& w, int mt, int nt, int g, uint2 o) {
+  __device__ static __forceinline__ void put(Base sC, const WavePos<T>& w, int mt, int nt, int g, uint2 o) {
     const int fl = w.r_base(mt, g);
     const int row = (w.wl * NTP + (nt % NTP)) * 32 + w.li;
-    lds_write_b64_hidden(lds_off(sC) + addr(row, fl >> 3) + (fl & 4) * 2, (u32x2_t){o.x, o.y});
+    const bool up = row >= HALF;
+    lds_write_b64_hidden((up ? sC.hi : sC.lo) + addr(up ? row - HALF : row, fl >> 3) + (fl & 4) * 2, (u32x2_t){o.x, o.y});
   }
   // dst -> element (L row 0, R index 0) of the tile; row_limit / col_limit = valid L rows / R indices (col_limit % 4 == 0).
   // Thread t owns 16-byte chunk t % CH of rows t / CH + 16 i: all LDS reads are issued before the first store, the
   // per-iteration row offsets are compile-time, and a tile that lies fully inside the matrix takes no bound checks
   // (the store tail was issue-bound: 325 cycles per store with the generic index arithmetic, measured by s_memtime).
-  __device__ static __forceinline__ void store(const char* sC, int pass, bf16_t* dst, int64_t ld, int64_t row_limit,
+  __device__ static __forceinline__ void store(Base sC, int pass, bf16_t* dst, int64_t ld, int64_t row_limit,
                                                int64_t col_limit, int tid) {
     constexpr int RPI = T::THREADS / CH;   // rows covered per iteration
     constexpr int BATCH = 4;               // LDS reads in flight before their stores (16 VGPRs; the kernel is at the cap)
-    static_assert(RPI * CH == T::THREADS && (32 * NTP) % RPI == 0 && ROWS % RPI == 0 && STORES_PER_WAVE % BATCH == 0,
+    static_assert(RPI * CH == T::THREADS && (32 * NTP) % RPI == 0 && ROWS % RPI == 0 && STORES_PER_WAVE % BATCH == 0 &&
+                      HALF % RPI == 0,
                   "store geometry");
     const int r0 = tid / CH, c = tid - r0 * CH;
     const int64_t nv = col_limit - c * 8;
@@ -291,9 +298,11 @@ struct CTile {
     for (int i0 = 0; i0 < STORES_PER_WAVE; i0 += BATCH) {
       u32x4_t v[BATCH];
       static_assert(BATCH == 4, "lds_read4_b128_hidden reads four chunks");
-      const uint32_t sb = lds_off(sC);
-      lds_read4_b128_hidden(sb + addr((i0 + 0) * RPI + r0, c), sb + addr((i0 + 1) * RPI + r0, c),
-                            sb + addr((i0 + 2) * RPI + r0, c), sb + addr((i0 + 3) * RPI + r0, c), v[0], v[1], v[2], v[3]);
+      auto at = [&](int i) {   // (i * RPI) is compile-time: so is the choice of the half
+        const int row = i * RPI;
+        return (row >= HALF ? sC.hi : sC.lo) + addr((row >= HALF ? row - HALF : row) + r0, c);
+      };
+      lds_read4_b128_hidden(at(i0 + 0), at(i0 + 1), at(i0 + 2), at(i0 + 3), v[0], v[1], v[2], v[3]);
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         constexpr int blk = 32 * NTP;
@@ -353,7 +362,23 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                   : TileSrc<T>(a.W + kbeg, ldw, a.N, a.X + kbeg, ldx, a.rows, c.n0, c.t0, w);
   };
 
-  float* sbias = (float*)(smem + T::SMEM_BYTES);
+#ifndef CONVDR_GEMM_R3
+#define CONVDR_GEMM_R3 1   // 0: the two-stage K step for the 256 x 256 tiles too (A/B builds)
+#endif
+  // R3 (256 x 256 tiles): the 3 R-slot / 2 L-slot K step of gemm_nt.hpp.  All 160 KB are operand slots, so between two
+  // tiles every byte has a second job: when a tile's main loop returns the slot state {rs, ls} of the next tile, R[rs]
+  // and L[ls] take the next tile's chunks 0 at once, the first KB of R[rs + 1] holds the next tile's bias slice (its
+  // chunk 1 is issued in step 0 of the next main loop, after every wave has folded the bias into its accumulators),
+  // and the two slots the last step read -- R[rs + 2] and L[ls ^ 1], dead after the epilogue's first barrier -- are the
+  // two halves of the parked output tile.
+  constexpr bool R3 = CONVDR_GEMM_R3 && T::WAVES == 8;
+  R3Slots st{0, 0};
+  auto sbias_of = [&](R3Slots s) { return (float*)(smem + (s.rs == 2 ? 0 : s.rs + 1) * T::R_BYTES); };
+  auto tile_src_all = [&](const Coord& cc) {
+    return cc.swap ? TileSrcAll<T>(a.X, ldx, a.rows, a.W, ldw, a.N, cc.t0, cc.n0, w)
+                   : TileSrcAll<T>(a.W + kbeg, ldw, a.N, a.X + kbeg, ldx, a.rows, cc.n0, cc.t0, w);
+  };
+  float* sbias = R3 ? sbias_of(st) : (float*)(smem + T::SMEM_BYTES);
   int trace_tile = 0;
 #ifdef CONVDR_ENABLE_TRACE   // make TRACE=1: phase stamps for tools/gemm_trace.py
 #define CONVDR_TRACE(ph)                                                                                       \
@@ -377,7 +402,9 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
   bool landed = false;   // chunk 0 of the current tile has been waited for
   if (threadIdx.x < T::TR) sbias[threadIdx.x] = bias_slice(c);
   TileSrc<T> src = tile_src(c);
-  gemm_issue_stage<T>(src, 0, smem + buf * T::STAGE_BYTES, w);
+  TileSrcAll<T> src3 = tile_src_all(c);
+  if constexpr (R3) gemm_r3_prologue<T>(src3, a.K, smem, w, st, false);
+  else gemm_issue_stage<T>(src, 0, smem + buf * T::STAGE_BYTES, w);
   __syncthreads();
   for (;;) {
     const uint32_t next = idx + stride;
@@ -413,8 +440,14 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
     float bias_next = has_next ? bias_slice(cn) : 0.f;
     CONVDR_TRACE(0)
     int idle;   // the stage the last K step did not read
+    if constexpr (R3) {
+      st = gemm_nt_mainloop_r3<T>(src3, c.swap ? a.K : klen, smem, acc, w, st, true, true, landed);
+      idle = 0;
+      sbias = sbias_of(st);   // free: neither read by the last step nor a prologue target
+    } else {
     idle = gemm_nt_mainloop<T>(src, c.swap ? a.K : klen, smem, acc, w, buf, true, landed,
                                (a.trace && trace_tile == 8) ? a.trace + ((size_t)blockIdx.x * 64 + 56) * 16 : nullptr);
+    }
     landed = false;
     // hipcc does not see the main loop's inline-asm waits: make it retire the bias loads HERE (a no-op wait, nothing
     // is in flight), not at their first use further down
@@ -424,10 +457,19 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
     if (threadIdx.x < T::TR) sbias[threadIdx.x] = bias_next;   // (every wave has read this tile's slice before its
     CONVDR_TRACE(1)                                             //  first main-loop barrier; nothing is in flight here)
     if (has_next) {
-      src = tile_src(cn);
-      gemm_issue_stage<T>(src, 0, smem + idle * T::STAGE_BYTES, w);
+      if constexpr (R3) {
+        src3 = tile_src_all(cn);
+        gemm_r3_prologue<T>(src3, a.K, smem, w, st, false);
+      } else {
+        src = tile_src(cn);
+        gemm_issue_stage<T>(src, 0, smem + idle * T::STAGE_BYTES, w);
+      }
     }
-    char* sC = smem + (idle ^ 1) * T::STAGE_BYTES;   // epilogue scratch: the stage of the last K step
+    // epilogue scratch: the stage (R3: the two slots) the last K step read
+    const typename CT::Base sC =
+        R3 ? typename CT::Base{lds_off(smem + (st.rs == 0 ? 2 : st.rs - 1) * T::R_BYTES),
+                               lds_off(smem + 3 * T::R_BYTES + (st.ls ^ 1) * T::L_BYTES)}
+           : CT::contiguous(smem + (idle ^ 1) * T::STAGE_BYTES);
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));   // opaque: keeps the epilogue's lane-dependent addresses out of the main loop's registers
     const WavePos<T> we(tid_e);

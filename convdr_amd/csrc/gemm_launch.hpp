@@ -17,7 +17,8 @@ inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
   static bool attr_done = false;
   if (!attr_done) {
     CONVDR_CHECK_HIP(
-        hipFuncSetAttribute((const void*)k_gemm<EPI, T>, hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM_BYTES + T::TR * 4));
+        hipFuncSetAttribute((const void*)k_gemm<EPI, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (CONVDR_GEMM_R3 && T::WAVES == 8) ? 160 * 1024 : T::SMEM_BYTES + T::TR * 4));
     attr_done = true;
   }
   static const int dbg = getenv("CONVDR_DBG_SAME_TILE") ? atoi(getenv("CONVDR_DBG_SAME_TILE")) : 0;
@@ -41,7 +42,8 @@ inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
   const int64_t slots = (int64_t)device_cu_count() * (T::SMEM_BYTES > 80 * 1024 ? 1 : 2);
   int64_t grid = (int64_t)a.tilesN * a.tilesT;
   if (!dbg_np && splits == 1 && grid > slots) grid = slots;
-  hipLaunchKernelGGL((k_gemm<EPI, T>), dim3((unsigned)grid, splits), dim3(T::THREADS), T::SMEM_BYTES + T::TR * 4, st, a);
+  const size_t lds = (CONVDR_GEMM_R3 && T::WAVES == 8) ? 160 * 1024 : T::SMEM_BYTES + T::TR * 4;
+  hipLaunchKernelGGL((k_gemm<EPI, T>), dim3((unsigned)grid, splits), dim3(T::THREADS), lds, st, a);
   CONVDR_CHECK_LAUNCH("k_gemm");
   return 0;
 }

@@ -295,13 +295,16 @@ struct TileSrcAll {   // all waves issue
 // Slot state of the R3 loop: R chunk 0 of a tile goes to R slot `rs`, chunk 1 to rs + 1 (mod 3), L chunk 0 to L slot `ls`.
 struct R3Slots { int rs, ls; };
 // the first three DMA groups of a tile (R chunk 0, L chunk 0, R chunk 1 -- in this order: the counted waits rely on it)
+// with_r1 = false leaves R chunk 1 to step 0 of the main loop (r1_deferred): its slot then stays untouched until every
+// wave has entered the loop -- k_gemm keeps the tile's bias slice there.
 template <class T>
-__device__ __forceinline__ void gemm_r3_prologue(const TileSrcAll<T>& src, int K, char* smem, const WavePos<T>& w, R3Slots s) {
+__device__ __forceinline__ void gemm_r3_prologue(const TileSrcAll<T>& src, int K, char* smem, const WavePos<T>& w, R3Slots s,
+                                                 bool with_r1 = true) {
   char* sR = smem;
   char* sL = smem + 3 * T::R_BYTES;
   gemm_stage<T::TR, T::WAVES, 0>(src.R, 0, sR + s.rs * T::R_BYTES, w.wave);
   gemm_stage<T::TL, T::WAVES, 0>(src.L, 0, sL + s.ls * T::L_BYTES, w.wave);
-  if (K > GEMM_BK) gemm_stage<T::TR, T::WAVES, 0>(src.R, 1, sR + (s.rs == 2 ? 0 : s.rs + 1) * T::R_BYTES, w.wave);
+  if (with_r1 && K > GEMM_BK) gemm_stage<T::TR, T::WAVES, 0>(src.R, 1, sR + (s.rs == 2 ? 0 : s.rs + 1) * T::R_BYTES, w.wave);
 }
 // Returns the slot state for the NEXT tile: once a wave is back from this call, the R slots `rs`, rs + 1 and the L slot
 // `ls` of the returned state are free (the last step read the other ones), so the next tile's prologue may be issued
@@ -309,7 +312,8 @@ __device__ __forceinline__ void gemm_r3_prologue(const TileSrcAll<T>& src, int K
 template <class T>
 __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src, int K, char* smem, GemmAcc<T>& acc,
                                                        const WavePos<T>& w, R3Slots st = R3Slots{0, 0},
-                                                       bool prologue_in_flight = false) {
+                                                       bool prologue_in_flight = false, bool r1_deferred = false,
+                                                       bool stage0_landed = false) {
   constexpr int R_DPW = T::TR / (8 * T::WAVES);   // DMA instructions per wave per R chunk
   const int nk = K / GEMM_BK;
   const int sw = (w.lane >> 1) & 7;
@@ -317,10 +321,14 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
   const int offL = (w.wl * T::NT * 32 + w.li) * 128;
   char* sR = smem;
   char* sL = smem + 3 * T::R_BYTES;
-  if (!prologue_in_flight) gemm_r3_prologue<T>(src, K, smem, w, st);
+  if (!prologue_in_flight) gemm_r3_prologue<T>(src, K, smem, w, st, !r1_deferred);
   int rs = st.rs, ls = st.ls;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R_DPW) : "memory");
+    // (r1_deferred: at step 0 only chunks 0 are in flight -- there is no newer R group to leave outstanding;
+    //  stage0_landed: the caller has already waited for them, ahead of its epilogue's stores)
+    if (kt == 0 && (r1_deferred || stage0_landed)) {
+      if (!stage0_landed) lds_dma_wait_all();
+    } else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R_DPW) : "memory");
     else lds_dma_wait_all();
     lds_barrier();
     const char* tR = sR + rs * T::R_BYTES + offR;
@@ -344,6 +352,7 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
     // MFMAs; 1 = both ride between the MFMA rows (L in sub-step 0, R in sub-step 3); 2 = L block, R between the rows
 #if CONVDR_R3_VARIANT != 1
     __builtin_amdgcn_sched_barrier(0);
+    if (r1_deferred && kt == 0 && issue_l) gemm_stage<T::TR, T::WAVES, 0>(src.R, 1, sR + (rs == 2 ? 0 : rs + 1) * T::R_BYTES, w.wave);
     if (issue_l) gemm_stage<T::TL, T::WAVES, 0>(src.L, kt + 1, l_dst, w.wave);
 #endif
 #pragma unroll
