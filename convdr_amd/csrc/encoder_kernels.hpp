@@ -221,17 +221,21 @@ struct GemmArgs {
 };
 
 
-// HF "gelu" is x * 0.5 * (1 + erf(x / sqrt 2)).  The forward epilogue evaluates it through a logistic with a fitted odd
-// polynomial argument:  Phi(x) ~ 1 / (1 + exp(-x (a + b u + c u^2))),
-// u = min(x^2, 64).  Max |error| of x Phi(x) against the exact erf form is 2.7e-5 over all x (fp32 evaluation; fit and
-// check in DESIGN.md section 5) -- two orders below the bf16 rounding of the stored activation -- for 7 VALU + 2
-// transcendentals per element instead of 15 + 2.  The constants carry the -log2(e) of exp -> v_exp_f32.
-__device__ __forceinline__ float gelu_sig(float x) {
-  const float u = fminf(x * x, 64.f);
-  float t = fmaf(u, 0.001023812276f, -0.106834618f);
-  t = fmaf(t, u, -2.30105646f);
-  const float e = __builtin_amdgcn_exp2f(t * x);          // exp(-x (a + b u + c u^2)); +inf for very negative x
-  return x * __builtin_amdgcn_rcpf(1.f + e);              // rcp(+inf) = 0
+// HF "gelu" is x * 0.5 * (1 + erf(x / sqrt 2)) = x Phi(x).  With t = |x| and the normal tail Q(t) = 1 - Phi(t):
+//     x Phi(x) = max(x, 0) - t Q(t),
+// and Q(t) = 0.5 exp2(-(c1 t + c2 t^2 + c3 t^3 + c4 t^4)) fitted (minimax on the product t Q, t <= 9; beyond that
+// t Q < 1e-17 and t is clamped because the quartic turns around).  Max |error| against the exact erf form is 8.8e-6 over
+// all x in fp32 (tests/test_gelu_fit_cpu.py) -- three orders below the bf16 rounding of the stored activation -- for
+// 7 VALU + ONE transcendental per element: the FFN1 epilogue is VALU-bound with the matrix pipe idle, and v_exp_f32 /
+// v_rcp_f32 issue at quarter rate (the logistic form this replaces, 1 / (1 + exp(-x (a + b u + c u^2))), needed both
+// and was 2.7e-5 off; A&S 7.1.26 needs 15 + 2).  The 0.5 rides in the exponent (-1).
+__device__ __forceinline__ float gelu_tail(float x) {
+  const float t = fminf(fabsf(x), 9.f);
+  float p = fmaf(t, 0.0041585f, -0.04571999f);
+  p = fmaf(p, t, -0.46495319f);
+  p = fmaf(p, t, -1.14955714f);
+  const float q = __builtin_amdgcn_exp2f(fmaf(p, t, -1.f));   // Q(t)
+  return fmaf(-t, q, fmaxf(x, 0.f));
 }
 
 // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
@@ -556,7 +560,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                 float y0 = v[4 * g + 0], y1 = v[4 * g + 1], y2 = v[4 * g + 2], y3 = v[4 * g + 3];   // bias included
                 if constexpr (EPI == EPI_GELU_BF16 || EPI == EPI_GELU_SAVE) {
                   if (out == 0) {
-                    y0 = gelu_sig(y0); y1 = gelu_sig(y1); y2 = gelu_sig(y2); y3 = gelu_sig(y3);
+                    y0 = gelu_tail(y0); y1 = gelu_tail(y1); y2 = gelu_tail(y2); y3 = gelu_tail(y3);
                   }
                 }
                 if constexpr (EPI == EPI_DGELU_BF16) {
