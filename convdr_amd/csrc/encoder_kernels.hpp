@@ -216,7 +216,7 @@ struct GemmArgs {
   int64_t ldt;
   int tilesN, tilesT;
   int dbg_same_tile;  // experiment: every workgroup reads tile (0, 0) (all-L2-hit upper bound); results are garbage
-  int dbg_skip_epi;   // experiment: 1 no epilogue, 3 no global stores of bf16 tiles (results are garbage)
+  int dbg_skip_epi;   // experiment: 1 no epilogue, 3 no global stores of bf16 tiles, 4 every tile stores to tile 0 (garbage results)
   unsigned long long* trace;   // experiment: [workgroup][64 tiles][16 phases] s_memtime stamps of wave 0 (or null)
 };
 
@@ -609,7 +609,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                 bf16_t* dst = na < a.H ? a.Qo + t0 * a.H + na : a.Ko + t0 * a.H + (na - a.H);
                 CT::store(sC, pass, dst, a.H, a.rows - t0, T::TR, tid_e);
               } else {
-                CT::store(sC, pass, (out ? a.Cb2 : a.Cb) + t0 * a.N + n0, a.N, a.rows - t0, a.N - n0, tid_e);
+                CT::store(sC, pass, a.dbg_skip_epi == 4 ? a.Cb : (out ? a.Cb2 : a.Cb) + t0 * a.N + n0, a.N, a.rows - t0, a.N - n0, tid_e);
               }
             }
             CONVDR_TRACE(6 + 4 * pass)
