@@ -18,10 +18,11 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def all_gather_rows(x, group=None):
-    """[n_local, d] on every rank (equal n_local) -> [W * n_local, d], rank order."""
+def all_gather_rows(x, group=None, force=False):
+    """[n_local, d] on every rank (equal n_local) -> [W * n_local, d], rank order.
+    (force: run the collective at world size 1 too -- single-GPU tests of the RCCL path.)"""
     W = _world()
-    if W == 1:
+    if W == 1 and not (force and dist.is_initialized()):
         return x
     parts = [torch.empty_like(x) for _ in range(W)]
     dist.all_gather(parts, x.contiguous(), group=group)
@@ -59,7 +60,7 @@ def search_sharded(index, queries, k, embid, group=None):
     return Dm.cpu().numpy(), Im.cpu().numpy()
 
 
-def search_sharded_device(index, queries, k, embid, group=None):
+def search_sharded_device(index, queries, k, embid, group=None, force=False):
     """search_sharded without the host round trip: `queries` and `embid` are tensors on the index's device, the
     per-rank (scores, record offsets) are exchanged with two all-gathers ([W, nq, k] fp32 + int64: 9.6 MB at W = 8,
     k = 100, nq = 1000) and merged on the device.  Returns device tensors (D [nq, k] fp32, offsets [nq, k] int64,
@@ -67,7 +68,7 @@ def search_sharded_device(index, queries, k, embid, group=None):
     D, I, status = index.search_device(queries, k)[:3]
     ids = torch.where(I >= 0, embid[I.clamp(min=0)], torch.full_like(I, -1))
     W = _world()
-    if W == 1:
+    if W == 1 and not (force and dist.is_initialized()):
         return D, ids, status
     Dl = [torch.empty_like(D) for _ in range(W)]
     Il = [torch.empty_like(ids) for _ in range(W)]

@@ -230,3 +230,32 @@ def test_clustered_embeddings_are_searched_exactly(torch_cuda, precision):
     raw.add(P)
     with pytest.raises(Exception):
         raw.search(Q, k)
+
+
+def test_sharded_search_exchange_over_rccl(torch_cuda):
+    """The N > 1 step of bench.py on one GPU: a 1-rank RCCL group, the collectives forced (all-gather of the query slices,
+    local exact top-k, all-gather of scores / record offsets, device merge) -- same tensors, dtypes and streams as with
+    8 ranks; the result must equal the plain local search mapped through embid."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from convdr_amd import parallel
+    P, Q = synth_corpus(41, 30000, 768), synth_corpus(42, 37, 768)
+    idx = _index()
+    idx.add(P)
+    dev = idx.device
+    embid = torch.arange(5, 5 + 3 * 30000, 3, device=dev, dtype=torch.int64)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29678")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        Qd = torch.from_numpy(Q).to(dev)
+        Qall = parallel.all_gather_rows(Qd, force=True)[:37]
+        D, I, st = parallel.search_sharded_device(idx, Qall, 100, embid, force=True)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    Dr, Ir = OS.flat_ip_search(Q, P, 100)
+    assert int(st.sum()) == 0
+    np.testing.assert_array_equal(I.cpu().numpy(), 5 + 3 * Ir)
+    np.testing.assert_array_equal(D.cpu().numpy(), Dr)
