@@ -118,6 +118,11 @@ class DataParallelStudent:
         flat = _flat_view(grads)
         buckets = self._layer_buckets(flat.numel()) if (flat is not None and flat.is_cuda) else None
         if buckets:
+            m = self.model.module if hasattr(self.model, "module") else self.model
+            if getattr(m.roberta, "_last_backward_arena", None) != flat.data_ptr():
+                buckets = None      # accumulated gradients (see train._EncoderFn.backward): one collective after the backward
+        self.last_path = "overlapped" if buckets else "single"   # (instrumentation for the tests)
+        if buckets:
             from . import _lib
             L = _lib.lib()
             cur = torch.cuda.current_stream(flat.device)

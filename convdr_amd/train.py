@@ -179,6 +179,10 @@ class _EncoderFn(torch.autograd.Function):
         flat = torch.zeros(int(offs[-1]), dtype=torch.float32, device=dev)
         views = [flat[int(o):int(o) + n].view(s) for o, n, s in zip(offs[:-1], sizes, ctx.shapes)]
         ptr = [v.data_ptr() for v in views]
+        # the arena this call's kernels write: DataParallelStudent overlaps the all-reduce with the backward only when the
+        # parameters' .grad ARE this arena (grads were None: autograd adopts the views); after an accumulation the
+        # .grad buffers are completed by autograd's own add kernels, which the per-layer events know nothing about
+        tower._last_backward_arena = flat.data_ptr()
         nl = len(tower.encoder.layer)
         with torch.cuda.device(dev):
             c, w, _keep = tower.packed(head)

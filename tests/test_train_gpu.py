@@ -360,13 +360,14 @@ def test_layer_completion_events_and_overlapped_allreduce():
     assert buckets is not None and len(buckets) == 4 and buckets[0][0] > 0 and buckets[-1][1] < flat.numel()
     ref = flat.clone()
 
-    # (a) snapshots behind the per-layer events
-    flat.zero_()
+    # (a) snapshots behind the per-layer events (fresh gradients: the arena the kernels write IS the parameters' .grad)
+    student.zero_grad()
     side = torch.cuda.Stream()
     busy = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
     for _ in range(40):                             # ~50 ms of queued work: the host gets ahead of the GPU, so the
         busy = (busy @ busy) * 1e-2                 # snapshots below are queued before the backward has even started
     (student(ids, mask) * G).sum().backward()       # enqueued, not waited for
+    flat = TR._flat_view([p.grad for p in student.parameters() if p.grad is not None])
     snaps = {}
     with torch.cuda.stream(side):
         for l in reversed(range(4)):
@@ -386,11 +387,20 @@ def test_layer_completion_events_and_overlapped_allreduce():
     try:
         backward()
         ddp.allreduce_grads(force_overlap=True)
+        assert ddp.last_path == "overlapped"
         out = TR._flat_view([p.grad for p in student.parameters() if p.grad is not None]).clone()   # on the compute stream: must be ordered
+        torch.cuda.synchronize()
+        # accumulated gradients (.grad kept across two backward calls) are finished by autograd's add kernels, not by
+        # the kernels the layer events cover: the overlapped path must step aside
+        (student(ids, mask) * G).sum().backward()
+        ddp.allreduce_grads(force_overlap=True)
+        assert ddp.last_path == "single"
+        acc2 = TR._flat_view([p.grad for p in student.parameters() if p.grad is not None]).clone()
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
     for b, e in buckets:
         assert torch.equal(out[b:e], ref[b:e])
+        assert torch.equal(acc2[b:e], 2 * ref[b:e])
     # embedding tables: fp32 atomics (sums of ~100 cancelling terms per row: compare on the scale of the terms)
     assert (out - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
