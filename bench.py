@@ -96,7 +96,8 @@ def main_train(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or bool(os.environ.get("CONVDR_BENCH_FORCE_DIST"))   # (the latter: 1-rank rehearsal of the N > 1 path)
+    if dist_on:
         dist.init_process_group("nccl", device_id=dev)
     from convdr_amd import _lib, train as TR
     from convdr_amd.parallel import DataParallelStudent
@@ -110,7 +111,7 @@ def main_train(args):
                             num_negatives=9, gradient_accumulation_steps=1)
     opt = TR.get_optimizer(targs, student, weight_decay=0.0)
     sched = TR.get_linear_schedule_with_warmup(opt, 0, 10_000)
-    ddp = DataParallelStudent(student) if world > 1 else None
+    ddp = DataParallelStudent(student) if dist_on else None
     g = torch.Generator(device=dev).manual_seed(rank)
     def turns(L, lo):
         ids = torch.randint(3, 50000, (Bt, L), generator=g, device=dev)
@@ -121,10 +122,10 @@ def main_train(args):
     batches = [turns(Ls, 32) + turns(Lt, 8) for _ in range(4)]
 
     def step(i):
-        return TR.train_step(targs, student, teacher, opt, sched, batches[i % 4], ddp=ddp)
+        return TR.train_step(targs, student, teacher, opt, sched, batches[i % 4], ddp=ddp, force_overlap=dist_on and world == 1)
 
     def sync_all():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
     for i in range(args.warmup):
@@ -150,7 +151,7 @@ def main_train(args):
         if cnt:
             kern[nme] = {"ms_per_step": ms / prof_steps, "launches_per_step": cnt / prof_steps}
     L_.convdr_prof_enable(0)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
@@ -201,7 +202,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or bool(os.environ.get("CONVDR_BENCH_FORCE_DIST"))   # (the latter: 1-rank rehearsal of the N > 1 path)
+    if dist_on:
         dist.init_process_group("nccl", device_id=dev)
     from convdr_amd import _lib
     from convdr_amd.search import FlatIPIndex
@@ -240,11 +242,11 @@ def main():
             if timers:
                 timers[1].record()
             building.update_rows((i % slots) * EB, emb)
-            if world > 1:
+            if dist_on:
                 # configs[3]: every rank holds (has encoded) a slice of the queries -> all-gather of the query embeddings;
                 # the corpus is sharded by block = rank: local exact top-k, two all-gathers, device merge
-                Qall = parallel.all_gather_rows(Q_local)[:nq]
-                out = parallel.search_sharded_device(index, Qall, k, embid)
+                Qall = parallel.all_gather_rows(Q_local, force=world == 1)[:nq]
+                out = parallel.search_sharded_device(index, Qall, k, embid, force=world == 1)
             else:
                 out = index.search_device(Q, k)
             if timers:
@@ -252,7 +254,7 @@ def main():
         return out
 
     def sync_all():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -276,7 +278,7 @@ def main():
         if cnt:
             spans[name] = (ms / cnt, cnt, ms / args.steps)
     L_.convdr_prof_enable(0)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()

@@ -70,11 +70,21 @@ def search_sharded_device(index, queries, k, embid, group=None, force=False):
     W = _world()
     if W == 1 and not (force and dist.is_initialized()):
         return D, ids, status
-    Dl = [torch.empty_like(D) for _ in range(W)]
-    Il = [torch.empty_like(ids) for _ in range(W)]
-    dist.all_gather(Dl, D.contiguous(), group=group)
-    dist.all_gather(Il, ids.contiguous(), group=group)
-    Dm, Im = merge_rank_topk(torch.stack(Dl), torch.stack(Il), k)
+    # one collective for both: [nq, k, 3] int32 = (score bits, offset low word, offset high word)
+    nq = D.shape[0]
+    buf = torch.empty((nq, k, 3), dtype=torch.int32, device=D.device)
+    buf[:, :, 0] = D.contiguous().view(torch.int32)
+    buf[:, :, 1:] = ids.contiguous().view(torch.int32).view(nq, k, 2)
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((W, nq, k, 3), dtype=torch.int32, device=D.device)
+        dist.all_gather_into_tensor(out, buf, group=group)
+    else:                                # gloo (the CPU tests) has no single-tensor all-gather
+        parts = [torch.empty_like(buf) for _ in range(W)]
+        dist.all_gather(parts, buf, group=group)
+        out = torch.stack(parts)
+    D_all = out[..., 0].contiguous().view(torch.float32)
+    I_all = out[..., 1:].contiguous().view(torch.int64).view(W, nq, k)
+    Dm, Im = merge_rank_topk(D_all, I_all, k)
     return Dm, Im, status
 
 

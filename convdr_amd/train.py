@@ -488,7 +488,8 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
-def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=None, doc_mask=None, ddp=None, doc_embs=None):
+def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=None, doc_mask=None, ddp=None, doc_embs=None,
+               force_overlap=False):
     """One iteration of the reference loop body (run_convdr_train.py:101-193) with pre-tokenised ranking documents
     (`doc_ids` / `doc_mask` int64 [B * (num_negatives + 1), Ld], positive first within each group).
     Returns (loss, loss1, loss2) as device scalars."""
@@ -534,7 +535,7 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
         loss = loss / args.gradient_accumulation_steps
     loss.backward()
     if ddp is not None:
-        ddp.allreduce_grads()          # one all-reduce of the flat gradient arena (parallel.py)
+        ddp.allreduce_grads(force_overlap=force_overlap)   # per-layer collectives under the backward (parallel.py)
     clip_grad_norm_(list(model.parameters()), args.max_grad_norm, defer_to=optimizer if isinstance(optimizer, AdamW) else None)
     optimizer.step()
     scheduler.step()
