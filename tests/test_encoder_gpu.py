@@ -268,3 +268,39 @@ def test_multi_chunk_matches_reference_fixture(golden_dir):
     _check(a[torch.from_numpy(live).cuda()], z["mc/emb_a"][live], "multi chunk")
     assert float(a[1, 1].abs().max()) == 0.0                                     # pure-padding chunk
     assert abs(loss - float(z["mc/loss"])) < 2e-2 * max(1.0, abs(float(z["mc/loss"])))
+
+
+def test_ragged_large_batch_matches_oracle_on_a_sample():
+    """A large RAGGED batch (about 47 k packed rows, not a multiple of any tile size): the 256 x 256 R3 kernels with a partial
+    last token tile (out-of-range rows come from the buffer descriptor's bounds check), the fused projection + LayerNorm
+    kernel's partial tile, the last layer's K / V-only projection and CLS-query attention with sequences of 1-128
+    tokens.  Sample vs the fp32 oracle, and vs the same passages encoded alone."""
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    torch.manual_seed(2)
+    model = MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig(num_hidden_layers=3))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.02)
+            elif "LayerNorm.weight" in n or n == "norm.weight":
+                p.add_(torch.randn_like(p) * 0.05)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda().eval()
+    rs = np.random.RandomState(3)
+    B, L = 733, 128
+    lens = rs.randint(1, L + 1, size=B)
+    lens[:4] = [1, 128, 2, 127]
+    ids = rs.randint(3, 50000, size=(B, L)).astype(np.int64)
+    ids[:, 0] = 0
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    ids *= mask
+    with torch.no_grad():
+        emb = model.body_emb(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda())
+    assert emb.shape == (B, 768) and bool(torch.isfinite(emb).all())
+    sample = [0, 1, 2, 3, 400, 731, 732]
+    ref = OE.rdot_nll_emb(sd, torch.from_numpy(ids[sample]), torch.from_numpy(mask[sample]), num_layers=3, num_heads=12).numpy()
+    _check(emb[sample], ref, "ragged large batch vs oracle")
+    with torch.no_grad():
+        alone = model.body_emb(torch.from_numpy(ids[sample]).cuda(), torch.from_numpy(mask[sample]).cuda())
+    cs = cosine(emb[sample].cpu().numpy(), alone.cpu().numpy())
+    assert cs.min() > 1 - 1e-4, cs
