@@ -404,3 +404,39 @@ def test_layer_completion_events_and_overlapped_allreduce():
         assert torch.equal(acc2[b:e], 2 * ref[b:e])
     # embedding tables: fp32 atomics (sums of ~100 cancelling terms per row: compare on the scale of the terms)
     assert (out - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def test_backward_at_256_tile_scale_matches_autograd():
+    """roberta-base-wide layer (768 / 12 heads / 3072) over ~17 k packed rows: enough for the training step's GEMMs to run as
+    256 x 256 tiles on the R3 K step (forward with saved pre-activations, x gelu', data-gradient and split-K
+    weight-gradient epilogues), which the small fixtures never reach.  Gradients vs torch autograd on the fp32 oracle."""
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    torch.manual_seed(12)
+    cfg = RobertaConfig(vocab_size=300, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072,
+                        max_position_embeddings=140, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = MSMarcoConfigDict["rdot_nll"].model_class(cfg)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.05)
+            elif "LayerNorm.weight" in n or n == "norm.weight":
+                p.add_(torch.randn_like(p) * 0.1)
+    rs = np.random.RandomState(12)
+    B, L = 150, 128
+    lens = rs.randint(100, L + 1, size=B).tolist()
+    ids, mask = _batch(rs, B, L, lens, vocab=300)
+    G = torch.from_numpy(rs.randn(B, 768).astype(np.float32))
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    ref_emb = OE.rdot_nll_emb(sd, ids, mask, num_layers=1, num_heads=12)
+    (ref_emb * G).sum().backward()
+    ref = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    model = model.cuda().train()
+    emb = model(ids.cuda(), mask.cuda())
+    assert cosine(emb.detach().cpu().numpy(), ref_emb.detach().numpy()).min() > 1 - 1e-3
+    (emb * G.cuda()).sum().backward()
+    checked = 0
+    for n, p in model.named_parameters():
+        if n in ref and not n.endswith("attention.self.key.bias"):
+            _compare(n, p.grad, ref[n])
+            checked += 1
+    assert checked >= 20
