@@ -128,6 +128,7 @@ register("convdr_encoder_backward", C.c_int, [C.POINTER(EncoderConfig), C.POINTE
                                               _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, C.c_size_t, _p,
                                               C.POINTER(EncoderGrads), _p])
 register("convdr_backward_wait_layer", C.c_int, [C.c_int, _p])
+register("convdr_wgrad", C.c_int, [_p, C.c_int, C.c_int64, _p, C.c_int, C.c_int64, C.c_int64, _p, C.c_size_t, _p, _p])
 register("convdr_transpose_f32_bf16", C.c_int, [_p, C.c_int, C.c_int, _p, _p])
 register("convdr_mse_fwd_bwd", C.c_int, [_p, _p, C.c_int64, C.c_float, _p, _p, _p])
 register("convdr_rank_ce_fwd_bwd", C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, C.c_int, _p])

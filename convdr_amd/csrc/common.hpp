@@ -39,6 +39,20 @@ int device_cu_count();
     }                                    \
   } while (0)
 
+// "first call on this device?" for per-device one-time setup (hipFuncSetAttribute is a property of the function ON a
+// device: a process that drives several GPUs must repeat it for each).  Not thread-safe by design: one caller thread per
+// device, and repeating the setup is harmless.
+struct DeviceOnce {
+  bool done[64] = {};
+  bool first() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+  }
+};
+
 // ---- optional per-kernel hipEvent timing (convdr_prof_enable / convdr_prof_collect) ----------
 int prof_begin(const char* name, hipStream_t st);
 void prof_end(int idx, hipStream_t st);

@@ -54,12 +54,10 @@ static int gemm_resid_ln(const bf16_t* W, const bf16_t* Wks, const bf16_t* A, in
                          const char* name, hipStream_t st) {
   // measured at 262k rows: K = 768: 0.52 ms fused vs 0.49 + 0.19 ms (GEMM + LayerNorm); K = 3072: 1.33 vs 1.17 + 0.19 ms
   if (H == 768 && rows >= g_fused_ln_min_rows && K % LN_SLICE == 0 && K <= g_fused_ln_max_k) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;
+    if (attr_done.first())
       CONVDR_CHECK_HIP(
           hipFuncSetAttribute((const void*)k_gemm_resid_ln, hipFuncAttributeMaxDynamicSharedMemorySize, LN_SMEM_BYTES));
-      attr_done = true;
-    }
     GemmLnArgs a{W, A, rows, K, bias, R, gamma, beta, eps, X,
                  K == 768 ? (unsigned long long*)g_gemm_trace_ln : nullptr, Wks};
     ProfScope prof(name, st);

@@ -14,17 +14,18 @@ inline void* g_attn_trace = nullptr;
 template <int EPI, class T>
 inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
   static_assert(T::TR == T::TL, "square tiles: the QKV kernel swaps operand roles per tile");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;   // function attributes are per device
+  if (attr_done.first()) {
     CONVDR_CHECK_HIP(
         hipFuncSetAttribute((const void*)k_gemm<EPI, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (CONVDR_GEMM_R3 && T::WAVES == 8) ? 160 * 1024 : T::SMEM_BYTES + T::TR * 4));
-    attr_done = true;
   }
+#ifdef CONVDR_ENABLE_TRACE   // timing experiments that produce garbage results: only in the `make TRACE=1` library
   static const int dbg = getenv("CONVDR_DBG_SAME_TILE") ? atoi(getenv("CONVDR_DBG_SAME_TILE")) : 0;
   a.dbg_same_tile = dbg;
   static const int dbg_epi = getenv("CONVDR_DBG_SKIP_EPI") ? atoi(getenv("CONVDR_DBG_SKIP_EPI")) : 0;
   a.dbg_skip_epi = dbg_epi;
+#endif
   static const int trace_epi = getenv("CONVDR_TRACE_EPI") ? atoi(getenv("CONVDR_TRACE_EPI")) : (int)EPI_GELU_BF16;
   a.trace = (EPI == trace_epi) ? (unsigned long long*)g_gemm_trace : nullptr;
   a.tilesN = (a.N + T::TR - 1) / T::TR;

@@ -703,24 +703,22 @@ static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
 
 template <int MODE, class T, bool X3>
 static int launch_scan_x(const ScanArgs& a, hipStream_t st) {
-  static bool attr_done = false;  // > 48 KB dynamic LDS needs the opt-in once per kernel
-  if (!attr_done) {
+  static DeviceOnce attr_done;  // > 48 KB dynamic LDS needs the opt-in once per kernel and device
+  if (attr_done.first())
     CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_scan<MODE, T, X3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          T::SMEM_BYTES));
-    attr_done = true;
-  }
   const unsigned tiles = (unsigned)a.nPt * (unsigned)a.nQt;
   static const bool r3 = getenv("CONVDR_DBG_SCAN_NO_R3") == nullptr;   // A/B switch: the two-stage loop
   if constexpr (MODE == IP_MODE_EMIT && !X3 && T::TR == 256) {
     if (r3) {
       constexpr int R3_SMEM = 3 * T::R_BYTES + 2 * T::L_BYTES;
-      static bool attr3 = false;
-      if (!attr3) {
+      static DeviceOnce attr3;
+      if (attr3.first())
         CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_scan_r3<T>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_SMEM));
-        attr3 = true;
-      }
       ScanArgs b = a;
+#ifdef CONVDR_ENABLE_TRACE   // timing only (every threshold = +inf: results are garbage): `make TRACE=1` library only
       if (getenv("CONVDR_DBG_SCAN_NOEMIT")) b.nq = 0;
+#endif
       ProfScope prof("ip_scan_emit", st);
       hipLaunchKernelGGL((k_ip_scan_r3<T>), dim3(std::min(tiles, (unsigned)device_cu_count())), dim3(T::THREADS), R3_SMEM, st, b);
       CONVDR_CHECK_LAUNCH("k_ip_scan_r3");
@@ -732,8 +730,10 @@ static int launch_scan_x(const ScanArgs& a, hipStream_t st) {
   const unsigned grid = one_tile_per_wg ? tiles : std::min(tiles, slots);
   ProfScope prof(MODE == IP_MODE_EMIT ? "ip_scan_emit" : "ip_scan_sample", st);
   ScanArgs b = a;
+#ifdef CONVDR_ENABLE_TRACE
   static const bool no_emit = getenv("CONVDR_DBG_SCAN_NOEMIT") != nullptr;   // timing only: every threshold = +inf
   if (no_emit) b.nq = 0;
+#endif
   hipLaunchKernelGGL((k_ip_scan<MODE, T, X3>), dim3(grid), dim3(T::THREADS), T::SMEM_BYTES, st, b);
   CONVDR_CHECK_LAUNCH("k_ip_scan");
   return 0;
@@ -900,24 +900,21 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
         if (r < 8) r = 8;
         if (int e = launch_scan<IP_MODE_TOP2>(a, p.big, st)) return e;
       }
-      static bool attr_done = false;
-      if (!attr_done) {
+      static DeviceOnce attr_done;
+      if (attr_done.first())
         CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_tau_select, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              IP_FULL_MAX_N * 4));
-        attr_done = true;
-      }
       hipLaunchKernelGGL(k_tau_select, dim3(nq), dim3(1024), (size_t)p.npow2 * 4, st, T, p.nvals, p.nq_pad, r, tau);
       CONVDR_CHECK_LAUNCH("k_tau_select");
     }
     a.nPt = p.nPt; a.pt_stride = 1;
     if (int e = launch_scan<IP_MODE_EMIT>(a, p.big, st)) return e;
   }
-  static bool attr_done2 = false;
-  if (!attr_done2) {
+  static DeviceOnce attr_done2;
+  if (attr_done2.first()) {
     CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_cut, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
     CONVDR_CHECK_HIP(
         hipFuncSetAttribute((const void*)k_ip_select, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12));
-    attr_done2 = true;
   }
   {
   ProfScope prof("ip_cut", st);

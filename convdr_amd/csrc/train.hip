@@ -3,6 +3,7 @@
 //   embs = model(concat_ids, concat_id_mask) ... loss.backward() ... clip_grad_norm_ ... optimizer.step()
 // (/root/reference/drivers/run_convdr_train.py:109-191) execute through torch autograd + HF AdamW.
 #include "gemm_launch.hpp"
+#include "gemm_tn.hpp"
 #include "train_kernels.hpp"
 
 #include "../../include/convdr_hip.h"
@@ -14,15 +15,21 @@ struct LayerSave {
   float *LSE, *Y1, *Y2;
 };
 
+// bf16 activation gradients of one layer that its weight-gradient products read (kept per layer: the weight-gradient
+// branch runs on its own stream, whole layers behind the activation-gradient chain, and must never be waited for)
+struct LayerBwd {
+  bf16_t *dYb, *dHpre, *dYb2, *dQKV;
+};
+
 struct TrainBufs {
   int32_t *tok_id, *tok_pos;
   LayerSave* L;  // host array (inside the plan object)
+  LayerBwd* G;   // host array
   bf16_t *Xout, *cls_b;
   float *cls_y, *cls_f, *head_y;
   // backward scratch
   float *G0, *G1, *Drow, *slab, *part, *dcls_y, *dcls_f, *dhead_y;
-  bf16_t *dYb2;   // second buffer for the LayerNorm-1 side, so the weight-gradient branch of LayerNorm 2's is not overwritten
-  bf16_t *dYb, *dYt, *dHpre, *dHpre_t, *dctx, *dctx_t, *dQKV, *dQKVt, *actT, *dhead_yb, *dhead_yt, *cls_bt, *dclsb;
+  bf16_t *dctx, *dctx_t, *dhead_yb, *dclsb;
   int64_t ldt, Tp;
   size_t slab_elems;
   size_t total;
@@ -35,11 +42,13 @@ constexpr size_t SLAB_ELEMS = (size_t)16 * 3072 * 768;  // >= splits * N * K for
 struct TrainPlan {
   TrainBufs b;
   LayerSave layers[TRAIN_MAX_LAYERS];
+  LayerBwd bwd[TRAIN_MAX_LAYERS];
 };
 
 static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char* base, TrainPlan& P) {
   TrainBufs& p = P.b;
   p.L = P.layers;
+  p.G = P.bwd;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return base + at; };
   const int H = c->hidden, I = c->intermediate;
@@ -62,7 +71,6 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
     s.Y2 = (float*)take(rs * H * 4);
   }
   const int64_t Bp = B + 128;
-  const int64_t Bt = (int64_t)align_up((size_t)B, 64) + 64;
   const int E = c->out_dim > 0 ? c->out_dim : 4;
   p.Xout = (bf16_t*)take(rs * H * 2);
   p.cls_b = (bf16_t*)take(Bp * H * 2);
@@ -78,34 +86,28 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
   p.dcls_y = (float*)take(Bp * H * 4);
   p.dcls_f = (float*)take(Bp * H * 4);
   p.dhead_y = (float*)take(Bp * E * 4);
-  p.dYb = (bf16_t*)take(rs * H * 2);
-  p.dYb2 = (bf16_t*)take(rs * H * 2);
-  p.dYt = (bf16_t*)take((size_t)H * p.ldt * 2);
-  p.dHpre = (bf16_t*)take(rs * I * 2);
-  p.dHpre_t = (bf16_t*)take((size_t)I * p.ldt * 2);
+  for (int l = 0; l < c->layers; ++l) {
+    LayerBwd& g = P.bwd[l];
+    g.dYb = (bf16_t*)take(rs * H * 2);
+    g.dHpre = (bf16_t*)take(rs * I * 2);
+    g.dYb2 = (bf16_t*)take(rs * H * 2);
+    g.dQKV = (bf16_t*)take(rs * 3 * H * 2);
+  }
   p.dctx = (bf16_t*)take(rs * H * 2);
   p.dctx_t = (bf16_t*)take((size_t)H * p.ldt * 2);
-  p.dQKV = (bf16_t*)take(rs * 3 * H * 2);
-  p.dQKVt = (bf16_t*)take((size_t)3 * H * p.ldt * 2);
-  p.actT = (bf16_t*)take((size_t)I * p.ldt * 2);
   p.dhead_yb = (bf16_t*)take(Bp * E * 2);
-  p.dhead_yt = (bf16_t*)take((size_t)E * Bt * 2);
-  p.cls_bt = (bf16_t*)take((size_t)H * Bt * 2);
   p.dclsb = (bf16_t*)take(Bp * H * 2);
   p.total = o;
 }
 
-// The weight-gradient branch of every projection -- bias column sums, the two operand transposes, the split-K GEMM and
-// its reduction -- has no consumer before the optimizer, and at training batch sizes each of its kernels (like each
-// kernel of the activation-gradient chain) fills only part of the chip.  The backward therefore forks it onto a private
-// stream: WgradFork::fork(k) makes the side stream wait for what the main stream has enqueued so far, done(k) marks the
-// end of branch k, wait(k) makes the main stream wait for it (called before the main chain overwrites a buffer the
-// branch reads; branches run in order on the side stream, so waiting for k covers all earlier ones).  Its scratch
-// (dYt, dHpre_t, dQKVt, actT, slab, the bias part of `part`) is touched by the side stream only.  join() at the end.
-// Waiting on an event that was never recorded is a no-op, which is what the first layer needs.
+// The weight-gradient branch of a layer -- the bias column sums of the QKV / FFN1 projections and ONE batched TN GEMM
+// launch for the four weight matrices -- has no consumer before the optimizer.  It runs on a private stream:
+// fork() makes the side stream wait for what the main stream has enqueued so far (the layer's activation gradients);
+// nothing on the main stream ever waits for the side stream before the final join, because every operand the branch
+// reads lives in a per-layer buffer (LayerBwd / LayerSave) and its scratch (slab, the bias part of `part`) is its own.
 struct WgradFork {
   hipStream_t main, side;
-  hipEvent_t prod[4], fin[4];
+  hipEvent_t prod, fin;
   // "every gradient of layer l is written": one event on each stream (convdr_backward_wait_layer)
   hipEvent_t layer_main[TRAIN_MAX_LAYERS], layer_side[TRAIN_MAX_LAYERS];
   int layers_recorded;
@@ -120,10 +122,8 @@ struct WgradFork {
     main = st;
     if (!ok) {
       CONVDR_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-      for (int i = 0; i < 4; ++i) {
-        CONVDR_CHECK_HIP(hipEventCreateWithFlags(&prod[i], hipEventDisableTiming));
-        CONVDR_CHECK_HIP(hipEventCreateWithFlags(&fin[i], hipEventDisableTiming));
-      }
+      CONVDR_CHECK_HIP(hipEventCreateWithFlags(&prod, hipEventDisableTiming));
+      CONVDR_CHECK_HIP(hipEventCreateWithFlags(&fin, hipEventDisableTiming));
       for (int i = 0; i < TRAIN_MAX_LAYERS; ++i) {
         CONVDR_CHECK_HIP(hipEventCreateWithFlags(&layer_main[i], hipEventDisableTiming));
         CONVDR_CHECK_HIP(hipEventCreateWithFlags(&layer_side[i], hipEventDisableTiming));
@@ -132,17 +132,14 @@ struct WgradFork {
     }
     return 0;
   }
-  int fork(int k) {
-    CONVDR_CHECK_HIP(hipEventRecord(prod[k], main));
-    CONVDR_CHECK_HIP(hipStreamWaitEvent(side, prod[k], 0));
+  int fork() {
+    CONVDR_CHECK_HIP(hipEventRecord(prod, main));
+    CONVDR_CHECK_HIP(hipStreamWaitEvent(side, prod, 0));
     return 0;
   }
-  int done(int k) {
-    CONVDR_CHECK_HIP(hipEventRecord(fin[k], side));
-    return 0;
-  }
-  int wait(int k) {
-    CONVDR_CHECK_HIP(hipStreamWaitEvent(main, fin[k], 0));
+  int join() {   // the main stream waits for everything enqueued on the side stream
+    CONVDR_CHECK_HIP(hipEventRecord(fin, side));
+    CONVDR_CHECK_HIP(hipStreamWaitEvent(main, fin, 0));
     return 0;
   }
   int layer_done(int l, hipStream_t side_or_main) {   // both chains have enqueued the last gradient writes of layer l
@@ -171,59 +168,117 @@ static int transpose(const bf16_t* in, int64_t rows, int C, int64_t ld_in, bf16_
   return 0;
 }
 
-// dW[n, k] (+)= sum_t dY[t, n] X[t, k] from the transposed operands dYt [N, ldt], Xt [K, ldt] (zero beyond the rows)
-static int wgrad(const bf16_t* dYt, int N, const bf16_t* Xt, int K, int64_t Tp, int64_t ldt, const TrainBufs& p, float* dW,
-                 hipStream_t st) {
-  const int64_t tiles = (int64_t)((N + 255) / 256) * ((K + 255) / 256);
-  int splits = (int)(Tp / 64);  // number of 64-wide contraction chunks
-  int want = (int)((320 + tiles - 1) / tiles);
-  int chunks = (splits + want - 1) / want;  // chunks of 64 per split
-  if (chunks < 1) chunks = 1;
-  while (splits % chunks) ++chunks;
-  int nsplit = splits / chunks;
-  while ((size_t)nsplit * N * K > p.slab_elems && nsplit > 1) {  // stay inside the slab arena
-    ++chunks;
-    while (splits % chunks) ++chunks;
-    nsplit = splits / chunks;
+// dW[n, k] += sum_t dY[t, n] X[t, k] for up to TN_MAX_PROBLEMS weight matrices in one launch, straight from the
+// token-major operands (TN engine, gemm_tn.hpp).  Every output tile runs the whole contraction and adds its result into
+// the gradient itself; only when the contraction is long and the tiles too few to fill the chip is it cut into slices,
+// each writing an fp32 slab that k_reduce_partials then adds into the gradient in slice order.  Deterministic either way.
+struct WgradItem {
+  const bf16_t* dY; int N; int64_t ld_dy;
+  const bf16_t* X; int K; int64_t ld_x;
+  float* dW;
+};
+template <class T>
+static int wgrad_launch(const WgradItem* it, int count, int64_t rows, float* slab, size_t slab_elems, hipStream_t st) {
+  static DeviceOnce attr_done;
+  if (attr_done.first())
+    CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_tn<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         TnCfg<T>::SMEM_BYTES));
+  GemmTnArgs g{};
+  g.count = count;
+  g.rows = rows;
+  int tiles = 0;
+  size_t elems = 0;
+  for (int i = 0; i < count; ++i) {
+    GemmTnProblem& q = g.p[i];
+    q.Rm = it[i].X; q.ldr = it[i].ld_x; q.NR = it[i].K;
+    q.Lm = it[i].dY; q.ldl = it[i].ld_dy; q.NL = it[i].N;
+    q.tilesR = (q.NR + T::TR - 1) / T::TR;
+    tiles += q.tilesR * ((q.NL + T::TL - 1) / T::TL);
+    q.tile_end = tiles;
+    q.out = it[i].dW;
+    elems += (size_t)q.NL * q.NR;
   }
-  CONVDR_REQUIRE((size_t)nsplit * N * K <= p.slab_elems, "wgrad: slab arena too small for %d x %d", N, K);
-  GemmArgs g{};
-  g.W = Xt; g.ldw = ldt; g.N = K;          // R operand: k index -> contiguous output index
-  g.X = dYt; g.ldx = ldt; g.rows = N;      // L operand: n index -> output row
-  g.K = (int)Tp; g.k_split_len = chunks * 64;
-  g.Cf = p.slab;
-  if (int e = launch_gemm<EPI_SLAB_F32>(g, st, "gemm_wgrad")) return e;
-  const int64_t n = (int64_t)N * K;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)(ceil_div64(n, 256) < 2048 ? ceil_div64(n, 256) : 2048)), dim3(256), 0,
-                     st, p.slab, nsplit, n, n, dW, 1);
-  CONVDR_CHECK_LAUNCH("k_reduce_partials");
+  const int steps = (int)ceil_div64(rows, 64);
+  int nsplit = 1;
+  if (steps >= 512 && slab) {   // long contraction, few tiles: slices of >= 256 K steps until the chip is full
+    nsplit = (int)ceil_div64(device_cu_count(), tiles);
+    if (nsplit > steps / 256) nsplit = steps / 256;
+    if ((size_t)nsplit * elems > slab_elems) nsplit = (int)(slab_elems / elems);
+    if (nsplit < 1) nsplit = 1;
+  }
+  g.steps_per_split = (steps + nsplit - 1) / nsplit;
+  if (g.steps_per_split < 1) g.steps_per_split = 1;
+  nsplit = steps > 0 ? (steps + g.steps_per_split - 1) / g.steps_per_split : 1;
+  g.nsplit = nsplit;
+  if (nsplit > 1) {
+    size_t o = 0;
+    for (int i = 0; i < count; ++i) {
+      g.p[i].out = slab + o;
+      o += (size_t)nsplit * g.p[i].NL * g.p[i].NR;
+    }
+  }
+  {
+    ProfScope prof("gemm_wgrad", st);
+    hipLaunchKernelGGL((k_gemm_tn<T>), dim3((unsigned)tiles, (unsigned)nsplit), dim3(T::THREADS), TnCfg<T>::SMEM_BYTES, st, g);
+    CONVDR_CHECK_LAUNCH("k_gemm_tn");
+  }
+  if (nsplit > 1)
+    for (int i = 0; i < count; ++i) {
+      const int64_t n = (int64_t)g.p[i].NL * g.p[i].NR;
+      hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)(ceil_div64(n / 4, 256) < 2048 ? ceil_div64(n / 4, 256) : 2048)),
+                         dim3(256), 0, st, g.p[i].out, nsplit, n, n, it[i].dW, 1);
+      CONVDR_CHECK_LAUNCH("k_reduce_partials");
+    }
   return 0;
+}
+static int wgrad_batch(const WgradItem* it, int count, int64_t rows, float* slab, size_t slab_elems, hipStream_t st) {
+  CONVDR_REQUIRE(count >= 1 && count <= TN_MAX_PROBLEMS, "wgrad: %d problems in one batch", count);
+  bool big = true;
+  for (int i = 0; i < count; ++i) {
+    CONVDR_REQUIRE(it[i].N % 8 == 0 && it[i].K % 8 == 0 && it[i].ld_dy % 8 == 0 && it[i].ld_x % 8 == 0,
+                   "wgrad: N, K and the row strides must be multiples of 8 (N=%d K=%d)", it[i].N, it[i].K);
+    big = big && it[i].N >= 256 && it[i].K >= 256;
+  }
+  // 256 x 256 tiles (half the L2 -> LDS bytes per FLOP of 128 x 128: at two 128-tiles per CU the operand stream, not the
+  // matrix pipe, bounded the round-1 kernel) unless a matrix is smaller than a tile
+  if (big) return wgrad_launch<Tile256>(it, count, rows, slab, slab_elems, st);
+  return wgrad_launch<Tile128>(it, count, rows, slab, slab_elems, st);
+}
+static int wgrad(const bf16_t* dY, int N, int64_t ld_dy, const bf16_t* X, int K, int64_t ld_x, int64_t rows, const TrainBufs& p,
+                 float* dW, hipStream_t st) {
+  const WgradItem it{dY, N, ld_dy, X, K, ld_x, dW};
+  return wgrad_batch(&it, 1, rows, p.slab, p.slab_elems, st);
 }
 
 static int bias_grad(const bf16_t* dY, int64_t rows, int C, const TrainBufs& p, float* db, hipStream_t st) {
+  CONVDR_REQUIRE(C % 8 == 0, "bias_grad: C %% 8 != 0 (%d)", C);
   float* part = p.part + (size_t)LN_BWD_BLOCKS * 3 * 3072;
   const int chunks = rows >= 2048 ? 64 : 8;
-  hipLaunchKernelGGL(k_colsum_bf16, dim3((C + 127) / 128, chunks), dim3(256), 0, st, dY, rows, C, part);
+  hipLaunchKernelGGL(k_colsum_bf16, dim3((C + 255) / 256, chunks), dim3(256), 0, st, dY, rows, C, part);
   CONVDR_CHECK_LAUNCH("k_colsum_bf16");
-  hipLaunchKernelGGL(k_reduce_partials_small, dim3((C + 63) / 64), dim3(256), 0, st, part, chunks, (int64_t)C, (int64_t)C, db, 1);
+  hipLaunchKernelGGL(k_reduce_partials_small, dim3((C + 15) / 16), dim3(256), 0, st, part, chunks, (int64_t)C, (int64_t)C, db, 1);
   CONVDR_CHECK_LAUNCH("k_reduce_partials(bias)");
   return 0;
 }
 
+// LayerNorm backward of `rows` rows; dbias (optional) = gradient of the bias of the dense layer that feeds this
+// LayerNorm (= column sums of dX).  The three parameter gradients are finished by one launch when they are adjacent in
+// the gradient arena (dbias, dgamma, dbeta -- train.py:_tower_params order), else by one launch each.
 static int ln_bwd(const float* dY, const float* Yin, int64_t rows, int H, const float* g, float eps, float* dXf, bf16_t* dXb,
-                  const TrainBufs& p, float* dgamma, float* dbeta, hipStream_t st) {
+                  const TrainBufs& p, float* dbias, float* dgamma, float* dbeta, hipStream_t st) {
   const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
   ProfScope prof("layernorm_bwd", st);
   hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, Yin, rows, H, g, eps, dXf, dXb, p.part);
   CONVDR_CHECK_LAUNCH("k_layernorm_bwd");
-  if (dbeta == dgamma + H) {   // weight and bias gradients adjacent in the arena: one launch
-    hipLaunchKernelGGL(k_reduce_partials_small, dim3((2 * H + 63) / 64), dim3(256), 0, st, p.part, blocks, (int64_t)2 * H,
-                       (int64_t)2 * H, dgamma, 1);
+  if (dbias && dgamma == dbias + H && dbeta == dgamma + H) {
+    hipLaunchKernelGGL(k_reduce_partials_small, dim3((3 * H + 15) / 16), dim3(256), 0, st, p.part, blocks, (int64_t)3 * H,
+                       (int64_t)3 * H, dbias, 1);
   } else {
-    hipLaunchKernelGGL(k_reduce_partials_small, dim3((H + 63) / 64), dim3(256), 0, st, p.part, blocks, (int64_t)2 * H,
-                       (int64_t)H, dgamma, 1);
-    hipLaunchKernelGGL(k_reduce_partials_small, dim3((H + 63) / 64), dim3(256), 0, st, p.part + H, blocks, (int64_t)2 * H,
-                       (int64_t)H, dbeta, 1);
+    float* outs[3] = {dbias, dgamma, dbeta};
+    for (int k = 0; k < 3; ++k)
+      if (outs[k])
+        hipLaunchKernelGGL(k_reduce_partials_small, dim3((H + 15) / 16), dim3(256), 0, st, p.part + (size_t)k * H, blocks,
+                           (int64_t)3 * H, (int64_t)H, outs[k], 1);
   }
   CONVDR_CHECK_LAUNCH("k_reduce_partials(ln)");
   return 0;
@@ -324,30 +379,27 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
   CONVDR_REQUIRE(workspace_bytes >= p.total, "convdr_encoder_backward: workspace too small (%zu < %zu)", workspace_bytes,
                  p.total);
   const int H = cfg->hidden, I = cfg->intermediate, NL = cfg->layers;
-  const int64_t Bt = (int64_t)align_up((size_t)B, 64) + 64;
   const convdr_layer_grads* lg_last = &gr->layers[NL - 1];
   const float* dcls = d_out;  // gradient w.r.t. LayerNorm2(cls rows) of the last layer
 
   // ---- head: out = LayerNorm(head_y), head_y = cls_b . head_w^T + head_b ----
   if (cfg->out_dim > 0) {
     const int E = cfg->out_dim;
-    if (int e = ln_bwd(d_out, p.head_y, B, E, w->head_ln_g, cfg->head_ln_eps, p.dhead_y, p.dhead_yb, p, gr->head_ln_g,
-                       gr->head_ln_b, st))
+    if (int e = ln_bwd(d_out, p.head_y, B, E, w->head_ln_g, cfg->head_ln_eps, p.dhead_y, p.dhead_yb, p, gr->head_b,
+                       gr->head_ln_g, gr->head_ln_b, st))
       return e;
-    if (int e = bias_grad(p.dhead_yb, B, E, p, gr->head_b, st)) return e;
     // d cls = d head_y . head_w : dgrad with the transposed head weight [H, E]
     GemmArgs g{};
     g.rows = B; g.W = (const bf16_t*)head_w_t; g.X = p.dhead_yb; g.N = H; g.K = E; g.Cf = p.dcls_f;
     if (int e = launch_gemm<EPI_F32>(g, st, "gemm_dgrad")) return e;
     // d head_w [E, H] = d head_y^T . cls_b
-    if (int e = transpose(p.dhead_yb, B, E, E, p.dhead_yt, Bt, st)) return e;
-    if (int e = transpose(p.cls_b, B, H, H, p.cls_bt, Bt, st)) return e;
-    if (int e = wgrad(p.dhead_yt, E, p.cls_bt, H, Bt - 64, Bt, p, gr->head_w, st)) return e;
+    if (int e = wgrad(p.dhead_yb, E, E, p.cls_b, H, H, B, p, gr->head_w, st)) return e;
     dcls = p.dcls_f;
   }
   // ---- last layer's LayerNorm2 on the CLS rows only, scattered into a zero [rows, H] gradient ----
-  if (int e = ln_bwd(dcls, p.cls_y, B, H, w->layers[NL - 1].ln2_g, cfg->ln_eps, p.dcls_y, (bf16_t*)nullptr, p, lg_last->ln2_g,
-                     lg_last->ln2_b, st))
+  // (its dbias output is the last layer's FFN2 bias gradient: only the CLS rows of that layer carry gradient)
+  if (int e = ln_bwd(dcls, p.cls_y, B, H, w->layers[NL - 1].ln2_g, cfg->ln_eps, p.dcls_y, (bf16_t*)nullptr, p, lg_last->b2,
+                     lg_last->ln2_g, lg_last->ln2_b, st))
     return e;
   CONVDR_CHECK_HIP(hipMemsetAsync(p.G0, 0, (size_t)rows * H * 4, st));
   hipLaunchKernelGGL(k_scatter_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, p.dcls_y, p.G0);
@@ -364,100 +416,69 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     const convdr_layer_weights_t* lt = &wt[l];
     const convdr_layer_grads* lg = &gr->layers[l];
     const LayerSave& s = P.layers[l];
+    const LayerBwd& d = P.bwd[l];
     const bool last = l == NL - 1;
     // A = d(pre-LN2 sum Y2) for the last layer (CLS rows only), d(layer output) otherwise
     float *dY2, *dX1, *dY1, *dXin;
-    if (fork_wgrad)
-      if (int e = wf.wait(0)) return e;   // branch 0 of the layer above has read dYb
     if (!last) {
-      if (int e = ln_bwd(A, s.Y2, rows, H, lw->ln2_g, cfg->ln_eps, Bf, p.dYb, p, lg->ln2_g, lg->ln2_b, st)) return e;
+      if (int e = ln_bwd(A, s.Y2, rows, H, lw->ln2_g, cfg->ln_eps, Bf, d.dYb, p, lg->b2, lg->ln2_g, lg->ln2_b, st)) return e;
       dY2 = Bf; dX1 = A; dY1 = Bf; dXin = A;
     } else {
-      hipLaunchKernelGGL(k_cast_f32_bf16, dim3(1024), dim3(256), 0, st, A, p.dYb, (int64_t)rows * H / 4);
+      hipLaunchKernelGGL(k_cast_f32_bf16, dim3(1024), dim3(256), 0, st, A, d.dYb, (int64_t)rows * H / 4);
       CONVDR_CHECK_LAUNCH("k_cast_f32_bf16");
       dY2 = A; dX1 = Bf; dY1 = A; dXin = Bf;
     }
-    // ---- FFN2: Y2 = Hm W2^T + b2 + X1 ----
-    if (fork_wgrad)
-      if (int e = wf.fork(0)) return e;
-    if (int e = bias_grad(p.dYb, rows, H, p, lg->b2, ss)) return e;
-    if (int e = transpose(p.dYb, rows, H, H, p.dYt, p.ldt, ss)) return e;
-    if (int e = transpose(s.Hm, rows, I, I, p.actT, p.ldt, ss)) return e;
-    if (int e = wgrad(p.dYt, H, p.actT, I, p.Tp, p.ldt, p, lg->w2, ss)) return e;
-    if (fork_wgrad) {
-      if (int e = wf.done(0)) return e;
-      if (int e = wf.wait(1)) return e;   // branch 1 of the layer above has read dHpre
-    }
+    // ---- FFN2: Y2 = Hm W2^T + b2 + X1:  dHpre = (dY2 W2) * gelu'(Hpre) ----
     GemmArgs g{};
-    g.rows = rows; g.W = (const bf16_t*)lt->w2_t; g.X = p.dYb; g.N = I; g.K = H; g.Cb = p.dHpre; g.R = s.Hpre;
-    if (int e = launch_gemm<EPI_DGELU_BF16>(g, st, "gemm_dgrad")) return e;   // dHpre = (dY2 W2) * gelu'(Hpre)
+    g.rows = rows; g.W = (const bf16_t*)lt->w2_t; g.X = d.dYb; g.N = I; g.K = H; g.Cb = d.dHpre; g.R = s.Hpre;
+    if (int e = launch_gemm<EPI_DGELU_BF16>(g, st, "gemm_dgrad")) return e;
     // ---- FFN1: Hpre = X1 W1^T + b1;  dX1 = dHpre W1 + dY2 (residual branch, fp32) ----
-    if (fork_wgrad)
-      if (int e = wf.fork(1)) return e;
-    if (int e = bias_grad(p.dHpre, rows, I, p, lg->b1, ss)) return e;
-    if (int e = transpose(p.dHpre, rows, I, I, p.dHpre_t, p.ldt, ss)) return e;
-    if (int e = transpose(s.X1, rows, H, H, p.actT, p.ldt, ss)) return e;
-    if (int e = wgrad(p.dHpre_t, I, p.actT, H, p.Tp, p.ldt, p, lg->w1, ss)) return e;
-    if (fork_wgrad) {
-      if (int e = wf.done(1)) return e;
-      if (int e = wf.wait(2)) return e;   // branch 2 of the layer above has read dYb2
-    }
     g = GemmArgs{};
-    g.rows = rows; g.W = (const bf16_t*)lt->w1_t; g.X = p.dHpre; g.N = H; g.K = I; g.Cf = dX1; g.Rf = dY2;
+    g.rows = rows; g.W = (const bf16_t*)lt->w1_t; g.X = d.dHpre; g.N = H; g.K = I; g.Cf = dX1; g.Rf = dY2;
     if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_dgrad")) return e;
     // ---- LayerNorm1 ----
-    if (int e = ln_bwd(dX1, s.Y1, rows, H, lw->ln1_g, cfg->ln_eps, dY1, p.dYb2, p, lg->ln1_g, lg->ln1_b, st)) return e;
+    if (int e = ln_bwd(dX1, s.Y1, rows, H, lw->ln1_g, cfg->ln_eps, dY1, d.dYb2, p, lg->bo, lg->ln1_g, lg->ln1_b, st)) return e;
     // ---- attention output projection: Y1 = ctx Wo^T + bo + Xin ----
-    if (fork_wgrad)
-      if (int e = wf.fork(2)) return e;
-    if (int e = bias_grad(p.dYb2, rows, H, p, lg->bo, ss)) return e;
-    if (int e = transpose(p.dYb2, rows, H, H, p.dYt, p.ldt, ss)) return e;
-    if (int e = transpose(s.ctx, rows, H, H, p.actT, p.ldt, ss)) return e;
-    if (int e = wgrad(p.dYt, H, p.actT, H, p.Tp, p.ldt, p, lg->wo, ss)) return e;
-    if (fork_wgrad)
-      if (int e = wf.done(2)) return e;
     g = GemmArgs{};
-    g.rows = rows; g.W = (const bf16_t*)lt->wo_t; g.X = p.dYb2; g.N = H; g.K = H; g.Cb = p.dctx;
+    g.rows = rows; g.W = (const bf16_t*)lt->wo_t; g.X = d.dYb2; g.N = H; g.K = H; g.Cb = p.dctx;
     if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
     // ---- attention ----
     if (int e = transpose(p.dctx, rows, H, H, p.dctx_t, p.ldt, st)) return e;
     hipLaunchKernelGGL(k_attn_rowdot, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.dctx, s.ctx, rows, H, p.Drow,
                        p.ldt);
     CONVDR_CHECK_LAUNCH("k_attn_rowdot");
-    if (fork_wgrad)
-      if (int e = wf.wait(3)) return e;   // branch 3 of the layer above has read dQKV
     {
-      AttnBwdArgs a{s.QKV, s.QKVt, p.dctx, p.dctx_t, s.LSE, p.Drow, p.ldt, cu_seqlens, seq_lens, H, p.dQKV, 0.125f};
-      static bool attr_done = false;
-      if (!attr_done) {
+      AttnBwdArgs a{s.QKV, s.QKVt, p.dctx, p.dctx_t, s.LSE, p.Drow, p.ldt, cu_seqlens, seq_lens, H, d.dQKV, 0.125f};
+      static DeviceOnce attr_done;
+      if (attr_done.first())
         CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_attention_bwd_dkv, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              4 * ATTB_TILE + 512));
-        attr_done = true;
-      }
       ProfScope prof("attention_bwd", st);
       const dim3 grid((max_len + 127) / 128, cfg->heads, B);
       hipLaunchKernelGGL(k_attention_bwd_dq, grid, dim3(256), 3 * ATTB_TILE, st, a);
       hipLaunchKernelGGL(k_attention_bwd_dkv, grid, dim3(256), 4 * ATTB_TILE + 512, st, a);
       CONVDR_CHECK_LAUNCH("k_attention_bwd");
     }
+    // ---- the layer's weight-gradient branch: every operand is complete now; it runs beside the layers below ----
+    if (fork_wgrad)
+      if (int e = wf.fork()) return e;
+    if (int e = bias_grad(d.dHpre, rows, I, p, lg->b1, ss)) return e;
+    if (int e = bias_grad(d.dQKV, rows, 3 * H, p, lg->bqkv, ss)) return e;
+    {
+      const WgradItem items[4] = {{d.dHpre, I, I, s.X1, H, H, lg->w1},          // Hpre = X1 W1^T
+                                  {d.dYb, H, H, s.Hm, I, I, lg->w2},            // Y2 = Hm W2^T
+                                  {d.dQKV, 3 * H, 3 * H, s.Xin, H, H, lg->wqkv},   // QKV = Xin Wqkv^T
+                                  {d.dYb2, H, H, s.ctx, H, H, lg->wo}};         // Y1 = ctx Wo^T
+      if (int e = wgrad_batch(items, 4, rows, p.slab, p.slab_elems, ss)) return e;
+    }
     // ---- QKV projection: QKV = Xin Wqkv^T + bqkv;  dXin = dQKV Wqkv + dY1 (residual branch, fp32) ----
-    if (fork_wgrad)
-      if (int e = wf.fork(3)) return e;
-    if (int e = bias_grad(p.dQKV, rows, 3 * H, p, lg->bqkv, ss)) return e;
-    if (int e = transpose(p.dQKV, rows, 3 * H, 3 * H, p.dQKVt, p.ldt, ss)) return e;
-    if (int e = transpose(s.Xin, rows, H, H, p.actT, p.ldt, ss)) return e;
-    if (int e = wgrad(p.dQKVt, 3 * H, p.actT, H, p.Tp, p.ldt, p, lg->wqkv, ss)) return e;
-    if (fork_wgrad)
-      if (int e = wf.done(3)) return e;
     g = GemmArgs{};
-    g.rows = rows; g.W = (const bf16_t*)lt->wqkv_t; g.X = p.dQKV; g.N = H; g.K = 3 * H; g.Cf = dXin; g.Rf = dY1;
+    g.rows = rows; g.W = (const bf16_t*)lt->wqkv_t; g.X = d.dQKV; g.N = H; g.K = 3 * H; g.Cf = dXin; g.Rf = dY1;
     if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_dgrad")) return e;
     if (dXin != A) { float* t = A; A = Bf; Bf = t; }   // A again holds the stream gradient (now d Xin = d output of layer l-1)
     if (int e = wf.layer_done(l, ss)) return e;
   }
   wf.layers_recorded = NL;
-  if (fork_wgrad)
-    if (int e = wf.wait(3)) return e;   // join: every weight gradient is complete for whatever follows on `stream`
   // ---- embeddings ----
   {
     const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
@@ -466,15 +487,24 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     CONVDR_CHECK_LAUNCH("k_embed_bwd");
     float* outs[3] = {gr->emb_ln_g, gr->emb_ln_b, gr->type_emb};
     for (int k = 0; k < 3; ++k) {
-      hipLaunchKernelGGL(k_reduce_partials_small, dim3((H + 63) / 64), dim3(256), 0, st, p.part + (size_t)k * H, blocks,
+      hipLaunchKernelGGL(k_reduce_partials_small, dim3((H + 15) / 16), dim3(256), 0, st, p.part + (size_t)k * H, blocks,
                          (int64_t)3 * H, (int64_t)H, outs[k], 1);
     }
     CONVDR_CHECK_LAUNCH("k_reduce_partials(embed)");
   }
+  if (fork_wgrad)
+    if (int e = wf.join()) return e;   // every weight gradient is complete for whatever follows on `stream`
   return 0;
 }
 
-// fp32 [n, k] row-major -> bf16 [k, n]
+extern "C" int convdr_wgrad(const void* dy, int N, int64_t ld_dy, const void* x, int K, int64_t ld_x, int64_t rows, float* slab,
+                            size_t slab_elems, float* dW, convdr_stream_t stream) {
+  CONVDR_REQUIRE(N > 0 && K > 0 && rows >= 0 && ld_dy >= N && ld_x >= K && (slab == nullptr || slab_elems >= (size_t)N * K),
+                 "convdr_wgrad: bad sizes N=%d K=%d rows=%lld", N, K, (long long)rows);
+  const WgradItem it{(const bf16_t*)dy, N, ld_dy, (const bf16_t*)x, K, ld_x, dW};
+  return wgrad_batch(&it, 1, rows, slab, slab_elems, (hipStream_t)stream);
+}
+
 extern "C" int convdr_backward_wait_layer(int layer, convdr_stream_t stream) {
   WgradFork& wf = WgradFork::get();
   CONVDR_REQUIRE(wf.ok && layer >= 0 && layer < wf.layers_recorded,
@@ -485,6 +515,7 @@ extern "C" int convdr_backward_wait_layer(int layer, convdr_stream_t stream) {
   return 0;
 }
 
+// fp32 [n, k] row-major -> bf16 [k, n]
 extern "C" int convdr_transpose_f32_bf16(const float* x, int n, int k, void* y, convdr_stream_t stream) {
   hipLaunchKernelGGL(k_transpose_f32_bf16, dim3((k + 63) / 64, (n + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, n, k,
                      (bf16_t*)y);
@@ -513,11 +544,9 @@ extern "C" int convdr_inbatch_ce_fwd_bwd(const float* embs, const float* docs, i
                                          float grad_scale, float* loss_per_query, float* d_embs, int accumulate,
                                          convdr_stream_t stream) {
   CONVDR_REQUIRE(B > 0 && N > 0 && N <= 16384 && E > 0, "convdr_inbatch_ce_fwd_bwd: bad sizes B=%d N=%d E=%d", B, N, E);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (attr_done.first())
     CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_inbatch_ce_fwd_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    attr_done = true;
-  }
   hipLaunchKernelGGL(k_inbatch_ce_fwd_bwd, dim3(B), dim3(256), (size_t)N * 4, (hipStream_t)stream, embs, docs, B, N, E, pos,
                      grad_scale, loss_per_query, d_embs, accumulate);
   CONVDR_CHECK_LAUNCH("k_inbatch_ce_fwd_bwd");

@@ -70,19 +70,20 @@ __global__ void __launch_bounds__(256) k_transpose_f32_bf16(const float* __restr
 // ---------------------------------------------------------------------------------------------
 // LayerNorm backward, one wave per row (grid-stride), H <= 1024.
 //   xhat = (y - mean) * rstd;  gdy = g * dy;  dx = rstd * (gdy - mean(gdy) - xhat * mean(gdy * xhat))
-// Per-workgroup partial sums of dgamma = sum dy * xhat and dbeta = sum dy go to part[block][2][H]
-// (k_reduce_partials adds them into the gradient in a fixed order: deterministic).
-// `rowmap` (optional) gathers the input rows (CLS rows) and `scatter` (optional) redirects the output rows.
+// Per-workgroup partial sums go to part[block][3][H] = (sum dx, dgamma = sum dy * xhat, dbeta = sum dy); sum dx is the
+// bias gradient of the dense layer whose output (+ residual) this LayerNorm normalises -- the arena keeps
+// [dense.bias, LayerNorm.weight, LayerNorm.bias] adjacent, so one k_reduce_partials_small launch finishes all three
+// (fixed order: deterministic).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__ dY, const float* __restrict__ Yin,
                                                        int64_t rows, int H, const float* __restrict__ g, float eps,
                                                        float* __restrict__ dXf, bf16_t* __restrict__ dXb,
                                                        float* __restrict__ part) {
-  __shared__ float red[4][2][1024];
+  __shared__ float red[4][3][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float4 ag[4], ab[4];
+  float4 ag[4], ab[4], ax[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { ag[j] = make_float4(0, 0, 0, 0); ab[j] = make_float4(0, 0, 0, 0); }
+  for (int j = 0; j < 4; ++j) { ag[j] = make_float4(0, 0, 0, 0); ab[j] = make_float4(0, 0, 0, 0); ax[j] = make_float4(0, 0, 0, 0); }
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     float4 y[4], d[4];
     float s = 0.f;
@@ -129,6 +130,7 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
         o.y = rstd * (d[j].y - m1 - y[j].y * m2);
         o.z = rstd * (d[j].z - m1 - y[j].z * m2);
         o.w = rstd * (d[j].w - m1 - y[j].w * m2);
+        ax[j].x += o.x; ax[j].y += o.y; ax[j].z += o.z; ax[j].w += o.w;
         if (dXf) *(float4*)(dXf + row * H + e0) = o;
         if (dXb) {
           uint2 p;
@@ -143,68 +145,113 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
   for (int j = 0; j < 4; ++j) {
     const int e0 = 256 * j + 4 * lane;
     if (e0 < H) {
-      *(float4*)&red[wave][0][e0] = ag[j];
-      *(float4*)&red[wave][1][e0] = ab[j];
+      *(float4*)&red[wave][0][e0] = ax[j];
+      *(float4*)&red[wave][1][e0] = ag[j];
+      *(float4*)&red[wave][2][e0] = ab[j];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * H; i += 256) {
+  for (int i = threadIdx.x; i < 3 * H; i += 256) {
     const int k = i / H, e = i - k * H;
-    part[((int64_t)blockIdx.x * 2 + k) * H + e] = red[0][k][e] + red[1][k][e] + red[2][k][e] + red[3][k][e];
+    part[((int64_t)blockIdx.x * 3 + k) * H + e] = red[0][k][e] + red[1][k][e] + red[2][k][e] + red[3][k][e];
   }
 }
 
-// out[e] (+)= sum_p part[p * stride + e], p in fixed order (deterministic)
+// out[e] (+)= sum_p part[p * stride + e], p in fixed order (deterministic).  16 bytes per thread, four partials in
+// flight per accumulator chain (the one-load-at-a-time form of round 1 spent its time in dependent L2 round trips).
 __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, int nparts, int64_t stride,
                                                          int64_t n, float* __restrict__ out, int accumulate) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * stride + i];
-    out[i] = accumulate ? out[i] + s : s;
+  const int64_t n4 = n >> 2;   // n % 4 == 0 (weight matrices)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p = 0;
+    for (; p + 4 <= nparts; p += 4) {
+      const float4 a = *(const float4*)(part + (int64_t)p * stride + 4 * i);
+      const float4 b = *(const float4*)(part + (int64_t)(p + 1) * stride + 4 * i);
+      const float4 c = *(const float4*)(part + (int64_t)(p + 2) * stride + 4 * i);
+      const float4 d = *(const float4*)(part + (int64_t)(p + 3) * stride + 4 * i);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+      s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+      s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+    for (; p < nparts; ++p) {
+      const float4 a = *(const float4*)(part + (int64_t)p * stride + 4 * i);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    if (accumulate) {
+      const float4 o = *(const float4*)(out + 4 * i);
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    *(float4*)(out + 4 * i) = s;
   }
 }
 
-// same contract for few outputs / many partials (LayerNorm and bias gradients): 64 outputs per block, the partials
-// are split over 4 thread rows and folded in LDS in a fixed order (deterministic)
+// same contract for few outputs / many partials (LayerNorm and bias gradients): 16 outputs per block, the partials
+// are split over 16 thread rows (each with four loads in flight) and folded in LDS in a fixed order (deterministic)
 static __global__ void __launch_bounds__(256) k_reduce_partials_small(const float* __restrict__ part, int nparts,
                                                                       int64_t stride, int64_t n, float* __restrict__ out,
                                                                       int accumulate) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + c;
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + c;
   float s = 0.f;
-  if (i < n)
-    for (int p = r; p < nparts; p += 4) s += part[(int64_t)p * stride + i];
+  if (i < n) {
+    int p = r;
+    for (; p + 48 < nparts; p += 64) {
+      const float a = part[(int64_t)p * stride + i], b = part[(int64_t)(p + 16) * stride + i];
+      const float c2 = part[(int64_t)(p + 32) * stride + i], d = part[(int64_t)(p + 48) * stride + i];
+      s += a; s += b; s += c2; s += d;
+    }
+    for (; p < nparts; p += 16) s += part[(int64_t)p * stride + i];
+  }
   red[r][c] = s;
   __syncthreads();
   if (r == 0 && i < n) {
-    const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][c];
     out[i] = accumulate ? out[i] + t : t;
   }
 }
 
-// column sums of a bf16 matrix [rows, C] (C even): part[chunk][C]; grid (ceil(C/128), chunks).
-// 256 threads = 64 column pairs x 4 row lanes; each block sums its row chunk, then folds the 4 row lanes in LDS.
+// column sums of a bf16 matrix [rows, C] (C % 8 == 0): part[chunk][C]; grid (ceil(C / 256), chunks).
+// 256 threads = 32 column groups of 8 (one 16-byte load each) x 8 row lanes, two rows in flight per lane; each block sums
+// its row chunk, then folds the 8 row lanes in LDS in a fixed order.
 static __global__ void __launch_bounds__(256) k_colsum_bf16(const bf16_t* __restrict__ in, int64_t rows, int C,
                                                             float* __restrict__ part) {
-  __shared__ float red[4][128];
-  const int cp = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 128 + 2 * cp;
+  __shared__ float red[8][256 + 8];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 256 + 8 * cg;
   const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
   const int64_t t0 = per * blockIdx.y, t1 = t0 + per < rows ? t0 + per : rows;
-  float s0 = 0.f, s1 = 0.f;
-  if (c < C)
-    for (int64_t t = t0 + rl; t < t1; t += 4) {
-      const uint32_t v = *(const uint32_t*)(in + t * C + c);
-      s0 += __uint_as_float(v << 16);
-      s1 += __uint_as_float(v & 0xffff0000u);
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  auto add = [&](const uint4& v) {
+    s[0] += __uint_as_float(v.x << 16); s[1] += __uint_as_float(v.x & 0xffff0000u);
+    s[2] += __uint_as_float(v.y << 16); s[3] += __uint_as_float(v.y & 0xffff0000u);
+    s[4] += __uint_as_float(v.z << 16); s[5] += __uint_as_float(v.z & 0xffff0000u);
+    s[6] += __uint_as_float(v.w << 16); s[7] += __uint_as_float(v.w & 0xffff0000u);
+  };
+  if (c < C) {
+    int64_t t = t0 + rl;
+    for (; t + 8 < t1; t += 16) {
+      const uint4 a = *(const uint4*)(in + t * C + c), b = *(const uint4*)(in + (t + 8) * C + c);
+      add(a); add(b);
     }
-  red[rl][2 * cp] = s0;
-  red[rl][2 * cp + 1] = s1;
+    for (; t < t1; t += 8) add(*(const uint4*)(in + t * C + c));
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl][8 * cg + j] = s[j];
   __syncthreads();
-  if (threadIdx.x < 128 && blockIdx.x * 128 + threadIdx.x < C)
-    part[(int64_t)blockIdx.y * C + blockIdx.x * 128 + threadIdx.x] =
-        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+    part[(int64_t)blockIdx.y * C + cc] = t;
+  }
 }
 
 // dst[cu[b], :] = src[b, :] for b < B (dst pre-zeroed): scatter CLS-row gradients into a [rows, H] matrix

@@ -206,6 +206,15 @@ int convdr_encoder_backward(const convdr_encoder_config* cfg, const convdr_encod
                             size_t workspace_bytes, const float* d_out, const convdr_encoder_grads* grads,
                             convdr_stream_t stream);
 
+/* One weight gradient of the backward above, exposed for parity tests at arbitrary shapes:
+ *   dW[n, k] += sum_t dy[t, n] * x[t, k]     (what autograd's Linear backward computes for
+ *   /root/reference/drivers/run_convdr_train.py:178; dy / x bf16 row-major with row strides ld_dy / ld_x, fp32 out)
+ * straight from the token-major operands (TN MFMA engine, csrc/gemm_tn.hpp).  N, K and the strides are multiples of 8.
+ * slab: fp32 scratch of slab_elems >= N * K elements (more lets the contraction be split across more workgroups; the
+ * slices are summed in a fixed order: deterministic). */
+int convdr_wgrad(const void* dy, int N, int64_t ld_dy, const void* x, int K, int64_t ld_x, int64_t rows, float* slab,
+                 size_t slab_elems, float* dW, convdr_stream_t stream);
+
 /* Gradient all-reduce under the backward (replaces what DistributedDataParallel's bucket hooks do for
  * /root/reference/drivers/run_convdr_train.py:52,178): makes `stream` wait until every gradient of encoder layer
  * `layer` written by the most recent convdr_encoder_backward on the current device is complete (the layers finish in

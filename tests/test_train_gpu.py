@@ -440,3 +440,27 @@ def test_backward_at_256_tile_scale_matches_autograd():
             _compare(n, p.grad, ref[n])
             checked += 1
     assert checked >= 20
+
+
+@pytest.mark.parametrize("rows,N,K,pad", [(1000, 128, 256, 0), (77, 72, 40, 8), (4100, 768, 384, 0), (64, 8, 8, 0), (1, 136, 264, 16),
+                                          (9001, 2304, 768, 0), (333, 264, 520, 8), (40000, 256, 320, 0)])
+def test_wgrad_tn_engine_matches_fp64(rows, N, K, pad):
+    """convdr_wgrad (csrc/gemm_tn.hpp: contraction over the rows, transposing LDS fragment reads) against the fp64
+    product of the same bf16 operands: ragged tile edges, row strides > width, 128- and 256-wide tiles, the sliced
+    contraction (>= 512 K steps with slab room), accumulation into dW."""
+    import ctypes as C
+    from convdr_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(rows + N)
+    dy_full = torch.randn(rows, N + pad, device="cuda", generator=g).to(torch.bfloat16)
+    x_full = torch.randn(rows, K + pad, device="cuda", generator=g).to(torch.bfloat16)
+    dy, x = dy_full[:, :N], x_full[:, :K]
+    ref = (dy.double().t() @ x.double())
+    for slab_mult in (1, 7):
+        slab = torch.full((slab_mult * N * K,), float("nan"), device="cuda")      # every slab element read must have been written
+        dW = torch.ones(N, K, device="cuda")                                       # += semantics
+        _lib.check(L.convdr_wgrad(_lib.ptr(dy_full), N, N + pad, _lib.ptr(x_full), K, K + pad, rows, _lib.ptr(slab),
+                                  slab.numel(), _lib.ptr(dW), _lib.stream_ptr()), "convdr_wgrad")
+        err = (dW.double() - 1 - ref).abs().max().item()
+        bound = 4e-6 * (dy.double().abs().t() @ x.double().abs()).max().item() + 1e-6
+        assert err < bound, "slab x%d: max error %.3e (bound %.3e)" % (slab_mult, err, bound)
