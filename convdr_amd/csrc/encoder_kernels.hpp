@@ -194,7 +194,7 @@ static __global__ void __launch_bounds__(256) k_gather_cls(const int32_t* __rest
 // ---------------------------------------------------------------------------------------------
 enum { EPI_BF16 = 0, EPI_GELU_BF16 = 1, EPI_RESID_F32 = 2, EPI_QKV = 3, EPI_F32 = 4,
        EPI_GELU_SAVE = 5,   // training FFN1: Cb = gelu(y) and Cb2 = y (pre-activation, for the backward)
-       EPI_DGELU_BF16 = 6,  // backward of FFN1's activation: Cb = acc * gelu'(R[t, f])
+       EPI_DGELU_BF16 = 6,  // backward of FFN1's activation: Cb = bf16(acc) * gelu'(R[t, f])
        EPI_SLAB_F32 = 7 };  // wgrad partial: Cf[split][rows][N] = acc (no bias)
 
 struct GemmArgs {
@@ -288,8 +288,13 @@ struct CTile {
   // Thread t owns 16-byte chunk t % CH of rows t / CH + 16 i: all LDS reads are issued before the first store, the
   // per-iteration row offsets are compile-time, and a tile that lies fully inside the matrix takes no bound checks
   // (the store tail was issue-bound: 325 cycles per store with the generic index arithmetic, measured by s_memtime).
+  // DGELU: the parked values are multiplied by gelu'(aux) on their way out, aux = the bf16 element at the same [row, col]
+  // of a second matrix `aux_delta` BYTES away from dst (EPI_DGELU_BF16: the saved FFN1 pre-activation).  Here a thread
+  // owns 8 consecutive columns of a row, so the aux tile is read in whole 512-byte rows; in the accumulator layout of the
+  // epilogue proper the same reads were 8-byte pieces of 32 different rows per instruction.
+  template <bool DGELU = false>
   __device__ static __forceinline__ void store(Base sC, int pass, bf16_t* dst, int64_t ld, int64_t row_limit,
-                                               int64_t col_limit, int tid) {
+                                               int64_t col_limit, int tid, int64_t aux_delta = 0) {
     constexpr int RPI = T::THREADS / CH;   // rows covered per iteration
     constexpr int BATCH = 4;               // LDS reads in flight before their stores (16 VGPRs; the kernel is at the cap)
     static_assert(RPI * CH == T::THREADS && (32 * NTP) % RPI == 0 && ROWS % RPI == 0 && STORES_PER_WAVE % BATCH == 0 &&
@@ -308,6 +313,28 @@ struct CTile {
         return (row >= HALF ? sC.hi : sC.lo) + addr((row >= HALF ? row - HALF : row) + r0, c);
       };
       lds_read4_b128_hidden(at(i0 + 0), at(i0 + 1), at(i0 + 2), at(i0 + 3), v[0], v[1], v[2], v[3]);
+      if constexpr (DGELU) {
+        u32x4_t r[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+          constexpr int blk = 32 * NTP;
+          const int i = i0 + j;
+          const int rowc = ((i * RPI) / blk * T::NT + pass * NTP) * 32 + (i * RPI) % blk;
+          const bool ok = inside || (rowc + r0 < row_limit && nv >= 8);
+          r[j] = ok ? *(const u32x4_t*)((const char*)(p + (int64_t)rowc * ld) + aux_delta) : (u32x4_t){0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+          const uint32_t* pv = (const uint32_t*)&v[j];
+          const uint32_t* pa = (const uint32_t*)&r[j];
+          uint32_t o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            o[q] = pack_bf16x2(__uint_as_float(pv[q] << 16) * gelu_grad(__uint_as_float(pa[q] << 16)),
+                               __uint_as_float(pv[q] & 0xffff0000u) * gelu_grad(__uint_as_float(pa[q] & 0xffff0000u)));
+          v[j] = (u32x4_t){o[0], o[1], o[2], o[3]};
+        }
+      }
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         constexpr int blk = 32 * NTP;
@@ -539,8 +566,8 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
             const bool t_ok = t < a.rows;
             const int64_t tc = t_ok ? t : a.rows - 1;
             uint2 res[T::MT][4];
-            if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_DGELU_BF16) {
-              if (EPI == EPI_DGELU_BF16 || a.Rf == nullptr) {
+            if constexpr (EPI == EPI_RESID_F32) {
+              if (a.Rf == nullptr) {
 #pragma unroll
                 for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
@@ -563,11 +590,6 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                   if (out == 0) {
                     y0 = gelu_tail(y0); y1 = gelu_tail(y1); y2 = gelu_tail(y2); y3 = gelu_tail(y3);
                   }
-                }
-                if constexpr (EPI == EPI_DGELU_BF16) {
-                  const uint2 r = res[mt][g];
-                  y0 *= gelu_grad(__uint_as_float(r.x << 16)); y1 *= gelu_grad(__uint_as_float(r.x & 0xffff0000u));
-                  y2 *= gelu_grad(__uint_as_float(r.y << 16)); y3 *= gelu_grad(__uint_as_float(r.y & 0xffff0000u));
                 }
                 if constexpr (EPI == EPI_RESID_F32) {
                   if (a.Rf) {
@@ -609,7 +631,11 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                 bf16_t* dst = na < a.H ? a.Qo + t0 * a.H + na : a.Ko + t0 * a.H + (na - a.H);
                 CT::store(sC, pass, dst, a.H, a.rows - t0, T::TR, tid_e);
               } else {
-                CT::store(sC, pass, a.dbg_skip_epi == 4 ? a.Cb : (out ? a.Cb2 : a.Cb) + t0 * a.N + n0, a.N, a.rows - t0, a.N - n0, tid_e);
+                if constexpr (EPI == EPI_DGELU_BF16)   // x gelu'(pre-activation), applied in the store layout
+                  CT::template store<true>(sC, pass, a.Cb + t0 * a.N + n0, a.N, a.rows - t0, a.N - n0, tid_e,
+                                           (int64_t)((const char*)a.R - (const char*)a.Cb));
+                else
+                  CT::store(sC, pass, a.dbg_skip_epi == 4 ? a.Cb : (out ? a.Cb2 : a.Cb) + t0 * a.N + n0, a.N, a.rows - t0, a.N - n0, tid_e);
               }
             }
             CONVDR_TRACE(6 + 4 * pass)

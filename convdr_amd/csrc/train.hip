@@ -30,13 +30,14 @@ struct TrainBufs {
   // backward scratch
   float *G0, *G1, *Drow, *slab, *part, *dcls_y, *dcls_f, *dhead_y;
   bf16_t *dctx, *dctx_t, *dhead_yb, *dclsb;
+  bf16_t *dXb1, *dXb2;   // dgrad outputs of FFN1 / the QKV projection (added to the fp32 stream by the next LayerNorm backward)
   int64_t ldt, Tp;
   size_t slab_elems;
   size_t total;
 };
 
 constexpr int TRAIN_MAX_LAYERS = 48;
-constexpr int LN_BWD_BLOCKS = 256;
+constexpr int LN_BWD_BLOCKS = 1024;
 constexpr size_t SLAB_ELEMS = (size_t)16 * 3072 * 768;  // >= splits * N * K for every weight of a base-size model
 
 struct TrainPlan {
@@ -93,6 +94,8 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
     g.dYb2 = (bf16_t*)take(rs * H * 2);
     g.dQKV = (bf16_t*)take(rs * 3 * H * 2);
   }
+  p.dXb1 = (bf16_t*)take(rs * H * 2);
+  p.dXb2 = (bf16_t*)take(rs * H * 2);
   p.dctx = (bf16_t*)take(rs * H * 2);
   p.dctx_t = (bf16_t*)take((size_t)H * p.ldt * 2);
   p.dhead_yb = (bf16_t*)take(Bp * E * 2);
@@ -261,14 +264,14 @@ static int bias_grad(const bf16_t* dY, int64_t rows, int C, const TrainBufs& p, 
   return 0;
 }
 
-// LayerNorm backward of `rows` rows; dbias (optional) = gradient of the bias of the dense layer that feeds this
+// LayerNorm backward of `rows` rows, incoming gradient dY (fp32) + dYadd (bf16, optional); dbias (optional) = gradient of the bias of the dense layer that feeds this
 // LayerNorm (= column sums of dX).  The three parameter gradients are finished by one launch when they are adjacent in
 // the gradient arena (dbias, dgamma, dbeta -- train.py:_tower_params order), else by one launch each.
-static int ln_bwd(const float* dY, const float* Yin, int64_t rows, int H, const float* g, float eps, float* dXf, bf16_t* dXb,
-                  const TrainBufs& p, float* dbias, float* dgamma, float* dbeta, hipStream_t st) {
+static int ln_bwd(const float* dY, const bf16_t* dYadd, const float* Yin, int64_t rows, int H, const float* g, float eps, float* dXf,
+                  bf16_t* dXb, const TrainBufs& p, float* dbias, float* dgamma, float* dbeta, hipStream_t st) {
   const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
   ProfScope prof("layernorm_bwd", st);
-  hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, Yin, rows, H, g, eps, dXf, dXb, p.part);
+  hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, dYadd, Yin, rows, H, g, eps, dXf, dXb, p.part);
   CONVDR_CHECK_LAUNCH("k_layernorm_bwd");
   if (dbias && dgamma == dbias + H && dbeta == dgamma + H) {
     hipLaunchKernelGGL(k_reduce_partials_small, dim3((3 * H + 15) / 16), dim3(256), 0, st, p.part, blocks, (int64_t)3 * H,
@@ -385,7 +388,7 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
   // ---- head: out = LayerNorm(head_y), head_y = cls_b . head_w^T + head_b ----
   if (cfg->out_dim > 0) {
     const int E = cfg->out_dim;
-    if (int e = ln_bwd(d_out, p.head_y, B, E, w->head_ln_g, cfg->head_ln_eps, p.dhead_y, p.dhead_yb, p, gr->head_b,
+    if (int e = ln_bwd(d_out, nullptr, p.head_y, B, E, w->head_ln_g, cfg->head_ln_eps, p.dhead_y, p.dhead_yb, p, gr->head_b,
                        gr->head_ln_g, gr->head_ln_b, st))
       return e;
     // d cls = d head_y . head_w : dgrad with the transposed head weight [H, E]
@@ -398,7 +401,7 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
   }
   // ---- last layer's LayerNorm2 on the CLS rows only, scattered into a zero [rows, H] gradient ----
   // (its dbias output is the last layer's FFN2 bias gradient: only the CLS rows of that layer carry gradient)
-  if (int e = ln_bwd(dcls, p.cls_y, B, H, w->layers[NL - 1].ln2_g, cfg->ln_eps, p.dcls_y, (bf16_t*)nullptr, p, lg_last->b2,
+  if (int e = ln_bwd(dcls, nullptr, p.cls_y, B, H, w->layers[NL - 1].ln2_g, cfg->ln_eps, p.dcls_y, (bf16_t*)nullptr, p, lg_last->b2,
                      lg_last->ln2_g, lg_last->ln2_b, st))
     return e;
   CONVDR_CHECK_HIP(hipMemsetAsync(p.G0, 0, (size_t)rows * H * 4, st));
@@ -409,8 +412,10 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
   static const bool fork_wgrad = !(getenv("CONVDR_NO_WGRAD_FORK") && atoi(getenv("CONVDR_NO_WGRAD_FORK")));
   if (int e = wf.init(st)) return e;
   hipStream_t ss = fork_wgrad ? wf.side : st;   // stream of the weight-gradient branches
-  float* A = p.G0;   // holds the gradient flowing down the residual stream
-  float* Bf = p.G1;  // scratch
+  // The gradient flowing down the residual stream is cur_f (fp32) + cur_b (bf16 dgrad tile output, or null)
+  float* cur_f = p.G0;
+  const bf16_t* cur_b = nullptr;
+  float* other = p.G1;
   for (int l = NL - 1; l >= 0; --l) {
     const convdr_layer_weights* lw = &w->layers[l];
     const convdr_layer_weights_t* lt = &wt[l];
@@ -418,26 +423,30 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     const LayerSave& s = P.layers[l];
     const LayerBwd& d = P.bwd[l];
     const bool last = l == NL - 1;
-    // A = d(pre-LN2 sum Y2) for the last layer (CLS rows only), d(layer output) otherwise
-    float *dY2, *dX1, *dY1, *dXin;
+    // d(pre-LN2 sum Y2): for the last layer cur_f already is that (CLS rows only), else LayerNorm2 backward
+    float* dY2;
     if (!last) {
-      if (int e = ln_bwd(A, s.Y2, rows, H, lw->ln2_g, cfg->ln_eps, Bf, d.dYb, p, lg->b2, lg->ln2_g, lg->ln2_b, st)) return e;
-      dY2 = Bf; dX1 = A; dY1 = Bf; dXin = A;
+      if (int e = ln_bwd(cur_f, cur_b, s.Y2, rows, H, lw->ln2_g, cfg->ln_eps, other, d.dYb, p, lg->b2, lg->ln2_g, lg->ln2_b, st))
+        return e;
+      dY2 = other; other = cur_f;
     } else {
-      hipLaunchKernelGGL(k_cast_f32_bf16, dim3(1024), dim3(256), 0, st, A, d.dYb, (int64_t)rows * H / 4);
+      hipLaunchKernelGGL(k_cast_f32_bf16, dim3(1024), dim3(256), 0, st, cur_f, d.dYb, (int64_t)rows * H / 4);
       CONVDR_CHECK_LAUNCH("k_cast_f32_bf16");
-      dY2 = A; dX1 = Bf; dY1 = A; dXin = Bf;
+      dY2 = cur_f;
     }
     // ---- FFN2: Y2 = Hm W2^T + b2 + X1:  dHpre = (dY2 W2) * gelu'(Hpre) ----
     GemmArgs g{};
     g.rows = rows; g.W = (const bf16_t*)lt->w2_t; g.X = d.dYb; g.N = I; g.K = H; g.Cb = d.dHpre; g.R = s.Hpre;
     if (int e = launch_gemm<EPI_DGELU_BF16>(g, st, "gemm_dgrad")) return e;
-    // ---- FFN1: Hpre = X1 W1^T + b1;  dX1 = dHpre W1 + dY2 (residual branch, fp32) ----
+    // ---- FFN1: Hpre = X1 W1^T + b1;  dX1 = dHpre W1 (bf16 tile output) + dY2 (residual branch, fp32) ----
     g = GemmArgs{};
-    g.rows = rows; g.W = (const bf16_t*)lt->w1_t; g.X = d.dHpre; g.N = H; g.K = I; g.Cf = dX1; g.Rf = dY2;
-    if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_dgrad")) return e;
-    // ---- LayerNorm1 ----
-    if (int e = ln_bwd(dX1, s.Y1, rows, H, lw->ln1_g, cfg->ln_eps, dY1, d.dYb2, p, lg->bo, lg->ln1_g, lg->ln1_b, st)) return e;
+    g.rows = rows; g.W = (const bf16_t*)lt->w1_t; g.X = d.dHpre; g.N = H; g.K = I; g.Cb = p.dXb1;
+    if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
+    // ---- LayerNorm1: dY1 = LN'(dY2 + dXb1) ----
+    float* dY1 = other;
+    if (int e = ln_bwd(dY2, p.dXb1, s.Y1, rows, H, lw->ln1_g, cfg->ln_eps, dY1, d.dYb2, p, lg->bo, lg->ln1_g, lg->ln1_b, st))
+      return e;
+    other = dY2;
     // ---- attention output projection: Y1 = ctx Wo^T + bo + Xin ----
     g = GemmArgs{};
     g.rows = rows; g.W = (const bf16_t*)lt->wo_t; g.X = d.dYb2; g.N = H; g.K = H; g.Cb = p.dctx;
@@ -471,18 +480,18 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
                                   {d.dYb2, H, H, s.ctx, H, H, lg->wo}};         // Y1 = ctx Wo^T
       if (int e = wgrad_batch(items, 4, rows, p.slab, p.slab_elems, ss)) return e;
     }
-    // ---- QKV projection: QKV = Xin Wqkv^T + bqkv;  dXin = dQKV Wqkv + dY1 (residual branch, fp32) ----
+    // ---- QKV projection: QKV = Xin Wqkv^T + bqkv;  dXin = dQKV Wqkv (bf16 tile output) + dY1 (residual branch, fp32) ----
     g = GemmArgs{};
-    g.rows = rows; g.W = (const bf16_t*)lt->wqkv_t; g.X = d.dQKV; g.N = H; g.K = 3 * H; g.Cf = dXin; g.Rf = dY1;
-    if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_dgrad")) return e;
-    if (dXin != A) { float* t = A; A = Bf; Bf = t; }   // A again holds the stream gradient (now d Xin = d output of layer l-1)
+    g.rows = rows; g.W = (const bf16_t*)lt->wqkv_t; g.X = d.dQKV; g.N = H; g.K = 3 * H; g.Cb = p.dXb2;
+    if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
+    cur_f = dY1; cur_b = p.dXb2;   // d(output of layer l - 1) = dY1 + dXb2
     if (int e = wf.layer_done(l, ss)) return e;
   }
   wf.layers_recorded = NL;
   // ---- embeddings ----
   {
     const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
-    hipLaunchKernelGGL(k_embed_bwd, dim3(blocks), dim3(256), 0, st, A, p.tok_id, p.tok_pos, rows, H, w->word_emb, w->pos_emb,
+    hipLaunchKernelGGL(k_embed_bwd, dim3(blocks), dim3(256), 0, st, cur_f, cur_b, p.tok_id, p.tok_pos, rows, H, w->word_emb, w->pos_emb,
                        w->type_emb, w->emb_ln_g, cfg->ln_eps, gr->word_emb, gr->pos_emb, p.part);
     CONVDR_CHECK_LAUNCH("k_embed_bwd");
     float* outs[3] = {gr->emb_ln_g, gr->emb_ln_b, gr->type_emb};

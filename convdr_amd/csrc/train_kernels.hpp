@@ -75,7 +75,21 @@ __global__ void __launch_bounds__(256) k_transpose_f32_bf16(const float* __restr
 // [dense.bias, LayerNorm.weight, LayerNorm.bias] adjacent, so one k_reduce_partials_small launch finishes all three
 // (fixed order: deterministic).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__ dY, const float* __restrict__ Yin,
+// The incoming gradient is dYa (fp32, optional) + dYb (bf16, optional): the residual stream stays fp32 while the
+// branch that comes out of a dgrad GEMM arrives as that GEMM's bf16 tile output (whole-row stores) instead of being
+// added inside its epilogue (16-byte pieces of 32 rows per instruction, read and written in fp32).
+__device__ __forceinline__ float4 grad_in(const float* __restrict__ a, const bf16_t* __restrict__ b, int64_t off) {
+  float4 d = a ? *(const float4*)(a + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (b) {
+    const uint2 v = *(const uint2*)(b + off);
+    d.x += __uint_as_float(v.x << 16); d.y += __uint_as_float(v.x & 0xffff0000u);
+    d.z += __uint_as_float(v.y << 16); d.w += __uint_as_float(v.y & 0xffff0000u);
+  }
+  return d;
+}
+
+__global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__ dY, const bf16_t* __restrict__ dYb,
+                                                       const float* __restrict__ Yin,
                                                        int64_t rows, int H, const float* __restrict__ g, float eps,
                                                        float* __restrict__ dXf, bf16_t* __restrict__ dXb,
                                                        float* __restrict__ part) {
@@ -92,7 +106,7 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
       const int e0 = 256 * j + 4 * lane;
       if (e0 < H) {
         y[j] = *(const float4*)(Yin + row * H + e0);
-        d[j] = *(const float4*)(dY + row * H + e0);
+        d[j] = grad_in(dY, dYb, row * H + e0);
         s += y[j].x + y[j].y + y[j].z + y[j].w;
       }
     }
@@ -269,7 +283,8 @@ __global__ void __launch_bounds__(256) k_scatter_cls(const int32_t* __restrict__
 // d_word[id], d_pos[p]; d_type[0] and the LayerNorm dgamma / dbeta go through per-block partials.
 // part[block][3][H] = (dgamma, dbeta, dtype0)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_embed_bwd(const float* __restrict__ dX, const int32_t* __restrict__ tok_id,
+__global__ void __launch_bounds__(256) k_embed_bwd(const float* __restrict__ dX, const bf16_t* __restrict__ dXb,
+                                                   const int32_t* __restrict__ tok_id,
                                                    const int32_t* __restrict__ tok_pos, int64_t rows, int H,
                                                    const float* __restrict__ word, const float* __restrict__ pos,
                                                    const float* __restrict__ type0, const float* __restrict__ g,
@@ -293,7 +308,7 @@ __global__ void __launch_bounds__(256) k_embed_bwd(const float* __restrict__ dX,
         const float4 a = *(const float4*)(word + (int64_t)id * H + e0), c = *(const float4*)(pos + (int64_t)pp * H + e0),
                      t = *(const float4*)(type0 + e0);
         y[j] = make_float4(a.x + c.x + t.x, a.y + c.y + t.y, a.z + c.z + t.z, a.w + c.w + t.w);
-        d[j] = *(const float4*)(dX + row * H + e0);
+        d[j] = grad_in(dX, dXb, row * H + e0);
         s += y[j].x + y[j].y + y[j].z + y[j].w;
       }
     }

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Per-stream timeline summary of the LAST `k_adamw_hf`-delimited training step in a rocprofv3 rocpd database
+(`rocprofv3 --kernel-trace`): wall span, busy time per queue/stream, idle gaps on the busiest one, top kernels.
+
+    python tools/train_timeline.py gpurun_out/x/prof_kd/..._results.db
+"""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    qcol = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
+    print("# columns:", cols)
+    rows = db.execute("select name, start, end, %s from kernels order by start" % (qcol or "0")).fetchall()
+    ends = [i for i, r in enumerate(rows) if "k_adamw_hf" in r[0]]
+    if len(ends) < 2:
+        print("fewer than two optimizer steps in the trace")
+        return
+    a, b = ends[-2] + 1, ends[-1] + 1
+    step = rows[a:b]
+    t0, t1 = step[0][1], max(r[2] for r in step)
+    print("step: %d kernels, wall %.3f ms" % (len(step), (t1 - t0) / 1e6))
+    per_q = defaultdict(list)
+    for n, s, e, q in step:
+        per_q[q].append((s, e, n))
+    for q, ks in sorted(per_q.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
+        busy = sum(e - s for s, e, _ in ks)
+        gaps = [ks[i + 1][0] - ks[i][1] for i in range(len(ks) - 1)]
+        pos = [g for g in gaps if g > 0]
+        print("queue %s: %4d kernels, busy %.3f ms, span %.3f ms, positive gaps %d (sum %.3f ms, median %.2f us)" % (
+            q, len(ks), busy / 1e6, (ks[-1][1] - ks[0][0]) / 1e6, len(pos), sum(pos) / 1e6,
+            (sorted(pos)[len(pos) // 2] / 1e3) if pos else 0.0))
+    agg = defaultdict(lambda: [0, 0])
+    for n, s, e, q in step:
+        agg[n[:70]][0] += 1
+        agg[n[:70]][1] += e - s
+    print("top kernels of the step:")
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+        print("  %-70s %4d %9.1f us  avg %7.1f" % (n, c, t / 1e3, t / 1e3 / c))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
