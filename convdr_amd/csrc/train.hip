@@ -19,6 +19,9 @@ struct LayerSave {
 // branch runs on its own stream, whole layers behind the activation-gradient chain, and must never be waited for)
 struct LayerBwd {
   bf16_t *dYb, *dHpre, *dYb2, *dQKV;
+  // per-block partial sums, finished by one k_reduce_multi launch on the weight-gradient stream:
+  // LayerNorm 2 / 1 backward [blocks][3][H] (dense bias, gamma, beta), bias column sums of FFN1 [chunks][I] and QKV [chunks][3H]
+  float *part_ln2, *part_ln1, *part_b1, *part_bqkv;
 };
 
 struct TrainBufs {
@@ -37,7 +40,8 @@ struct TrainBufs {
 };
 
 constexpr int TRAIN_MAX_LAYERS = 48;
-constexpr int LN_BWD_BLOCKS = 1024;
+constexpr int LN_BWD_BLOCKS = 512;
+constexpr int COLSUM_CHUNKS = 64;
 constexpr size_t SLAB_ELEMS = (size_t)16 * 3072 * 768;  // >= splits * N * K for every weight of a base-size model
 
 struct TrainPlan {
@@ -83,7 +87,7 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
   p.Drow = (float*)take((size_t)c->heads * p.ldt * 4);
   p.slab_elems = SLAB_ELEMS;
   p.slab = (float*)take(p.slab_elems * 4);
-  p.part = (float*)take((size_t)LN_BWD_BLOCKS * 3 * 3072 * 4 + (size_t)64 * 3 * 3072 * 4);
+  p.part = (float*)take((size_t)LN_BWD_BLOCKS * 3 * 1024 * 4);   // head / CLS LayerNorm, embeddings
   p.dcls_y = (float*)take(Bp * H * 4);
   p.dcls_f = (float*)take(Bp * H * 4);
   p.dhead_y = (float*)take(Bp * E * 4);
@@ -93,6 +97,10 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
     g.dHpre = (bf16_t*)take(rs * I * 2);
     g.dYb2 = (bf16_t*)take(rs * H * 2);
     g.dQKV = (bf16_t*)take(rs * 3 * H * 2);
+    g.part_ln2 = (float*)take((size_t)LN_BWD_BLOCKS * 3 * H * 4);
+    g.part_ln1 = (float*)take((size_t)LN_BWD_BLOCKS * 3 * H * 4);
+    g.part_b1 = (float*)take((size_t)COLSUM_CHUNKS * I * 4);
+    g.part_bqkv = (float*)take((size_t)COLSUM_CHUNKS * 3 * H * 4);
   }
   p.dXb1 = (bf16_t*)take(rs * H * 2);
   p.dXb2 = (bf16_t*)take(rs * H * 2);
@@ -253,38 +261,57 @@ static int wgrad(const bf16_t* dY, int N, int64_t ld_dy, const bf16_t* X, int K,
   return wgrad_batch(&it, 1, rows, p.slab, p.slab_elems, st);
 }
 
-static int bias_grad(const bf16_t* dY, int64_t rows, int C, const TrainBufs& p, float* db, hipStream_t st) {
-  CONVDR_REQUIRE(C % 8 == 0, "bias_grad: C %% 8 != 0 (%d)", C);
-  float* part = p.part + (size_t)LN_BWD_BLOCKS * 3 * 3072;
-  const int chunks = rows >= 2048 ? 64 : 8;
-  hipLaunchKernelGGL(k_colsum_bf16, dim3((C + 255) / 256, chunks), dim3(256), 0, st, dY, rows, C, part);
-  CONVDR_CHECK_LAUNCH("k_colsum_bf16");
-  hipLaunchKernelGGL(k_reduce_partials_small, dim3((C + 15) / 16), dim3(256), 0, st, part, chunks, (int64_t)C, (int64_t)C, db, 1);
-  CONVDR_CHECK_LAUNCH("k_reduce_partials(bias)");
+static int colsum_chunks(int64_t rows) { return rows >= 2048 ? COLSUM_CHUNKS : 8; }
+
+// LayerNorm backward of `rows` rows, incoming gradient dY (fp32) + dYadd (bf16, optional).  Partial sums of
+// (dense bias = column sums of dX, dgamma, dbeta) go to part[blocks][3][H]; returns the number of blocks.
+static int ln_bwd_kernel(const float* dY, const bf16_t* dYadd, const float* Yin, int64_t rows, int H, const float* g, float eps,
+                         float* dXf, bf16_t* dXb, float* part, int* blocks_out, hipStream_t st) {
+  const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
+  ProfScope prof("layernorm_bwd", st);
+  hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, dYadd, Yin, rows, H, g, eps, dXf, dXb, part);
+  CONVDR_CHECK_LAUNCH("k_layernorm_bwd");
+  *blocks_out = blocks;
   return 0;
 }
 
-// LayerNorm backward of `rows` rows, incoming gradient dY (fp32) + dYadd (bf16, optional); dbias (optional) = gradient of the bias of the dense layer that feeds this
-// LayerNorm (= column sums of dX).  The three parameter gradients are finished by one launch when they are adjacent in
-// the gradient arena (dbias, dgamma, dbeta -- train.py:_tower_params order), else by one launch each.
+struct ReduceList {
+  ReduceJobs a{};
+  int blocks = 0;
+  // out[0 .. n) += sum over nparts of part[p * stride + .]
+  void add(const float* part, int nparts, int64_t stride, int n, float* out) {
+    ReduceJob& q = a.j[a.count++];
+    q.part = part; q.out = out; q.stride = stride; q.nparts = nparts; q.n = n;
+    blocks += (n + 15) / 16;
+    q.block_end = blocks;
+  }
+  // the three parameter gradients of a LayerNorm backward: one job when they are adjacent in the gradient arena
+  // (dbias, dgamma, dbeta -- train.py:_tower_params order), else one job each
+  void add_ln(const float* part, int blocks_ln, int H, float* dbias, float* dgamma, float* dbeta) {
+    if (dbias && dgamma == dbias + H && dbeta == dgamma + H) {
+      add(part, blocks_ln, (int64_t)3 * H, 3 * H, dbias);
+    } else {
+      float* outs[3] = {dbias, dgamma, dbeta};
+      for (int k = 0; k < 3; ++k)
+        if (outs[k]) add(part + (size_t)k * H, blocks_ln, (int64_t)3 * H, H, outs[k]);
+    }
+  }
+  int launch(hipStream_t st) {
+    if (!a.count) return 0;
+    hipLaunchKernelGGL(k_reduce_multi, dim3(blocks), dim3(256), 0, st, a);
+    CONVDR_CHECK_LAUNCH("k_reduce_multi");
+    return 0;
+  }
+};
+
+// LayerNorm backward whose parameter gradients are finished at once on the same stream (head / CLS rows)
 static int ln_bwd(const float* dY, const bf16_t* dYadd, const float* Yin, int64_t rows, int H, const float* g, float eps, float* dXf,
                   bf16_t* dXb, const TrainBufs& p, float* dbias, float* dgamma, float* dbeta, hipStream_t st) {
-  const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
-  ProfScope prof("layernorm_bwd", st);
-  hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, dYadd, Yin, rows, H, g, eps, dXf, dXb, p.part);
-  CONVDR_CHECK_LAUNCH("k_layernorm_bwd");
-  if (dbias && dgamma == dbias + H && dbeta == dgamma + H) {
-    hipLaunchKernelGGL(k_reduce_partials_small, dim3((3 * H + 15) / 16), dim3(256), 0, st, p.part, blocks, (int64_t)3 * H,
-                       (int64_t)3 * H, dbias, 1);
-  } else {
-    float* outs[3] = {dbias, dgamma, dbeta};
-    for (int k = 0; k < 3; ++k)
-      if (outs[k])
-        hipLaunchKernelGGL(k_reduce_partials_small, dim3((H + 15) / 16), dim3(256), 0, st, p.part + (size_t)k * H, blocks,
-                           (int64_t)3 * H, (int64_t)H, outs[k], 1);
-  }
-  CONVDR_CHECK_LAUNCH("k_reduce_partials(ln)");
-  return 0;
+  int blocks = 0;
+  if (int e = ln_bwd_kernel(dY, dYadd, Yin, rows, H, g, eps, dXf, dXb, p.part, &blocks, st)) return e;
+  ReduceList r;
+  r.add_ln(p.part, blocks, H, dbias, dgamma, dbeta);
+  return r.launch(st);
 }
 
 }  // namespace convdr
@@ -415,6 +442,8 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
   // The gradient flowing down the residual stream is cur_f (fp32) + cur_b (bf16 dgrad tile output, or null)
   float* cur_f = p.G0;
   const bf16_t* cur_b = nullptr;
+  const int chunks = colsum_chunks(rows);
+  CONVDR_REQUIRE(I % 8 == 0 && H % 8 == 0, "train: hidden / intermediate %% 8 != 0");
   float* other = p.G1;
   for (int l = NL - 1; l >= 0; --l) {
     const convdr_layer_weights* lw = &w->layers[l];
@@ -425,8 +454,9 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     const bool last = l == NL - 1;
     // d(pre-LN2 sum Y2): for the last layer cur_f already is that (CLS rows only), else LayerNorm2 backward
     float* dY2;
+    int blocks_ln2 = 0, blocks_ln1 = 0;
     if (!last) {
-      if (int e = ln_bwd(cur_f, cur_b, s.Y2, rows, H, lw->ln2_g, cfg->ln_eps, other, d.dYb, p, lg->b2, lg->ln2_g, lg->ln2_b, st))
+      if (int e = ln_bwd_kernel(cur_f, cur_b, s.Y2, rows, H, lw->ln2_g, cfg->ln_eps, other, d.dYb, d.part_ln2, &blocks_ln2, st))
         return e;
       dY2 = other; other = cur_f;
     } else {
@@ -436,15 +466,20 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     }
     // ---- FFN2: Y2 = Hm W2^T + b2 + X1:  dHpre = (dY2 W2) * gelu'(Hpre) ----
     GemmArgs g{};
-    g.rows = rows; g.W = (const bf16_t*)lt->w2_t; g.X = d.dYb; g.N = I; g.K = H; g.Cb = d.dHpre; g.R = s.Hpre;
-    if (int e = launch_gemm<EPI_DGELU_BF16>(g, st, "gemm_dgrad")) return e;
+    g.rows = rows; g.W = (const bf16_t*)lt->w2_t; g.X = d.dYb; g.N = I; g.K = H; g.Cb = d.dHpre;
+    if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
+    {
+      ProfScope prof("dgelu_colsum", st);
+      hipLaunchKernelGGL(k_dgelu_colsum, dim3((I + 255) / 256, chunks), dim3(256), 0, st, d.dHpre, s.Hpre, rows, I, d.part_b1);
+      CONVDR_CHECK_LAUNCH("k_dgelu_colsum");
+    }
     // ---- FFN1: Hpre = X1 W1^T + b1;  dX1 = dHpre W1 (bf16 tile output) + dY2 (residual branch, fp32) ----
     g = GemmArgs{};
     g.rows = rows; g.W = (const bf16_t*)lt->w1_t; g.X = d.dHpre; g.N = H; g.K = I; g.Cb = p.dXb1;
     if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
     // ---- LayerNorm1: dY1 = LN'(dY2 + dXb1) ----
     float* dY1 = other;
-    if (int e = ln_bwd(dY2, p.dXb1, s.Y1, rows, H, lw->ln1_g, cfg->ln_eps, dY1, d.dYb2, p, lg->bo, lg->ln1_g, lg->ln1_b, st))
+    if (int e = ln_bwd_kernel(dY2, p.dXb1, s.Y1, rows, H, lw->ln1_g, cfg->ln_eps, dY1, d.dYb2, d.part_ln1, &blocks_ln1, st))
       return e;
     other = dY2;
     // ---- attention output projection: Y1 = ctx Wo^T + bo + Xin ----
@@ -471,8 +506,16 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     // ---- the layer's weight-gradient branch: every operand is complete now; it runs beside the layers below ----
     if (fork_wgrad)
       if (int e = wf.fork()) return e;
-    if (int e = bias_grad(d.dHpre, rows, I, p, lg->b1, ss)) return e;
-    if (int e = bias_grad(d.dQKV, rows, 3 * H, p, lg->bqkv, ss)) return e;
+    {
+      hipLaunchKernelGGL(k_colsum_bf16, dim3((3 * H + 255) / 256, chunks), dim3(256), 0, ss, d.dQKV, rows, 3 * H, d.part_bqkv);
+      CONVDR_CHECK_LAUNCH("k_colsum_bf16");
+      ReduceList r;
+      if (!last) r.add_ln(d.part_ln2, blocks_ln2, H, lg->b2, lg->ln2_g, lg->ln2_b);
+      r.add_ln(d.part_ln1, blocks_ln1, H, lg->bo, lg->ln1_g, lg->ln1_b);
+      r.add(d.part_b1, chunks, I, I, lg->b1);
+      r.add(d.part_bqkv, chunks, 3 * H, 3 * H, lg->bqkv);
+      if (int e = r.launch(ss)) return e;
+    }
     {
       const WgradItem items[4] = {{d.dHpre, I, I, s.X1, H, H, lg->w1},          // Hpre = X1 W1^T
                                   {d.dYb, H, H, s.Hm, I, I, lg->w2},            // Y2 = Hm W2^T
@@ -495,11 +538,9 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
                        w->type_emb, w->emb_ln_g, cfg->ln_eps, gr->word_emb, gr->pos_emb, p.part);
     CONVDR_CHECK_LAUNCH("k_embed_bwd");
     float* outs[3] = {gr->emb_ln_g, gr->emb_ln_b, gr->type_emb};
-    for (int k = 0; k < 3; ++k) {
-      hipLaunchKernelGGL(k_reduce_partials_small, dim3((H + 15) / 16), dim3(256), 0, st, p.part + (size_t)k * H, blocks,
-                         (int64_t)3 * H, (int64_t)H, outs[k], 1);
-    }
-    CONVDR_CHECK_LAUNCH("k_reduce_partials(embed)");
+    ReduceList r;
+    for (int k = 0; k < 3; ++k) r.add(p.part + (size_t)k * H, blocks, (int64_t)3 * H, H, outs[k]);
+    if (int e = r.launch(st)) return e;
   }
   if (fork_wgrad)
     if (int e = wf.join()) return e;   // every weight gradient is complete for whatever follows on `stream`

@@ -268,6 +268,100 @@ static __global__ void __launch_bounds__(256) k_colsum_bf16(const bf16_t* __rest
   }
 }
 
+// FFN1 activation backward fused with the bias column sums:  g[t, c] <- g[t, c] * gelu'(pre[t, c])  (in place: g is the
+// bf16 tile output of the FFN2 dgrad GEMM), part[chunk][C] = column sums of the result (= d b1).  Same geometry as
+// k_colsum_bf16.  As a separate memory-bound pass the ~30 VALU slots per element of gelu' run under the loads; inside
+// the GEMM epilogue they ran with the matrix pipe idle (126 -> ~55 + ~40 us per layer at 9 k rows).
+static __global__ void __launch_bounds__(256) k_dgelu_colsum(bf16_t* __restrict__ g, const bf16_t* __restrict__ pre, int64_t rows,
+                                                             int C, float* __restrict__ part) {
+  __shared__ float red[8][256 + 8];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 256 + 8 * cg;
+  const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+  const int64_t t0 = per * blockIdx.y, t1 = t0 + per < rows ? t0 + per : rows;
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  auto one = [&](const uint4& gv, const uint4& pv, int64_t t) {
+    const uint32_t* a = (const uint32_t*)&gv;
+    const uint32_t* b = (const uint32_t*)&pv;
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float lo = __uint_as_float(a[q] << 16) * gelu_grad(__uint_as_float(b[q] << 16));
+      const float hi = __uint_as_float(a[q] & 0xffff0000u) * gelu_grad(__uint_as_float(b[q] & 0xffff0000u));
+      o[q] = pack_bf16x2(lo, hi);
+      s[2 * q] += __uint_as_float(o[q] << 16);          // sums of the ROUNDED values: db1 matches the operand wgrad reads
+      s[2 * q + 1] += __uint_as_float(o[q] & 0xffff0000u);
+    }
+    *(uint4*)(g + t * C + c) = make_uint4(o[0], o[1], o[2], o[3]);
+  };
+  if (c < C) {
+    int64_t t = t0 + rl;
+    for (; t + 8 < t1; t += 16) {
+      const uint4 g0 = *(const uint4*)(g + t * C + c), p0 = *(const uint4*)(pre + t * C + c);
+      const uint4 g1 = *(const uint4*)(g + (t + 8) * C + c), p1 = *(const uint4*)(pre + (t + 8) * C + c);
+      one(g0, p0, t);
+      one(g1, p1, t + 8);
+    }
+    for (; t < t1; t += 8) one(*(const uint4*)(g + t * C + c), *(const uint4*)(pre + t * C + c), t);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl][8 * cg + j] = s[j];
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+    part[(int64_t)blockIdx.y * C + cc] = t;
+  }
+}
+
+// Several k_reduce_partials_small jobs in one launch (all of a layer's LayerNorm / bias partial sums are finished by ONE
+// kernel on the weight-gradient stream instead of one launch each on the activation-gradient chain).
+constexpr int REDUCE_MAX_JOBS = 8;
+struct ReduceJob {
+  const float* part;
+  float* out;
+  int64_t stride;
+  int nparts, n;
+  int block_end;    // one past this job's last block (16 outputs per block)
+};
+struct ReduceJobs {
+  ReduceJob j[REDUCE_MAX_JOBS];
+  int count;
+};
+static __global__ void __launch_bounds__(256) k_reduce_multi(const ReduceJobs a) {
+  __shared__ float red[16][17];
+  int ji = 0;
+#pragma unroll
+  for (int i = 0; i < REDUCE_MAX_JOBS - 1; ++i)
+    if (i + 1 < a.count && (int)blockIdx.x >= a.j[i].block_end) ji = i + 1;
+  const ReduceJob& q = a.j[ji];
+  const int blk = (int)blockIdx.x - (ji ? a.j[ji - 1].block_end : 0);
+  const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blk * 16 + c;
+  float s = 0.f;
+  if (i < q.n) {
+    int p = r;
+    for (; p + 48 < q.nparts; p += 64) {
+      const float v0 = q.part[(int64_t)p * q.stride + i], v1 = q.part[(int64_t)(p + 16) * q.stride + i];
+      const float v2 = q.part[(int64_t)(p + 32) * q.stride + i], v3 = q.part[(int64_t)(p + 48) * q.stride + i];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; p < q.nparts; p += 16) s += q.part[(int64_t)p * q.stride + i];
+  }
+  red[r][c] = s;
+  __syncthreads();
+  if (r == 0 && i < q.n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][c];
+    q.out[i] += t;
+  }
+}
+
 // dst[cu[b], :] = src[b, :] for b < B (dst pre-zeroed): scatter CLS-row gradients into a [rows, H] matrix
 __global__ void __launch_bounds__(256) k_scatter_cls(const int32_t* __restrict__ cu, int B, int H,
                                                      const float* __restrict__ src, float* __restrict__ dst) {

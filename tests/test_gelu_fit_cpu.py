@@ -29,3 +29,25 @@ def test_gelu_fit_is_within_1e5_of_exact_erf_gelu():
     assert np.abs(got - exact).max() < 1e-5
     # saturation: identity for large positive inputs, nothing left (|t Q(t)| < 1e-15) for large negative ones
     assert got[-2] == 1e4 and abs(got[-7]) < 1e-15 and got[-1] == 0.0
+
+
+def gelu_grad_fp32(x):
+    """encoder_kernels.hpp: gelu_grad (same constants and operation order)."""
+    x = x.astype(F)
+    t = np.minimum(np.abs(x), F(9.0))
+    p = _fma(t, F(0.0041585), F(-0.04571999))
+    p = _fma(p, t, F(-0.46495319))
+    p = _fma(p, t, F(-1.14955714))
+    q = np.exp2(_fma(p, t, F(-1.0)).astype(np.float64)).astype(F)
+    cdf = np.where(x >= 0, F(1.0) - q, q).astype(F)
+    e = np.exp2((F(-0.7213475204444817) * x * x).astype(np.float64)).astype(F)
+    return _fma(x * F(0.3989422804014327), e, cdf)
+
+
+def test_gelu_grad_fit_is_within_1e4_of_exact_derivative():
+    x = np.concatenate([np.linspace(-12, 12, 960001), np.array([-1e4, -100.0, -30.0, 30.0, 100.0, 1e4, 0.0])])
+    exact = 0.5 * (1.0 + erf(x / np.sqrt(2.0))) + x * np.exp(-0.5 * x * x) / np.sqrt(2.0 * np.pi)
+    got = gelu_grad_fp32(x).astype(np.float64)
+    assert np.isfinite(got).all()
+    assert np.abs(got - exact).max() < 1e-4          # bf16 gradients resolve 4e-3
+    assert got[-2] == 1.0 and abs(got[-7]) < 1e-15 and got[-1] == 0.5
