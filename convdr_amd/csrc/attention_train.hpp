@@ -1,0 +1,527 @@
+// Self-attention of the TRAINING step on gfx950: forward that keeps the log-sum-exp, and the backward (dQ / dK, dV).
+// Replaces what torch autograd runs for BertSelfAttention (HF transformers 2.3.0 modeling_bert.py, reached from
+// /root/reference/model/models.py:141-142 under /root/reference/drivers/run_convdr_train.py:109,178).
+//
+// Everything reads ONE token-major buffer QKV [rows, 3H] (Q | K | V, the fused projection's tile output) and the
+// token-major dO [rows, H]: no transposed copies exist.  Round 1 kept V^T, Q^T, K^T and dO^T in HBM (two transposes per
+// layer, a third of the bytes every backward workgroup staged); here an operand that MFMA wants with the contraction
+// index on the tile's ROW axis is read from the same LDS tile with the transposing LDS read:
+//   tile image  [64 rows][64 d] bf16, 128-byte rows, 16-byte chunk index XOR (row >> 1) & 7 (the engine's swizzle, so the
+//               row-fragment ds_read_b128 stay conflict-free; the transposing reads see 2-way conflicts, irrelevant here:
+//               these kernels are bound by latency and VALU, not by LDS bandwidth)
+//   A^T frag    rows d = 32 dt + (lane & 31), contraction slots j = 0..7 <-> tile rows 16 s + 8 (lane >> 5) + j:
+//               two ds_read_b64_tr_b16 (tile rows +0..3 | +4..7); within a 16-lane group lane i hands in the address of
+//               tile row (i >> 2), columns 4 (i & 3) .. + 3 of the group's 16-column block (gemm_tn.hpp).
+// Tiles arrive by LDS-DMA through a buffer descriptor whose window ends with the last packed row: rows past it read as
+// zeros (0 x finite, never 0 x junk, in the MFMAs whose other operand is masked to zero).  Two tile sets in flight.
+#pragma once
+#include "encoder_kernels.hpp"
+
+namespace convdr {
+
+// ---- staging: 64 rows x 128 bytes from a [nrows, ld] bf16 matrix, window [row 0, nrows) ------------------------------
+struct AttnTileSrc {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t voff;     // this lane's offset inside a round (row-in-round x row pitch + swizzled chunk)
+  uint32_t pitch8;   // bytes of 8 rows
+  uint32_t rowb;     // bytes of one row
+};
+__device__ __forceinline__ AttnTileSrc attn_tile_src(const bf16_t* base, int64_t ld, int64_t nrows, int lane) {
+  AttnTileSrc s;
+  int64_t bytes = nrows * ld * 2;
+  bytes = bytes > 0xffffffffll ? 0xffffffffll : bytes;
+  const uint64_t b = (uint64_t)base;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  const uint32_t nb = __builtin_amdgcn_readfirstlane((uint32_t)bytes);
+  s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
+  const int r = lane >> 3;                       // row inside an 8-row wave instruction
+  s.rowb = __builtin_amdgcn_readfirstlane((uint32_t)(ld * 2));
+  s.pitch8 = 8 * s.rowb;
+  // rows of a round are r0 = 8 * (i * 4 + wave) + r: (row >> 1) & 7 = (4 (i * 4 + wave) + (r >> 1)) & 7 -> needs wave, see stage()
+  s.voff = (uint32_t)r * s.rowb;
+  return s;
+}
+// first_row: the tile's first row in the matrix, col_bytes: byte offset of the head's 64 columns inside a row
+__device__ __forceinline__ void attn_stage_tile(const AttnTileSrc& s, int64_t first_row, uint32_t col_bytes, char* lds, int wave,
+                                                int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r0 = (i * 4 + wave) * 8;
+    const int row = r0 + (lane >> 3);
+    const uint32_t gch = (uint32_t)((lane & 7) ^ ((row >> 1) & 7));
+    const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)((first_row + r0) * s.rowb) + col_bytes);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds + r0 * 128), 16, s.voff + gch * 16, soff, 0, 0);
+  }
+}
+
+// ---- transposing fragment reads from a 64 x 128 B tile ---------------------------------------------------------------
+// per-lane byte offsets for (dt, rd): d block dt (32 columns), rd = second read of the fragment (tile rows + 4)
+struct TrLane {
+  uint32_t a[2][2];
+};
+__device__ __forceinline__ TrLane tr_lane(int lane) {
+  TrLane t;
+  const int g = lane >> 4, i16 = lane & 15;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int row = 8 * (g >> 1) + (i16 >> 2) + 4 * rd;          // inside a 16-row block (blocks keep (row >> 1) & 7)
+      const int c = 4 * dt + 2 * (g & 1) + ((i16 & 3) >> 1);      // source chunk of this lane's 4 columns
+      t.a[dt][rd] = (uint32_t)(row * 128 + ((c ^ ((row >> 1) & 7)) << 4) + 8 * (i16 & 1));
+    }
+  return t;
+}
+union TrFrag {
+  bf16x8 v;
+  u32x2_t h[2];
+};
+// fragment of d block dt for the 16 tile rows starting at ROW0 (a multiple of 16); tile = LDS byte address of the tile
+template <int ROW0>
+__device__ __forceinline__ void tr_frag(uint32_t tile, const TrLane& t, int dt, TrFrag& f) {
+  const uint32_t a0 = tile + t.a[dt][0], a1 = tile + t.a[dt][1];
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"
+               : "=&v"(f.h[0]), "=&v"(f.h[1])
+               : "v"(a0), "v"(a1), "n"(ROW0 * 128)
+               : "memory");
+}
+// Wait until all but the newest N LDS reads of this wave have returned, naming the fragments that are now valid: hipcc does
+// not count an asm load, so every consumer (and every register copy the allocator wants to make) of those fragments must
+// sit behind this statement -- "+v" makes it their definition (cdna guide 5.7 item 1, form ii); the sched_barrier keeps
+// register-only MFMAs from being hoisted above the wait (rule 18).
+template <int N>
+__device__ __forceinline__ void tr_wait2(TrFrag& x, TrFrag& y) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x.h[0]), "+v"(x.h[1]), "+v"(y.h[0]), "+v"(y.h[1]) : "n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
+__device__ __forceinline__ void tr_wait4(TrFrag& x, TrFrag& y, TrFrag& z, TrFrag& w) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(x.h[0]), "+v"(x.h[1]), "+v"(y.h[0]), "+v"(y.h[1]), "+v"(z.h[0]), "+v"(z.h[1]), "+v"(w.h[0]), "+v"(w.h[1])
+               : "n"(N)
+               : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+constexpr int ATT_TILE = 64 * 128;   // one 64-row x 128-byte LDS tile
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward (training): same lane-local scheme as k_attention_fwd (S^T = K Q^T, O^T = V^T P^T, lane = query), V read
+// from its token-major tile through transposing reads, LSE (natural log) saved for the backward.
+// ---------------------------------------------------------------------------------------------------------------------
+struct AttnTrainArgs {
+  const bf16_t* QKV;   // [rows, 3H]
+  int64_t rows;
+  const int32_t *cu, *lens;
+  int H;
+  bf16_t* ctx;         // [rows, H]
+  float* lse;          // [heads, ldt]: log2 of the softmax denominator, log2(sum_k exp(s_k * scale)) (base 2: the backward's exp2 argument)
+  int64_t ldt;
+  float scale;
+};
+
+static __global__ void __launch_bounds__(256, 3) k_attention_train_fwd(const AttnTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K tile | V tile)
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int len = a.lens[b];
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= len) return;
+  const int64_t base = a.cu[b];
+  const int plen = a.cu[b + 1] - (int)base;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  const int q = q0 + wave * 32 + li;
+  const int qc = q < len ? q : len - 1;
+  const int H = a.H, H3 = 3 * a.H;
+  bf16x8 qf[4];
+  {
+    const bf16_t* qp = a.QKV + (base + qc) * H3 + h * 64 + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+  }
+  const float c = a.scale * 1.44269504088896341f;
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  const int krow = (li & ~12) | ((li & 4) << 1) | ((li & 8) >> 1);   // bits 2 <-> 3 (see k_attention_fwd)
+  const int ksw = (krow >> 1) & 7;
+  const AttnTileSrc src = attn_tile_src(a.QKV, H3, a.rows, lane);
+  const TrLane trl = tr_lane(lane);
+  const uint32_t s0 = lds_off(smem);
+  auto stage = [&](int kv0, int buf) {
+    attn_stage_tile(src, base + kv0, (uint32_t)((H + h * 64) * 2), smem + buf * 2 * ATT_TILE, wave, lane);
+    attn_stage_tile(src, base + kv0, (uint32_t)((2 * H + h * 64) * 2), smem + buf * 2 * ATT_TILE + ATT_TILE, wave, lane);
+  };
+  stage(0, 0);
+  if (len > 64) stage(64, 1);
+  const bool active = q0 + wave * 32 < plen;   // waves whose 32 queries all lie past the sequence only help with the staging
+  for (int kv0 = 0, it = 0; kv0 < len; kv0 += 64, ++it) {
+    const int buf = it & 1;
+    lds_dma_wait_all();
+    __syncthreads();
+    if (it >= 1 && kv0 + 64 < len) stage(kv0 + 64, buf ^ 1);
+    if (!active) continue;
+    const char* sK = smem + buf * 2 * ATT_TILE;
+    const uint32_t tV = s0 + buf * 2 * ATT_TILE + ATT_TILE;
+    f32x16 st[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+      const char* kp = sK + (kt * 32 + krow) * 128;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *(const bf16x8*)(kp + (((2 * s + hi) ^ ksw) * 16));
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kt], 0, 0, 0);
+      }
+    }
+    // V^T fragments, two register sets: the first is issued now and returns under the softmax arithmetic, set s + 1 under
+    // the MFMAs of key block s
+    TrFrag vf[2][2];
+    tr_frag<0>(tV, trl, 0, vf[0][0]);  tr_frag<0>(tV, trl, 1, vf[0][1]);
+    float mx = -INFINITY;
+    if (kv0 + 64 > len) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
+          if (key >= len) st[kt][r] = -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float mnc = mn * c;
+    const float alpha = __builtin_amdgcn_exp2f(m * c - mnc);
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], c, -mnc));
+        st[kt][r] = p;
+        ps += p;
+      }
+    l = l * alpha + ps;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+#define CONVDR_PV_STEP(S4, NEXT_ROW0, WAITN)                                                                    \
+    {                                                                                                            \
+      constexpr int kt = (S4) >> 1, r0 = ((S4) & 1) * 8, cur = (S4) & 1;                                         \
+      if ((S4) < 3) { tr_frag<NEXT_ROW0>(tV, trl, 0, vf[cur ^ 1][0]); tr_frag<NEXT_ROW0>(tV, trl, 1, vf[cur ^ 1][1]); } \
+      union { bf16x8 v; uint32_t u[4]; } pb;                                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) pb.u[j] = pack_bf16x2(st[kt][r0 + 2 * j], st[kt][r0 + 2 * j + 1]); \
+      tr_wait2<WAITN>(vf[cur][0], vf[cur][1]);                                                                   \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                           \
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[cur][dt].v, pb.v, o[dt], 0, 0, 0);                    \
+    }
+    CONVDR_PV_STEP(0, 16, 4)
+    CONVDR_PV_STEP(1, 32, 4)
+    CONVDR_PV_STEP(2, 48, 4)
+    CONVDR_PV_STEP(3, 48, 0)
+#undef CONVDR_PV_STEP
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (q < plen) {
+    const float inv = q < len ? 1.f / l : 0.f;   // alignment rows [len, plen): zeros
+    bf16_t* dst = a.ctx + (base + q) * H + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 ov;
+        ov.x = pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        ov.y = pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        *(uint2*)(dst + dt * 32 + 8 * g + 4 * hi) = ov;
+      }
+    if (hi == 0) a.lse[(int64_t)h * a.ldt + base + q] = q < len ? m * c + __log2f(l) : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------------------
+struct AttnBwdArgs {
+  const bf16_t* QKV;   // [rows, 3H] token-major (Q | K | V)
+  const bf16_t* dO;    // [rows, H]
+  int64_t rows;
+  const float* LSE;    // [heads, ldt], base-2 (see AttnTrainArgs::lse)
+  int heads;
+  const float* Dr;     // [heads, ldt]  D[h, t] = sum_d dO[t, d] O[t, d]
+  int64_t ldt;
+  const int32_t *cu, *lens;
+  int H;
+  bf16_t* dQKV;        // [rows, 3H]
+  float scale;
+};
+
+constexpr int ATTB_DQ_SMEM = 2 * 2 * ATT_TILE;            // two sets of (K tile | V tile)
+constexpr int ATTB_DKV_SMEM = 2 * (2 * ATT_TILE + 512);   // two sets of (Q tile | dO tile | 64 LSE | 64 D)
+
+// dQ: workgroup = 128 queries of one (sequence, head); loop over 64-key tiles.  S^T = K Q^T and dP^T = V dO^T have lane =
+// query, registers = keys; dQ^T = K^T dS^T with dS^T fed from registers and K^T read transposed from the K tile.
+static __global__ void __launch_bounds__(256, 3) k_attention_bwd_dq(const AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int len = a.lens[b];
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= len) return;
+  const int64_t base = a.cu[b];
+  const int plen = a.cu[b + 1] - (int)base;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  const int q = q0 + wave * 32 + li;
+  const int qc = q < len ? q : len - 1;
+  const int H = a.H, H3 = 3 * a.H;
+  bf16x8 qf[4], dof[4];
+  {
+    const bf16_t* qp = a.QKV + (base + qc) * H3 + h * 64 + 8 * hi;
+    const bf16_t* dp = a.dO + (base + qc) * H + h * 64 + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { qf[s] = *(const bf16x8*)(qp + 16 * s); dof[s] = *(const bf16x8*)(dp + 16 * s); }
+  }
+  const float c = a.scale * 1.44269504088896341f;
+  const float lse2 = a.LSE[(int64_t)h * a.ldt + base + qc];
+  const float Di = a.Dr[(int64_t)h * a.ldt + base + qc];
+  f32x16 dq[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+  const int krow = (li & ~12) | ((li & 4) << 1) | ((li & 8) >> 1);
+  const int ksw = (krow >> 1) & 7;
+  const AttnTileSrc src = attn_tile_src(a.QKV, H3, a.rows, lane);
+  const TrLane trl = tr_lane(lane);
+  const uint32_t s0 = lds_off(smem);
+  auto stage = [&](int kv0, int buf) {
+    attn_stage_tile(src, base + kv0, (uint32_t)((H + h * 64) * 2), smem + buf * 2 * ATT_TILE, wave, lane);
+    attn_stage_tile(src, base + kv0, (uint32_t)((2 * H + h * 64) * 2), smem + buf * 2 * ATT_TILE + ATT_TILE, wave, lane);
+  };
+  stage(0, 0);
+  if (len > 64) stage(64, 1);
+  const bool active = q0 + wave * 32 < len;
+  for (int kv0 = 0, it = 0; kv0 < len; kv0 += 64, ++it) {
+    const int buf = it & 1;
+    lds_dma_wait_all();
+    __syncthreads();
+    if (it >= 1 && kv0 + 64 < len) stage(kv0 + 64, buf ^ 1);
+    if (!active) continue;
+    const char* sK = smem + buf * 2 * ATT_TILE;
+    const char* sV = sK + ATT_TILE;
+    const uint32_t tK = s0 + buf * 2 * ATT_TILE;
+    f32x16 st[2], dp[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[kt][r] = 0.f; dp[kt][r] = 0.f; }
+      const char* kp = sK + (kt * 32 + krow) * 128;
+      const char* vp = sV + (kt * 32 + krow) * 128;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int ch = ((2 * s + hi) ^ ksw) * 16;
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp + ch), qf[s], st[kt], 0, 0, 0);
+        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(vp + ch), dof[s], dp[kt], 0, 0, 0);
+      }
+    }
+    TrFrag kt_f[2][2];   // K^T fragments, two register sets (first one returns under the elementwise pass)
+    tr_frag<0>(tK, trl, 0, kt_f[0][0]);  tr_frag<0>(tK, trl, 1, kt_f[0][1]);
+    const bool ragged = kv0 + 64 > len;   // workgroup-uniform
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], c, -lse2));
+        float ds = p * (dp[kt][r] - Di) * a.scale;
+        if (ragged) {
+          const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
+          ds = key < len ? ds : 0.f;   // select, never 0 * junk
+        }
+        st[kt][r] = ds;
+      }
+#define CONVDR_DQ_STEP(S4, NEXT_ROW0, WAITN)                                                                    \
+    {                                                                                                            \
+      constexpr int kt = (S4) >> 1, r0 = ((S4) & 1) * 8, cur = (S4) & 1;                                         \
+      if ((S4) < 3) { tr_frag<NEXT_ROW0>(tK, trl, 0, kt_f[cur ^ 1][0]); tr_frag<NEXT_ROW0>(tK, trl, 1, kt_f[cur ^ 1][1]); } \
+      union { bf16x8 v; uint32_t u[4]; } pb;                                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) pb.u[j] = pack_bf16x2(st[kt][r0 + 2 * j], st[kt][r0 + 2 * j + 1]); \
+      tr_wait2<WAITN>(kt_f[cur][0], kt_f[cur][1]);                                                               \
+      _Pragma("unroll") for (int dt = 0; dt < 2; ++dt)                                                           \
+        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt_f[cur][dt].v, pb.v, dq[dt], 0, 0, 0);                \
+    }
+    CONVDR_DQ_STEP(0, 16, 4)
+    CONVDR_DQ_STEP(1, 32, 4)
+    CONVDR_DQ_STEP(2, 48, 4)
+    CONVDR_DQ_STEP(3, 48, 0)
+#undef CONVDR_DQ_STEP
+  }
+  if (q < plen) {
+    const float keep = q < len ? 1.f : 0.f;
+    bf16_t* dst = a.dQKV + (base + q) * H3 + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 ov;
+        ov.x = pack_bf16x2(dq[dt][4 * g + 0] * keep, dq[dt][4 * g + 1] * keep);
+        ov.y = pack_bf16x2(dq[dt][4 * g + 2] * keep, dq[dt][4 * g + 3] * keep);
+        *(uint2*)(dst + dt * 32 + 8 * g + 4 * hi) = ov;
+      }
+  }
+}
+
+// dK, dV: workgroup = 128 keys of one (sequence, head), lane = key; loop over 64-query tiles.
+//   S = Q K^T and dP = dO V^T with A = query rows (registers), B = this lane's key;
+//   dV^T = dO^T P and dK^T = Q^T dS with P / dS fed from registers, dO^T / Q^T read transposed from the dO / Q tiles.
+static __global__ void __launch_bounds__(256, 2) k_attention_bwd_dkv(const AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int SET = 2 * ATT_TILE + 512;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int len = a.lens[b];
+  const int k0 = blockIdx.x * 128;
+  if (k0 >= len) return;
+  const int64_t base = a.cu[b];
+  const int plen = a.cu[b + 1] - (int)base;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  const int key = k0 + wave * 32 + li;
+  const int kc = key < len ? key : len - 1;
+  const int H = a.H, H3 = 3 * a.H;
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16_t* kp = a.QKV + (base + kc) * H3 + H + h * 64 + 8 * hi;
+    const bf16_t* vp = a.QKV + (base + kc) * H3 + 2 * H + h * 64 + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { kf[s] = *(const bf16x8*)(kp + 16 * s); vf[s] = *(const bf16x8*)(vp + 16 * s); }
+  }
+  const float c = a.scale * 1.44269504088896341f;
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+  const int qrow = (li & ~12) | ((li & 4) << 1) | ((li & 8) >> 1);
+  const int qsw = (qrow >> 1) & 7;
+  const AttnTileSrc srcQ = attn_tile_src(a.QKV, H3, a.rows, lane);
+  const AttnTileSrc srcO = attn_tile_src(a.dO, H, a.rows, lane);
+  const TrLane trl = tr_lane(lane);
+  const uint32_t s0 = lds_off(smem);
+  // LSE / D of the tile's 64 queries ride the same DMA queue (4 bytes per lane; an ordinary load here would make hipcc
+  // drain the tile DMA it follows).  Columns past the last row lie inside the [heads, ldt] slack; past the array: zeros.
+  const AttnTileSrc srcL = attn_tile_src((const bf16_t*)a.LSE, 2 * a.ldt, a.heads, lane);
+  const AttnTileSrc srcD = attn_tile_src((const bf16_t*)a.Dr, 2 * a.ldt, a.heads, lane);
+  auto stage = [&](int q0, int buf) {
+    char* set = smem + buf * SET;
+    attn_stage_tile(srcQ, base + q0, (uint32_t)(h * 64 * 2), set, wave, lane);
+    attn_stage_tile(srcO, base + q0, (uint32_t)(h * 64 * 2), set + ATT_TILE, wave, lane);
+    if (wave < 2) {   // wave-uniform
+      const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)(((int64_t)h * a.ldt + base + q0) * 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wave == 0 ? srcL.rsrc : srcD.rsrc, (lptr_t)(set + 2 * ATT_TILE + wave * 256), 4,
+                                               (uint32_t)lane * 4, soff, 0, 0);
+    }
+  };
+  stage(0, 0);
+  if (len > 64) stage(64, 1);
+  const bool active = k0 + wave * 32 < len;
+  for (int q0 = 0, it = 0; q0 < len; q0 += 64, ++it) {
+    const int buf = it & 1;
+    lds_dma_wait_all();
+    __syncthreads();
+    if (it >= 1 && q0 + 64 < len) stage(q0 + 64, buf ^ 1);
+    if (!active) continue;
+    const char* sQ = smem + buf * SET;
+    const char* sdO = sQ + ATT_TILE;
+    const float* sLse = (const float*)(sQ + 2 * ATT_TILE);
+    const float* sD = sLse + 64;
+    const uint32_t tQ = s0 + buf * SET, tO = tQ + ATT_TILE;
+    const bool ragged = q0 + 64 > len;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {  // 32 queries at a time (keeps the register footprint at one S / dP tile)
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      const char* qp = sQ + (qt * 32 + qrow) * 128;
+      const char* op = sdO + (qt * 32 + qrow) * 128;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int ch = ((2 * s4 + hi) ^ qsw) * 16;
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qp + ch), kf[s4], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(op + ch), vf[s4], dp, 0, 0, 0);
+      }
+      // transposed fragments [set][dt] of the 16-query halves, dO^T and Q^T: half 0 is issued now and returns under the
+      // elementwise pass, half 1 under the MFMAs of half 0
+      TrFrag of[2][2], qf[2][2];
+      if (qt == 0) {
+        tr_frag<0>(tO, trl, 0, of[0][0]); tr_frag<0>(tO, trl, 1, of[0][1]);
+        tr_frag<0>(tQ, trl, 0, qf[0][0]); tr_frag<0>(tQ, trl, 1, qf[0][1]);
+      } else {
+        tr_frag<32>(tO, trl, 0, of[0][0]); tr_frag<32>(tO, trl, 1, of[0][1]);
+        tr_frag<32>(tQ, trl, 0, qf[0][0]); tr_frag<32>(tQ, trl, 1, qf[0][1]);
+      }
+      // register r <-> query q0 + 32 qt + 16 (r >> 3) + 8 hi + (r & 7)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = 32 * qt + 16 * (r >> 3) + 8 * hi + (r & 7);
+        float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -sLse[qi]));
+        float ds = p * (dp[r] - sD[qi]) * a.scale;
+        if (ragged) {
+          const bool ok = q0 + qi < len;
+          p = ok ? p : 0.f;
+          ds = ok ? ds : 0.f;
+        }
+        s[r] = p;
+        dp[r] = ds;
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {  // 16 queries per MFMA k-step
+        const int r0 = half * 8;
+        if (half == 0) {
+          if (qt == 0) {
+            tr_frag<16>(tO, trl, 0, of[1][0]); tr_frag<16>(tO, trl, 1, of[1][1]);
+            tr_frag<16>(tQ, trl, 0, qf[1][0]); tr_frag<16>(tQ, trl, 1, qf[1][1]);
+          } else {
+            tr_frag<48>(tO, trl, 0, of[1][0]); tr_frag<48>(tO, trl, 1, of[1][1]);
+            tr_frag<48>(tQ, trl, 0, qf[1][0]); tr_frag<48>(tQ, trl, 1, qf[1][1]);
+          }
+        }
+        union { bf16x8 v; uint32_t u[4]; } pb, sb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pb.u[j] = pack_bf16x2(s[r0 + 2 * j], s[r0 + 2 * j + 1]);
+          sb.u[j] = pack_bf16x2(dp[r0 + 2 * j], dp[r0 + 2 * j + 1]);
+        }
+        if (half == 0) tr_wait4<8>(of[0][0], of[0][1], qf[0][0], qf[0][1]);
+        else tr_wait4<0>(of[1][0], of[1][1], qf[1][0], qf[1][1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[half][dt].v, pb.v, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[half][dt].v, sb.v, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (key < plen) {
+    const float keep = key < len ? 1.f : 0.f;
+    bf16_t* dstk = a.dQKV + (base + key) * H3 + H + h * 64;
+    bf16_t* dstv = a.dQKV + (base + key) * H3 + 2 * H + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 ok, ov;
+        ok.x = pack_bf16x2(dk[dt][4 * g + 0] * keep, dk[dt][4 * g + 1] * keep);
+        ok.y = pack_bf16x2(dk[dt][4 * g + 2] * keep, dk[dt][4 * g + 3] * keep);
+        ov.x = pack_bf16x2(dv[dt][4 * g + 0] * keep, dv[dt][4 * g + 1] * keep);
+        ov.y = pack_bf16x2(dv[dt][4 * g + 2] * keep, dv[dt][4 * g + 3] * keep);
+        *(uint2*)(dstk + dt * 32 + 8 * g + 4 * hi) = ok;
+        *(uint2*)(dstv + dt * 32 + 8 * g + 4 * hi) = ov;
+      }
+  }
+}
+
+}  // namespace convdr

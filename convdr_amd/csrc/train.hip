@@ -5,13 +5,14 @@
 #include "gemm_launch.hpp"
 #include "gemm_tn.hpp"
 #include "train_kernels.hpp"
+#include "attention_train.hpp"
 
 #include "../../include/convdr_hip.h"
 
 namespace convdr {
 
 struct LayerSave {
-  bf16_t *Xin, *QKV, *QKVt, *ctx, *X1, *Hpre, *Hm;
+  bf16_t *Xin, *QKV, *ctx, *X1, *Hpre, *Hm;
   float *LSE, *Y1, *Y2;
 };
 
@@ -32,7 +33,7 @@ struct TrainBufs {
   float *cls_y, *cls_f, *head_y;
   // backward scratch
   float *G0, *G1, *Drow, *slab, *part, *dcls_y, *dcls_f, *dhead_y;
-  bf16_t *dctx, *dctx_t, *dhead_yb, *dclsb;
+  bf16_t *dctx, *dhead_yb, *dclsb;
   bf16_t *dXb1, *dXb2;   // dgrad outputs of FFN1 / the QKV projection (added to the fp32 stream by the next LayerNorm backward)
   int64_t ldt, Tp;
   size_t slab_elems;
@@ -66,7 +67,6 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
     LayerSave& s = P.layers[l];
     s.Xin = (bf16_t*)take(rs * H * 2);
     s.QKV = (bf16_t*)take(rs * 3 * H * 2);
-    s.QKVt = (bf16_t*)take((size_t)3 * H * p.ldt * 2);
     s.ctx = (bf16_t*)take(rs * H * 2);
     s.X1 = (bf16_t*)take(rs * H * 2);
     s.Hpre = (bf16_t*)take(rs * I * 2);
@@ -105,7 +105,6 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
   p.dXb1 = (bf16_t*)take(rs * H * 2);
   p.dXb2 = (bf16_t*)take(rs * H * 2);
   p.dctx = (bf16_t*)take(rs * H * 2);
-  p.dctx_t = (bf16_t*)take((size_t)H * p.ldt * 2);
   p.dhead_yb = (bf16_t*)take(Bp * E * 2);
   p.dclsb = (bf16_t*)take(Bp * H * 2);
   p.total = o;
@@ -168,14 +167,6 @@ static int check_train_config(const convdr_encoder_config* c) {
                  "train: unsupported intermediate/layers (%d, %d)", c->intermediate, c->layers);
   CONVDR_REQUIRE(c->out_dim == 0 || (c->out_dim % 64 == 0 && c->out_dim <= 1024), "train: out_dim %% 64 != 0 (%d)",
                  c->out_dim);
-  return 0;
-}
-
-static int transpose(const bf16_t* in, int64_t rows, int C, int64_t ld_in, bf16_t* out, int64_t ldt, hipStream_t st) {
-  ProfScope prof("transpose", st);
-  hipLaunchKernelGGL(k_transpose_bf16, dim3((C + 63) / 64, (unsigned)(ldt / 64)), dim3(256), 0, st, in, rows, C, ld_in, out,
-                     ldt, ldt);
-  CONVDR_CHECK_LAUNCH("k_transpose_bf16");
   return 0;
 }
 
@@ -352,13 +343,11 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
     GemmArgs g{};
     g.rows = rows; g.W = (const bf16_t*)lw->wqkv; g.X = s.Xin; g.N = 3 * H; g.K = H; g.bias = lw->bqkv; g.Cb = s.QKV;
     if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_qkv")) return e;
-    if (int e = transpose(s.QKV, rows, 3 * H, 3 * H, s.QKVt, p.ldt, st)) return e;
     {
-      AttnArgs a{s.QKV, s.QKV + H, s.QKVt + (size_t)2 * H * p.ldt, p.ldt, cu_seqlens, seq_lens, H, (int64_t)3 * H, s.ctx,
-                 s.LSE, 0.125f, nullptr};
+      AttnTrainArgs a{s.QKV, rows, cu_seqlens, seq_lens, H, s.ctx, s.LSE, p.ldt, 0.125f};
       ProfScope prof("attention", st);
-      hipLaunchKernelGGL(k_attention_fwd<false>, dim3((max_len + 127) / 128, cfg->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
-      CONVDR_CHECK_LAUNCH("k_attention_fwd");
+      hipLaunchKernelGGL(k_attention_train_fwd, dim3((max_len + 127) / 128, cfg->heads, B), dim3(256), 4 * ATT_TILE, st, a);
+      CONVDR_CHECK_LAUNCH("k_attention_train_fwd");
     }
     g = GemmArgs{};
     g.rows = rows; g.W = (const bf16_t*)lw->wo; g.X = s.ctx; g.N = H; g.K = H; g.bias = lw->bo; g.Cf = s.Y1; g.R = s.Xin;
@@ -487,20 +476,15 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     g.rows = rows; g.W = (const bf16_t*)lt->wo_t; g.X = d.dYb2; g.N = H; g.K = H; g.Cb = p.dctx;
     if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
     // ---- attention ----
-    if (int e = transpose(p.dctx, rows, H, H, p.dctx_t, p.ldt, st)) return e;
     hipLaunchKernelGGL(k_attn_rowdot, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.dctx, s.ctx, rows, H, p.Drow,
                        p.ldt);
     CONVDR_CHECK_LAUNCH("k_attn_rowdot");
     {
-      AttnBwdArgs a{s.QKV, s.QKVt, p.dctx, p.dctx_t, s.LSE, p.Drow, p.ldt, cu_seqlens, seq_lens, H, d.dQKV, 0.125f};
-      static DeviceOnce attr_done;
-      if (attr_done.first())
-        CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_attention_bwd_dkv, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             4 * ATTB_TILE + 512));
+      AttnBwdArgs a{s.QKV, p.dctx, rows, s.LSE, cfg->heads, p.Drow, p.ldt, cu_seqlens, seq_lens, H, d.dQKV, 0.125f};
       ProfScope prof("attention_bwd", st);
       const dim3 grid((max_len + 127) / 128, cfg->heads, B);
-      hipLaunchKernelGGL(k_attention_bwd_dq, grid, dim3(256), 3 * ATTB_TILE, st, a);
-      hipLaunchKernelGGL(k_attention_bwd_dkv, grid, dim3(256), 4 * ATTB_TILE + 512, st, a);
+      hipLaunchKernelGGL(k_attention_bwd_dq, grid, dim3(256), ATTB_DQ_SMEM, st, a);
+      hipLaunchKernelGGL(k_attention_bwd_dkv, grid, dim3(256), ATTB_DKV_SMEM, st, a);
       CONVDR_CHECK_LAUNCH("k_attention_bwd");
     }
     // ---- the layer's weight-gradient branch: every operand is complete now; it runs beside the layers below ----

@@ -4,52 +4,11 @@
 // for the student encoder: LayerNorm / GELU / attention / embedding backward and the data-layout helpers the
 // dgrad / wgrad MFMA GEMMs need.  All dense contractions reuse the NT tile engine (gemm_nt.hpp):
 //   dgrad  dX[t,k]  = sum_n dY[t,n] W[n,k]    -> operands dY [rows,N] and W^T [K,N]   (W^T kept packed)
-//   wgrad  dW[n,k]  = sum_t dY[t,n] X[t,k]    -> operands X^T [K,Tp] and dY^T [N,Tp]  (k_transpose_bf16), split over t
+//   wgrad  dW[n,k]  = sum_t dY[t,n] X[t,k]    -> TN engine (gemm_tn.hpp), straight from the token-major operands
 #pragma once
 #include "encoder_kernels.hpp"
 
 namespace convdr {
-
-// ---------------------------------------------------------------------------------------------
-// bf16 [rows, C] (row stride ld_in) -> [C, ldt] transposed; columns t in [rows, tcols) are written as zeros so the
-// result can be used as a zero-padded contraction operand.  64 x 64 tiles through LDS.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_transpose_bf16(const bf16_t* __restrict__ in, int64_t rows, int C,
-                                                        int64_t ld_in, bf16_t* __restrict__ out, int64_t ldt,
-                                                        int64_t tcols) {
-  __shared__ bf16_t tile[64][66];
-  const int c0 = blockIdx.x * 64;
-  const int64_t t0 = (int64_t)blockIdx.y * 64;
-  {
-    const int r = threadIdx.x >> 2, cq = (threadIdx.x & 3) * 16;  // 64 rows x 4 quarter-rows of 16 elements
-    const int64_t t = t0 + r;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c = cq + 8 * h;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (t < rows && c0 + c < C) v = *(const uint4*)(in + t * ld_in + c0 + c);
-      const bf16_t* e = (const bf16_t*)&v;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) tile[r][c + j] = e[j];
-    }
-  }
-  __syncthreads();
-  {
-    const int c = threadIdx.x >> 2, tq = (threadIdx.x & 3) * 16;
-    if (c0 + c < C) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int tt = tq + 8 * h;
-        if (t0 + tt < tcols) {
-          bf16_t e[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) e[j] = tile[tt + j][c];
-          *(uint4*)(out + (int64_t)(c0 + c) * ldt + t0 + tt) = *(const uint4*)e;
-        }
-      }
-    }
-  }
-}
 
 // fp32 [n, k] -> bf16 [k, n]  (weight packing for dgrad: W^T)
 __global__ void __launch_bounds__(256) k_transpose_f32_bf16(const float* __restrict__ in, int n, int k,
@@ -482,237 +441,6 @@ __global__ void __launch_bounds__(256) k_attn_rowdot(const bf16_t* __restrict__ 
               __uint_as_float(a.y & 0xffff0000u) * __uint_as_float(b.y & 0xffff0000u);
     s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
     if ((lane & 15) == 0) D[(int64_t)(e0 >> 6) * ldt + row] = s;
-  }
-}
-
-struct AttnBwdArgs {
-  const bf16_t* QKV;   // [rows, 3H] token-major (Q | K | V)
-  const bf16_t* QKVt;  // [3H, ldt] feature-major, zero beyond the last row
-  const bf16_t* dO;    // [rows, H]
-  const bf16_t* dOt;   // [H, ldt]
-  const float* LSE;    // [heads, ldt]
-  const float* Dr;     // [heads, ldt]
-  int64_t ldt;
-  const int32_t *cu, *lens;
-  int H;
-  bf16_t* dQKV;        // [rows, 3H]
-  float scale;
-};
-
-constexpr int ATTB_TILE = 64 * 128;  // one 64-row x 128-byte LDS tile
-
-// stage a 64 x 128 B tile (rows `row_stride_elems` apart) with the engine's swizzle
-__device__ __forceinline__ void attn_stage64(const bf16_t* src, int64_t row_stride, char* lds, int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r0 = (i * 4 + wave) * 8;
-    const int row = r0 + (lane >> 3);
-    const int gch = (lane & 7) ^ ((row >> 1) & 7);
-    glds16((const char*)(src + (int64_t)row * row_stride) + gch * 16, lds + r0 * 128);
-  }
-}
-
-// dQ: workgroup = 128 queries of one (sequence, head); loop over 64-key tiles.  Same lane-local layout as the
-// forward: S^T and dP^T = V dO^T have lane = query, registers = keys; dQ^T = K^T dS^T with dS^T fed from registers.
-__global__ void __launch_bounds__(256) k_attention_bwd_dq(const AttnBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;
-  char* sV = smem + ATTB_TILE;
-  char* sKt = smem + 2 * ATTB_TILE;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int len = a.lens[b];
-  const int q0 = blockIdx.x * 128;
-  if (q0 >= len) return;
-  const int64_t base = a.cu[b];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int hi = lane >> 5, li = lane & 31;
-  const int q = q0 + wave * 32 + li;
-  const int qc = q < len ? q : len - 1;
-  const int H = a.H, H3 = 3 * a.H;
-  bf16x8 qf[4], dof[4];
-  {
-    const bf16_t* qp = a.QKV + (base + qc) * H3 + h * 64 + 8 * hi;
-    const bf16_t* dp = a.dO + (base + qc) * H + h * 64 + 8 * hi;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { qf[s] = *(const bf16x8*)(qp + 16 * s); dof[s] = *(const bf16x8*)(dp + 16 * s); }
-  }
-  const float c = a.scale * 1.44269504088896341f;
-  const float lse2 = a.LSE[(int64_t)h * a.ldt + base + qc] * 1.44269504088896341f;
-  const float Di = a.Dr[(int64_t)h * a.ldt + base + qc];
-  f32x16 dq[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
-  const int sw = (lane >> 1) & 7;
-  const int krow = (li & ~12) | ((li & 4) << 1) | ((li & 8) >> 1);
-  const int ksw = (krow >> 1) & 7;
-
-  for (int kv0 = 0; kv0 < len; kv0 += 64) {
-    __syncthreads();
-    attn_stage64(a.QKV + (base + kv0) * H3 + H + h * 64, H3, sK, wave, lane);
-    attn_stage64(a.QKV + (base + kv0) * H3 + 2 * H + h * 64, H3, sV, wave, lane);
-    attn_stage64(a.QKVt + (int64_t)(H + h * 64) * a.ldt + base + kv0, a.ldt, sKt, wave, lane);
-    lds_dma_wait_all();
-    __syncthreads();
-    f32x16 st[2], dp[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { st[kt][r] = 0.f; dp[kt][r] = 0.f; }
-      const char* kp = sK + (kt * 32 + krow) * 128;
-      const char* vp = sV + (kt * 32 + krow) * 128;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int ch = ((2 * s + hi) ^ ksw) * 16;
-        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(kp + ch), qf[s], st[kt], 0, 0, 0);
-        dp[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(vp + ch), dof[s], dp[kt], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
-        const float p = exp2f(st[kt][r] * c - lse2);
-        st[kt][r] = key < len ? p * (dp[kt][r] - Di) * a.scale : 0.f;  // dS^T (select, never 0 * junk)
-      }
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int kt = s4 >> 1, r0 = (s4 & 1) * 8;
-      union { bf16x8 v; uint32_t u[4]; } pb;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) pb.u[j] = pack_bf16x2(st[kt][r0 + 2 * j], st[kt][r0 + 2 * j + 1]);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const bf16x8 kf = *(const bf16x8*)(sKt + (dt * 32 + li) * 128 + (((2 * s4 + hi) ^ sw) * 16));
-        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, pb.v, dq[dt], 0, 0, 0);
-      }
-    }
-  }
-  const int plen = a.cu[b + 1] - (int)base;
-  if (q < plen) {
-    const float keep = q < len ? 1.f : 0.f;
-    bf16_t* dst = a.dQKV + (base + q) * H3 + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 ov;
-        ov.x = pack_bf16x2(dq[dt][4 * g + 0] * keep, dq[dt][4 * g + 1] * keep);
-        ov.y = pack_bf16x2(dq[dt][4 * g + 2] * keep, dq[dt][4 * g + 3] * keep);
-        *(uint2*)(dst + dt * 32 + 8 * g + 4 * hi) = ov;
-      }
-  }
-}
-
-// dK, dV: workgroup = 128 keys of one (sequence, head), lane = key; loop over 64-query tiles.
-//   S = Q K^T and dP = dO V^T with A = query rows (registers), B = this lane's key;
-//   dV^T = dO^T P and dK^T = Q^T dS with P / dS fed from registers.
-__global__ void __launch_bounds__(256) k_attention_bwd_dkv(const AttnBwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sQ = smem;
-  char* sdO = smem + ATTB_TILE;
-  char* sQt = smem + 2 * ATTB_TILE;
-  char* sdOt = smem + 3 * ATTB_TILE;
-  float* sLse = (float*)(smem + 4 * ATTB_TILE);
-  float* sD = sLse + 64;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int len = a.lens[b];
-  const int k0 = blockIdx.x * 128;
-  if (k0 >= len) return;
-  const int64_t base = a.cu[b];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int hi = lane >> 5, li = lane & 31;
-  const int key = k0 + wave * 32 + li;
-  const int kc = key < len ? key : len - 1;
-  const int H = a.H, H3 = 3 * a.H;
-  bf16x8 kf[4], vf[4];
-  {
-    const bf16_t* kp = a.QKV + (base + kc) * H3 + H + h * 64 + 8 * hi;
-    const bf16_t* vp = a.QKV + (base + kc) * H3 + 2 * H + h * 64 + 8 * hi;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { kf[s] = *(const bf16x8*)(kp + 16 * s); vf[s] = *(const bf16x8*)(vp + 16 * s); }
-  }
-  const float c = a.scale * 1.44269504088896341f;
-  f32x16 dk[2], dv[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
-  const int sw = (lane >> 1) & 7;
-  const int qrow = (li & ~12) | ((li & 4) << 1) | ((li & 8) >> 1);
-  const int qsw = (qrow >> 1) & 7;
-
-  for (int q0 = 0; q0 < len; q0 += 64) {
-    __syncthreads();
-    attn_stage64(a.QKV + (base + q0) * H3 + h * 64, H3, sQ, wave, lane);
-    attn_stage64(a.dO + (base + q0) * H + h * 64, H, sdO, wave, lane);
-    attn_stage64(a.QKVt + (int64_t)(h * 64) * a.ldt + base + q0, a.ldt, sQt, wave, lane);
-    attn_stage64(a.dOt + (int64_t)(h * 64) * a.ldt + base + q0, a.ldt, sdOt, wave, lane);
-    if (threadIdx.x < 64) {
-      sLse[threadIdx.x] = a.LSE[(int64_t)h * a.ldt + base + q0 + threadIdx.x] * 1.44269504088896341f;
-      sD[threadIdx.x] = a.Dr[(int64_t)h * a.ldt + base + q0 + threadIdx.x];
-    }
-    lds_dma_wait_all();
-    __syncthreads();
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {  // 32 queries at a time (keeps the register footprint at one S / dP tile)
-      f32x16 s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-      const char* qp = sQ + (qt * 32 + qrow) * 128;
-      const char* op = sdO + (qt * 32 + qrow) * 128;
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int ch = ((2 * s4 + hi) ^ qsw) * 16;
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qp + ch), kf[s4], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(op + ch), vf[s4], dp, 0, 0, 0);
-      }
-      // register r <-> query q0 + 32 qt + 16 (r >> 3) + 8 hi + (r & 7)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qi = 32 * qt + 16 * (r >> 3) + 8 * hi + (r & 7);
-        const bool ok = q0 + qi < len;
-        const float p = ok ? exp2f(s[r] * c - sLse[qi]) : 0.f;
-        s[r] = p;                                               // P
-        dp[r] = ok ? p * (dp[r] - sD[qi]) * a.scale : 0.f;      // dS
-      }
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {  // 16 queries per MFMA k-step
-        const int r0 = half * 8;
-        union { bf16x8 v; uint32_t u[4]; } pb, sb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          pb.u[j] = pack_bf16x2(s[r0 + 2 * j], s[r0 + 2 * j + 1]);
-          sb.u[j] = pack_bf16x2(dp[r0 + 2 * j], dp[r0 + 2 * j + 1]);
-        }
-        const int chq = (((2 * (2 * qt + half) + hi) ^ sw) * 16);  // queries 32 qt + 16 half + 8 hi .. +8
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 of = *(const bf16x8*)(sdOt + (dt * 32 + li) * 128 + chq);
-          const bf16x8 qf = *(const bf16x8*)(sQt + (dt * 32 + li) * 128 + chq);
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of, pb.v, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, sb.v, dk[dt], 0, 0, 0);
-        }
-      }
-    }
-  }
-  const int plen = a.cu[b + 1] - (int)base;
-  if (key < plen) {
-    const float keep = key < len ? 1.f : 0.f;
-    bf16_t* dstk = a.dQKV + (base + key) * H3 + H + h * 64;
-    bf16_t* dstv = a.dQKV + (base + key) * H3 + 2 * H + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 ok, ov;
-        ok.x = pack_bf16x2(dk[dt][4 * g + 0] * keep, dk[dt][4 * g + 1] * keep);
-        ok.y = pack_bf16x2(dk[dt][4 * g + 2] * keep, dk[dt][4 * g + 3] * keep);
-        ov.x = pack_bf16x2(dv[dt][4 * g + 0] * keep, dv[dt][4 * g + 1] * keep);
-        ov.y = pack_bf16x2(dv[dt][4 * g + 2] * keep, dv[dt][4 * g + 3] * keep);
-        *(uint2*)(dstk + dt * 32 + 8 * g + 4 * hi) = ok;
-        *(uint2*)(dstv + dt * 32 + 8 * g + 4 * hi) = ov;
-      }
   }
 }
 
