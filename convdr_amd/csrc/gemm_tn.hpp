@@ -83,10 +83,27 @@ __device__ __forceinline__ void tn_frag(uint32_t addr, TnFrag& f) {
                : "v"(addr), "n"(OFF), "n"(OFF + 4 * ROWB)
                : "memory");
 }
-template <int N>
-__device__ __forceinline__ void tn_wait_frags() {   // all but the newest N LDS reads of this wave have returned
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-  __builtin_amdgcn_sched_barrier(0);                 // (rule: register-only MFMAs must not be hoisted above the wait)
+// All but the newest N LDS reads of this wave have returned: fragment set (fa[0..MT), fb[0..NT)) is valid.  The statement
+// names the set's registers "+v": hipcc does not count an asm load, so every consumer of the set -- and any register copy
+// the allocator wants to make of it -- must come after this wait (cdna guide 5.7 item 1, form ii); the sched_barrier keeps
+// the register-only MFMAs below it (rule 18).
+template <int N, int MT, int NT>
+__device__ __forceinline__ void tn_wait_frags(TnFrag* fa, TnFrag* fb) {
+  static_assert(NT == 2 && (MT == 2 || MT == 4), "fragment-set shapes of Tile128 / Tile256");
+  if constexpr (MT == 2) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(fa[0].h[0]), "+v"(fa[0].h[1]), "+v"(fa[1].h[0]), "+v"(fa[1].h[1]), "+v"(fb[0].h[0]), "+v"(fb[0].h[1]),
+                   "+v"(fb[1].h[0]), "+v"(fb[1].h[1])
+                 : "n"(N)
+                 : "memory");
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(%12)"
+                 : "+v"(fa[0].h[0]), "+v"(fa[0].h[1]), "+v"(fa[1].h[0]), "+v"(fa[1].h[1]), "+v"(fa[2].h[0]), "+v"(fa[2].h[1]),
+                   "+v"(fa[3].h[0]), "+v"(fa[3].h[1]), "+v"(fb[0].h[0]), "+v"(fb[0].h[1]), "+v"(fb[1].h[0]), "+v"(fb[1].h[1])
+                 : "n"(N)
+                 : "memory");
+  }
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // acc += sum over K steps [0, nk) of the staged operands.  Two stages, one barrier per step; every wave issues its share
@@ -140,15 +157,15 @@ __device__ __forceinline__ void gemm_tn_mainloop(const TnStageSrc<T::TR, T::WAVE
   }
     CONVDR_TN_LOAD(0, 0)
     CONVDR_TN_LOAD(1, 1)
-    tn_wait_frags<NFRAG_READS>();
+    tn_wait_frags<NFRAG_READS, T::MT, T::NT>(fa[0], fb[0]);
     CONVDR_TN_MMA(0)
     CONVDR_TN_LOAD(2, 0)
-    tn_wait_frags<NFRAG_READS>();
+    tn_wait_frags<NFRAG_READS, T::MT, T::NT>(fa[1], fb[1]);
     CONVDR_TN_MMA(1)
     CONVDR_TN_LOAD(3, 1)
-    tn_wait_frags<NFRAG_READS>();
+    tn_wait_frags<NFRAG_READS, T::MT, T::NT>(fa[0], fb[0]);
     CONVDR_TN_MMA(0)
-    tn_wait_frags<0>();
+    tn_wait_frags<0, T::MT, T::NT>(fa[1], fb[1]);
     CONVDR_TN_MMA(1)
 #undef CONVDR_TN_LOAD
 #undef CONVDR_TN_MMA

@@ -587,12 +587,12 @@ extern "C" int convdr_inbatch_ce_fwd_bwd(const float* embs, const float* docs, i
   return 0;
 }
 
-extern "C" int convdr_grad_norm_clip(float* grads, int64_t n, float max_norm, float* scratch /* >= 1024 floats */,
+extern "C" int convdr_grad_norm_clip(float* grads, int64_t n, float max_norm, float pre_scale, float* scratch /* >= 1024 floats */,
                                      float* norm_and_coef /* [2] */, int apply, convdr_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (int)(ceil_div64(n, 256) < 1024 ? ceil_div64(n, 256) : 1024);
   hipLaunchKernelGGL(k_sumsq_partial, dim3(blocks), dim3(256), 0, st, grads, n, scratch);
-  hipLaunchKernelGGL(k_norm_finish, dim3(1), dim3(64), 0, st, scratch, blocks, max_norm, norm_and_coef);
+  hipLaunchKernelGGL(k_norm_finish, dim3(1), dim3(64), 0, st, scratch, blocks, max_norm, pre_scale, norm_and_coef);
   if (apply) hipLaunchKernelGGL(k_scale_inplace, dim3(blocks), dim3(256), 0, st, grads, n, norm_and_coef + 1);
   CONVDR_CHECK_LAUNCH("convdr_grad_norm_clip");
   return 0;

@@ -574,15 +574,20 @@ __global__ void __launch_bounds__(256) k_sumsq_partial(const float* __restrict__
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-// norm_out[0] = sqrt(sum part) ; norm_out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))  (torch clip_grad_norm_)
-__global__ void k_norm_finish(const float* __restrict__ part, int nparts, float max_norm, float* __restrict__ out) {
+// norm_out[0] = pre_scale * sqrt(sum part); norm_out[1] = pre_scale * min(1, max_norm / (norm + 1e-6))  (torch clip_grad_norm_
+// of the gradients scaled by pre_scale)
+__global__ void k_norm_finish(const float* __restrict__ part, int nparts, float max_norm, float pre_scale,
+                              float* __restrict__ out) {
+  // one wave; lane l folds partials l, l + 64, ... in fp64, then a fixed butterfly (deterministic)
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 64) s += (double)part[i];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < nparts; ++i) s += part[i];
-    const float nm = (float)sqrt(s);
+    const float nm = pre_scale * (float)sqrt(s);   // norm of the gradients AFTER the pending scale (1 / world size)
     out[0] = nm;
     const float cf = max_norm / (nm + 1e-6f);
-    out[1] = cf < 1.f ? cf : 1.f;
+    out[1] = pre_scale * (cf < 1.f ? cf : 1.f);    // what the raw gradients still have to be multiplied by
   }
 }
 

@@ -164,8 +164,27 @@ class EncoderTower(nn.Module):
 
     # ---- packed weights ---------------------------------------------------------------------
     def _version_key(self, extra):
-        ps = list(self.parameters()) + list(extra)
-        return tuple((p.data_ptr(), p._version) for p in ps)
+        # (walking the module tree costs 0.2 ms per call at 200 parameters; the list is rebuilt only when a parameter
+        # object has been replaced, e.g. by resize_token_embeddings)
+        ps = self.__dict__.get("_plist")
+        if ps is None or self.embeddings.word_embeddings.weight is not ps[0]:
+            ps = self.__dict__["_plist"] = list(self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in ps) + tuple((p.data_ptr(), p._version) for p in extra)
+
+    def invalidate_packed(self):
+        """Forget the packed bf16 copies.  Needed after writes that bypass the version counters (``p.data`` writes such
+        as a broadcast into ``p.data``)."""
+        self._packed = None
+        self._packed_key = None
+        self.__dict__.pop("_packed_t", None)
+
+    def check_positions(self, max_len):
+        """The reference's position-embedding lookup raises IndexError when a sequence needs a position past the table
+        (RoBERTa: position = pad_idx + running count of non-pad tokens; BERT: the column index)."""
+        need = max_len + (self.config.pad_token_id + 1 if self.kind == "roberta" else 0)
+        if need > self.config.max_position_embeddings:
+            raise IndexError("a sequence of %d tokens needs position %d of a %d-row position-embedding table"
+                             % (max_len, need - 1, self.config.max_position_embeddings))
 
     @staticmethod
     def _bf16(t):
@@ -311,20 +330,16 @@ class EncoderTower(nn.Module):
             raise ValueError("attention_mask=None needs seq_lens")
         B, L = ids.shape
         dev = ids.device
-        if seq_lens is None:
-            seq_lens = mask.sum(1).to(torch.int32)
-            lens_host = seq_lens.cpu().numpy()          # one small D2H sync per batch
-            if not bool(mask[:, 0].all()):
-                raise ValueError("attention_mask[:, 0] must be 1 (CLS position); the reference right-pads")
-        else:
-            lens_host = np.asarray(seq_lens, np.int32)
-            seq_lens = torch.as_tensor(lens_host, device=dev)
+        from ..train import _lens_and_check, _pinned_upload
+        # one small D2H round trip per batch unless the caller knows the lengths; it also validates the token ids
+        seq_lens, lens_host = _lens_and_check(ids, mask, self.embeddings.word_embeddings.num_embeddings, seq_lens)
         if lens_host.min() < 1:
             raise ValueError("every sequence needs at least one unmasked token")
+        self.check_positions(int(lens_host.max()))
         cu_host = np.zeros(B + 1, np.int32)
         np.cumsum((lens_host + 7) // 8 * 8, out=cu_host[1:])
         rows, max_len = int(cu_host[-1]), int(lens_host.max())
-        cu = torch.as_tensor(cu_host, device=dev)
+        cu = _pinned_upload(cu_host, dev)
         with torch.cuda.device(dev):
             c, w, _keep = self.packed(head)
             self._ensure_kslice(c, w, _keep, rows, dev)
@@ -406,6 +421,18 @@ class EmbeddingMixin:
         raise NotImplementedError("Please Implement this method")
 
 
+def _wants_autograd(module):
+    """The activation-saving (differentiable) forward runs in train() mode with gradients enabled -- what the reference's
+    training loop does (run_convdr_train.py:107).  An eval()-mode call takes the inference kernels even when the caller
+    forgot torch.no_grad(): the training forward keeps ~12 layers of activations, which at corpus-encode batch sizes is an
+    out-of-memory, not a convenience (set ``module.autograd_in_eval = True`` to differentiate through an eval() model)."""
+    if not torch.is_grad_enabled():
+        return False
+    if not (module.training or getattr(module, "autograd_in_eval", False)):
+        return False
+    return any(p.requires_grad for p in module.parameters())
+
+
 def _pairwise_nll(q_embs, a_embs, b_embs):
     logit_matrix = torch.cat([(q_embs * a_embs).sum(-1).unsqueeze(1), (q_embs * b_embs).sum(-1).unsqueeze(1)], dim=1)
     lsm = torch.nn.functional.log_softmax(logit_matrix, dim=1)
@@ -416,11 +443,12 @@ class NLL(EmbeddingMixin):
     """models.py:52-75."""
 
     def forward(self, query_ids, attention_mask_q, input_ids_a=None, attention_mask_a=None, input_ids_b=None,
-                attention_mask_b=None, is_query=True):
+                attention_mask_b=None, is_query=True, seq_lens=None):
+        kw = {} if seq_lens is None else {"seq_lens": seq_lens}
         if input_ids_b is None and is_query:
-            return self.query_emb(query_ids, attention_mask_q)
+            return self.query_emb(query_ids, attention_mask_q, **kw)
         elif input_ids_b is None:
-            return self.body_emb(query_ids, attention_mask_q)
+            return self.body_emb(query_ids, attention_mask_q, **kw)
         q_embs = self.query_emb(query_ids, attention_mask_q)
         a_embs = self.body_emb(input_ids_a, attention_mask_a)
         b_embs = self.body_emb(input_ids_b, attention_mask_b)
@@ -451,16 +479,17 @@ class RobertaDot_NLL_LN(NLL, _PretrainedMixin, nn.Module):
         self.norm = nn.LayerNorm(768)
         self.apply(self._init_weights)
 
-    def query_emb(self, input_ids, attention_mask):
+    def query_emb(self, input_ids, attention_mask, seq_lens=None):
+        """seq_lens (extension): optional host int array of token counts; saves the forward's device -> host round trip."""
         if self.use_mean:
             raise NotImplementedError("use_mean=True is not registered by any reference config (models.py:295-307)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if _wants_autograd(self):
             from ..train import encoder_autograd
-            return encoder_autograd(self, self.roberta, (self.embeddingHead, self.norm), input_ids, attention_mask)
-        return self.roberta.embed(input_ids, attention_mask, head=(self.embeddingHead, self.norm))
+            return encoder_autograd(self, self.roberta, (self.embeddingHead, self.norm), input_ids, attention_mask, seq_lens)
+        return self.roberta.embed(input_ids, attention_mask, head=(self.embeddingHead, self.norm), seq_lens=seq_lens)
 
-    def body_emb(self, input_ids, attention_mask):
-        return self.query_emb(input_ids, attention_mask)
+    def body_emb(self, input_ids, attention_mask, seq_lens=None):
+        return self.query_emb(input_ids, attention_mask, seq_lens)
 
     def resize_token_embeddings(self, new_num_tokens):
         """run_convdr_train.py:474: grow the word-embedding table, new rows N(0, 0.02) like HF's _init_weights."""
@@ -472,6 +501,9 @@ class RobertaDot_NLL_LN(NLL, _PretrainedMixin, nn.Module):
         n = min(old.num_embeddings, new_num_tokens)
         new.weight.data[:n] = old.weight.data[:n]
         self.roberta.embeddings.word_embeddings = new
+        self.roberta.__dict__.pop("_plist", None)
+        self.roberta.__dict__.pop("_flat", None)     # the word table left the flat arena: re-run flatten_parameters
+        self.roberta.invalidate_packed()
         self.config.vocab_size = new_num_tokens
         return new
 
@@ -553,7 +585,7 @@ class HFBertEncoder(EncoderTower):
         return enc
 
     def forward(self, input_ids, attention_mask):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if _wants_autograd(self):
             from ..train import encoder_autograd
             pooled = encoder_autograd(self, self, None, input_ids, attention_mask)
         else:

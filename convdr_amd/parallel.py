@@ -31,9 +31,27 @@ def all_gather_rows(x, group=None, force=False):
 
 def merge_rank_topk(D_all, I_all, k):
     """D_all / I_all: [W, nq, k] per-rank results (each row sorted descending) -> global [nq, k].
-    Ties keep the lower rank (= earlier block) first, then the earlier position: a stable descending sort of the
-    rank-ordered concatenation, which is what chaining the reference's `>=` two-way merge over blocks 0..W-1 gives."""
+    Ties keep the lower rank (= earlier block) first, then the earlier position: what chaining the reference's `>=`
+    two-way merge (run_convdr_inference.py:213-229) over blocks 0..W-1 gives.  On a GPU that chain is run literally with
+    the device merge kernel (convdr_topk_merge, k outputs per step: entries past rank k can never re-enter); CPU tensors
+    (the gloo tests) take a stable descending sort of the rank-ordered concatenation, the same permutation."""
     W, nq, kk = D_all.shape
+    if D_all.is_cuda:
+        from . import _lib
+        L = _lib.lib()
+        D_all, I_all = D_all.contiguous(), I_all.contiguous()
+        Dm, Im = D_all[0], I_all[0]
+        with torch.cuda.device(D_all.device):
+            for r in range(1, W):
+                na = Dm.shape[1]
+                no = min(k, na + kk)
+                Do = torch.empty((nq, no), dtype=torch.float32, device=D_all.device)
+                Io = torch.empty((nq, no), dtype=torch.int64, device=D_all.device)
+                _lib.check(L.convdr_topk_merge(_lib.ptr(Dm), _lib.ptr(Im), na, Dm.stride(0), _lib.ptr(D_all[r]), _lib.ptr(I_all[r]),
+                                               kk, D_all[r].stride(0), nq, no, _lib.ptr(Do), _lib.ptr(Io), Do.stride(0),
+                                               _lib.stream_ptr()), "convdr_topk_merge")
+                Dm, Im = Do, Io
+        return Dm[:, :k], Im[:, :k]
     d = D_all.permute(1, 0, 2).reshape(nq, W * kk)
     i = I_all.permute(1, 0, 2).reshape(nq, W * kk)
     order = torch.sort(d, dim=1, descending=True, stable=True).indices[:, :k]
@@ -96,6 +114,10 @@ class DataParallelStudent:
         if broadcast and _world() > 1:   # what the DDP constructor does (gen_passage_embeddings.py:64-69)
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, 0, group=group)
+            # the writes went through .data (no version bump): drop the packed bf16 copies made before them
+            for mod in model.modules():
+                if hasattr(mod, "invalidate_packed"):
+                    mod.invalidate_packed()
 
     def _layer_buckets(self, n_flat):
         """[(begin, end)] of each encoder layer's gradients in the flat arena (train._tower_params order: 5 embedding
@@ -113,16 +135,25 @@ class DataParallelStudent:
         nl = len(tower.encoder.layer)
         return [(offs[5 + 16 * l], offs[5 + 16 * (l + 1)]) for l in range(nl)]
 
-    def allreduce_grads(self, force_overlap=False):
-        """Average the gradients over the ranks.  With the flat arena on a GPU the all-reduce runs UNDER the backward:
+    def allreduce_grads(self, force_overlap=False, average=True):
+        """Sum the gradients over the ranks; average=True also divides them by the world size, average=False returns that
+        factor (1 / W) for the caller to fold into its clip / optimizer pass (train_step does: one pass over the 0.5 GB
+        gradient arena less).  With the flat arena on a GPU the all-reduce runs UNDER the backward:
         convdr_encoder_backward has only been enqueued when this is called, so one collective per encoder layer
         (28 MB of fp32 for roberta-base: large enough for the xGMI ring, 12 of them in flight behind each other) is
         queued on a communication stream behind that layer's completion events (convdr_backward_wait_layer), last
         layer first; embeddings + head follow the whole backward.  The compute stream waits for all of them at the
         end.  (force_overlap: run this path at world size 1 too -- the single-GPU test of the stream logic.)"""
         W = _world()
+        scale = 1.0 / W
+
+        def finish(tensors):
+            if average and W > 1:
+                for t in tensors:
+                    t.div_(W)
+            return 1.0 if average else scale
         if W == 1 and not force_overlap:
-            return
+            return 1.0
         from .train import _flat_view
         grads = [p.grad for p in self.model.parameters() if p.grad is not None]
         flat = _flat_view(grads)
@@ -150,15 +181,12 @@ class DataParallelStudent:
             for wk in works:
                 wk.wait()                          # the compute stream waits; the host does not
             cur.wait_stream(comm)
-            if W > 1:
-                flat.div_(W)
-            return
+            return finish([flat])
         if W == 1:
-            return
+            return 1.0
         if flat is not None:                       # one arena, but not on a GPU (gloo tests): a single collective
             dist.all_reduce(flat, group=self.group)
-            flat.div_(W)
-            return
+            return finish([flat])
         for g in grads:
             dist.all_reduce(g, group=self.group)
-            g.div_(W)
+        return finish(grads)

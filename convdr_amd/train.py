@@ -15,6 +15,7 @@ hidden / attention dropout 0.1 whose RNG streams cannot be reproduced; parity is
 """
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -125,9 +126,74 @@ def _packed_t(tower, head):
     return arr, head_t
 
 
+class _WsEntry:
+    """One activation workspace of a tower.  `owner` is a weak reference to the token held by the autograd context whose
+    saved activations live in it: the buffer may be handed to another forward only once that context has run its backward
+    (token.done) or has been dropped without one.  `gen` counts hand-outs, so a backward that finds its workspace re-used
+    (retain_graph + a second backward after a newer forward) fails loudly instead of reading foreign activations."""
+    __slots__ = ("ws", "owner", "gen")
+
+    def __init__(self, ws):
+        self.ws, self.owner, self.gen = ws, None, 0
+
+
+class _WsToken:
+    __slots__ = ("done", "__weakref__")
+
+    def __init__(self):
+        self.done = False
+
+
+def _take_workspace(tower, need, dev):
+    """A workspace of >= need bytes that no pending backward still reads (one shared buffer per tower let the
+    2nd / 3rd differentiable forward of NLL.forward(q, a, b) overwrite the activations saved by the first)."""
+    pool = tower.__dict__.setdefault("_train_ws_pool", [])
+    free = []
+    for ent in pool:
+        tok = ent.owner() if ent.owner is not None else None
+        if tok is None or tok.done:
+            free.append(ent)
+    for ent in free:
+        if ent.ws.numel() >= need and ent.ws.device == dev:
+            break
+    else:
+        for ent in free:                       # too small / wrong device: let the allocator have it back
+            pool.remove(ent)
+        ent = _WsEntry(torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev))
+        pool.append(ent)
+    token = _WsToken()
+    ent.owner, ent.gen = weakref.ref(token), ent.gen + 1
+    return ent, token
+
+
+def _pinned_upload(arr, dev):
+    """Small host array -> device tensor without blocking the host on the stream (pageable copies do)."""
+    t = torch.from_numpy(arr).pin_memory()
+    return t.to(dev, non_blocking=True)
+
+
+def _lens_and_check(ids, mask, vocab, seq_lens=None):
+    """(device int32 lens, host int32 lens).  Without caller-provided host lengths this is the one device -> host
+    round trip of a forward; the largest / smallest token id ride along and are validated like the reference's
+    embedding lookup would (IndexError instead of an out-of-bounds read)."""
+    dev = ids.device
+    if seq_lens is not None:
+        lens_host = np.ascontiguousarray(np.asarray(seq_lens, dtype=np.int32))
+        return _pinned_upload(lens_host, dev), lens_host
+    lens_dev = mask.sum(1).to(torch.int32)
+    stats = torch.cat([lens_dev, ids.max().reshape(1).to(torch.int32), ids.min().reshape(1).to(torch.int32),
+                       mask[:, 0].min().reshape(1).to(torch.int32)]).cpu().numpy()
+    lens_host = np.ascontiguousarray(stats[:-3])
+    if stats[-3] >= vocab or stats[-2] < 0:
+        raise IndexError("token id out of range for the %d-row word-embedding table (min %d, max %d)" % (vocab, stats[-2], stats[-3]))
+    if stats[-1] == 0:
+        raise ValueError("every sequence needs attention_mask[:, 0] == 1")
+    return lens_dev, lens_host
+
+
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tower, head, input_ids, attention_mask, *params):
+    def forward(ctx, tower, head, input_ids, attention_mask, seq_lens, *params):
         L_ = _lib.lib()
         ids = input_ids.long().contiguous()
         mask = attention_mask.long().contiguous()
@@ -135,23 +201,22 @@ class _EncoderFn(torch.autograd.Function):
             raise _lib.ConvdrError("encoder inputs must be CUDA tensors (no CPU fallback)")
         B, L = ids.shape
         dev = ids.device
-        seq_lens = mask.sum(1).to(torch.int32)
-        lens_host = seq_lens.cpu().numpy()
-        if lens_host.min() < 1 or not bool(mask[:, 0].all()):
-            raise ValueError("every sequence needs attention_mask[:, 0] == 1")
+        seq_lens_dev, lens_host = _lens_and_check(ids, mask, tower.embeddings.word_embeddings.num_embeddings, seq_lens)
+        if lens_host.min() < 1:
+            raise ValueError("every sequence needs at least one unmasked token")
+        tower.check_positions(int(lens_host.max()))
         cu_host = np.zeros(B + 1, np.int32)
         np.cumsum((lens_host + 7) // 8 * 8, out=cu_host[1:])
         rows, max_len = int(cu_host[-1]), int(lens_host.max())
-        cu = torch.as_tensor(cu_host, device=dev)
+        cu = _pinned_upload(cu_host, dev)
         with torch.cuda.device(dev):
             c, w, _keep = tower.packed(head)
             out = torch.empty((B, c.out_dim or c.hidden), dtype=torch.float32, device=dev)
             need = L_.convdr_encoder_train_workspace_bytes(C.byref(c), rows, B)
-            ws = getattr(tower, "_train_ws", None)
-            if ws is None or ws.numel() < need or ws.device != dev:
-                ws = tower._train_ws = torch.empty(int(need * 1.1), dtype=torch.uint8, device=dev)
+            ent, token = _take_workspace(tower, need, dev)
+            ws = ent.ws
             _lib.check(L_.convdr_encoder_train_forward(C.byref(c), C.byref(w), _lib.ptr(ids), 0, _lib.ptr(mask), B, L,
-                                                       _lib.ptr(cu), _lib.ptr(seq_lens), rows, max_len, _lib.ptr(ws),
+                                                       _lib.ptr(cu), _lib.ptr(seq_lens_dev), rows, max_len, _lib.ptr(ws),
                                                        ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
                        "convdr_encoder_train_forward")
             # the transposed weight copies are needed by the backward only: pack them on the side stream, under this
@@ -163,7 +228,8 @@ class _EncoderFn(torch.autograd.Function):
                 ctx.packed_t = _packed_t(tower, head)
                 ctx.packed_t_ready = side.record_event()
         ctx.tower, ctx.head = tower, head
-        ctx.saved = (cu, seq_lens, B, rows, max_len, ws)
+        ctx.packed = (c, w, _keep)           # the weights cannot change between a forward and its backward
+        ctx.saved = (cu, seq_lens_dev, B, rows, max_len, ent, ent.gen, token)
         ctx.shapes = [p.shape for p in params]
         return out
 
@@ -171,13 +237,16 @@ class _EncoderFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         L_ = _lib.lib()
         tower, head = ctx.tower, ctx.head
-        cu, seq_lens, B, rows, max_len, ws = ctx.saved
+        cu, seq_lens, B, rows, max_len, ent, gen, token = ctx.saved
+        if ent.gen != gen:
+            raise RuntimeError("the activation workspace of this forward has been handed to a newer forward "
+                               "(a second backward through the same graph after retain_graph is not supported)")
+        ws = ent.ws
         dev = grad_out.device
         go = grad_out.float().contiguous()
         sizes = [int(np.prod(s)) for s in ctx.shapes]
-        offs = np.concatenate([[0], np.cumsum(sizes)])
-        flat = torch.zeros(int(offs[-1]), dtype=torch.float32, device=dev)
-        views = [flat[int(o):int(o) + n].view(s) for o, n, s in zip(offs[:-1], sizes, ctx.shapes)]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        views = [v.view(s) if len(s) != 1 else v for v, s in zip(flat.split_with_sizes(sizes), ctx.shapes)]
         ptr = [v.data_ptr() for v in views]
         # the arena this call's kernels write: DataParallelStudent overlaps the all-reduce with the backward only when the
         # parameters' .grad ARE this arena (grads were None: autograd adopts the views); after an accumulation the
@@ -185,7 +254,7 @@ class _EncoderFn(torch.autograd.Function):
         tower._last_backward_arena = flat.data_ptr()
         nl = len(tower.encoder.layer)
         with torch.cuda.device(dev):
-            c, w, _keep = tower.packed(head)
+            c, w, _keep = ctx.packed
             torch.cuda.current_stream().wait_event(ctx.packed_t_ready)
             wt, head_t = ctx.packed_t
             lg = (_lib.LayerGrads * nl)()
@@ -206,11 +275,14 @@ class _EncoderFn(torch.autograd.Function):
                                                   C.c_void_p(head_t) if head_t else None, B, rows, max_len, _lib.ptr(ws),
                                                   ws.numel(), _lib.ptr(go), C.byref(gr), _lib.stream_ptr()),
                        "convdr_encoder_backward")
-        return (None, None, None, None) + tuple(views)
+        token.done = True      # (stream order: a later forward on this stream overwrites the workspace after these kernels)
+        return (None, None, None, None, None) + tuple(views)
 
 
-def encoder_autograd(model, tower, head, input_ids, attention_mask):
-    """Differentiable embeddings of `tower` (+ optional (Linear, LayerNorm) head)."""
+def encoder_autograd(model, tower, head, input_ids, attention_mask, seq_lens=None):
+    """Differentiable embeddings of `tower` (+ optional (Linear, LayerNorm) head).
+    seq_lens: optional HOST int array of the rows' token counts (right padding); with it the forward has no device ->
+    host round trip, so the host can run a whole step ahead of the GPU."""
     cfg = tower.config
     if head is None and tower is model:
         pass  # BERT tower of the BiEncoder (no projection head)
@@ -218,7 +290,7 @@ def encoder_autograd(model, tower, head, input_ids, attention_mask):
         if not getattr(model, "_dropout_notice", False):
             model._dropout_notice = True
             print("convdr_amd: training without dropout (p treated as 0; see convdr_amd/train.py)")
-    return _EncoderFn.apply(tower, head, input_ids, attention_mask, *_tower_params(tower, head))
+    return _EncoderFn.apply(tower, head, input_ids, attention_mask, seq_lens, *_tower_params(tower, head))
 
 
 # --------------------------------------------------------------------------------------------
@@ -334,12 +406,15 @@ def _flat_view(tensors):
     return torch.as_strided(base, (n,), (1,), base.storage_offset())
 
 
-def clip_grad_norm_(parameters, max_norm, defer_to=None):
+def clip_grad_norm_(parameters, max_norm, defer_to=None, extra_scale=1.0):
     """torch.nn.utils.clip_grad_norm_ (run_convdr_train.py:188-189) in one or a few kernels.  Returns the total
     norm as a device scalar (no host sync).
     defer_to: an ``AdamW`` of this module.  When the gradients form one flat arena the clip coefficient is then only
     computed and handed to the optimizer, whose update kernel multiplies it into the gradient on the fly -- one pass over
-    the 125 M gradients less; the stored gradients stay unscaled (train_step zeroes them right after the update)."""
+    the 125 M gradients less; the stored gradients stay unscaled (train_step zeroes them right after the update).
+    extra_scale: the gradients are (sum over ranks) and still have to be multiplied by this factor (1 / world size):
+    the norm and the clip coefficient are those of the scaled gradients, the scaling itself rides on the same pass."""
+    parameters = list(parameters)
     grads = [p.grad for p in parameters if p.grad is not None]
     if not grads:
         return torch.zeros(())
@@ -350,16 +425,21 @@ def clip_grad_norm_(parameters, max_norm, defer_to=None):
     with torch.cuda.device(dev):
         flat = _flat_view(grads)
         if flat is not None:
-            defer = defer_to is not None and defer_to.can_flat_step()
-            _lib.check(L.convdr_grad_norm_clip(_lib.ptr(flat), flat.numel(), float(max_norm), _lib.ptr(scratch), _lib.ptr(out),
-                                               0 if defer else 1, _lib.stream_ptr()), "convdr_grad_norm_clip")
+            defer = defer_to is not None and defer_to.can_flat_step(flat)
+            _lib.check(L.convdr_grad_norm_clip(_lib.ptr(flat), flat.numel(), float(max_norm), float(extra_scale),
+                                               _lib.ptr(scratch), _lib.ptr(out), 0 if defer else 1, _lib.stream_ptr()),
+                       "convdr_grad_norm_clip")
             if defer:
                 defer_to._pending_grad_scale = out[1:2]
             return out[0]
+        if extra_scale != 1.0:
+            sc = torch.full((1,), float(extra_scale), dtype=torch.float32, device=dev)
+            for g in grads:
+                _lib.check(L.convdr_scale_f32(_lib.ptr(g), g.numel(), _lib.ptr(sc), _lib.stream_ptr()), "convdr_scale_f32")
         norms = torch.empty((len(grads), 2), dtype=torch.float32, device=dev)
         for i, g in enumerate(grads):
             assert g.is_contiguous() and g.dtype == torch.float32
-            _lib.check(L.convdr_grad_norm_clip(_lib.ptr(g), g.numel(), float(max_norm), _lib.ptr(scratch), _lib.ptr(norms[i]),
+            _lib.check(L.convdr_grad_norm_clip(_lib.ptr(g), g.numel(), float(max_norm), 1.0, _lib.ptr(scratch), _lib.ptr(norms[i]),
                                                0, _lib.stream_ptr()), "convdr_grad_norm_clip")
         total = norms[:, 0].double().pow(2).sum().sqrt().float()
         coef = (max_norm / (total + 1e-6)).clamp(max=1.0).reshape(1).contiguous()
@@ -378,12 +458,18 @@ def _bump_version(t):
 
 
 class AdamW(torch.optim.Optimizer):
-    """transformers==2.3.0 ``AdamW`` (what utils/dpr_utils.py:87 constructs) with the fused HIP update."""
+    """transformers==2.3.0 ``AdamW`` (what utils/dpr_utils.py:87 constructs) with the fused HIP update.
+
+    ``state`` keeps the reference optimizer's layout -- per parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` -- so
+    ``state_dict()`` / ``load_state_dict()`` round-trip through the reference's checkpoints (run_convdr_train.py:34).
+    When the parameters live in one flat arena (flatten_parameters) the moments are views of two arenas of the same
+    layout and the whole model is updated by one launch."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
 
-    def _flat_operands(self):
+    # ---- flat-arena path ------------------------------------------------------------------------
+    def _flat_operands(self, G=None):
         """(params, P, G) when one launch can update the whole model: parameters in a flat arena (flatten_parameters),
         gradients in the matching arena written by the backward, all groups sharing their hyper-parameters."""
         g0 = self.param_groups[0]
@@ -394,21 +480,53 @@ class AdamW(torch.optim.Optimizer):
         if not ps:
             return ps, None, None
         P = _flat_view([p.data for p in ps])
-        G = _flat_view([p.grad for p in ps])
+        if G is None:
+            G = _flat_view([p.grad for p in ps])
         if P is None or G is None or P.numel() != G.numel():
             return None
-        order_p = sorted(ps, key=lambda p: p.data.data_ptr())
-        order_g = sorted(ps, key=lambda p: p.grad.data_ptr())
-        if any(a is not b for a, b in zip(order_p, order_g)):
+        p0, g0p = P.data_ptr(), G.data_ptr()
+        if any(p.grad.data_ptr() - g0p != p.data.data_ptr() - p0 for p in ps):     # same order in both arenas
             return None
         return ps, P, G
 
-    def can_flat_step(self):
-        ops = self._flat_operands()
-        return ops is not None and ops[1] is not None
+    def can_flat_step(self, G=None):
+        ops = self._flat_operands(G)
+        ok = ops is not None and ops[1] is not None
+        self.__dict__["_flat_ops_cache"] = ops if ok else None     # reused by the step() that follows a clip
+        return ok
+
+    def _adopt_flat_state(self, ps, P):
+        """Make ``self.state[p]['exp_avg' / 'exp_avg_sq']`` views of two arenas laid out like P (moving any state that
+        load_state_dict or the per-parameter path created into them).  Raises if the arena layout changed under existing
+        moments instead of silently restarting them from zero."""
+        st = self.__dict__.get("_flat_state")
+        if st is not None and (st["m"].numel() != P.numel() or st["m"].device != P.device or st["base"] != P.data_ptr()):
+            raise RuntimeError("AdamW: the flat parameter arena changed (size %d -> %d) under existing optimizer moments; "
+                               "build a new optimizer after flatten_parameters / resize_token_embeddings"
+                               % (st["m"].numel(), P.numel()))
+        if st is None:
+            st = self.__dict__["_flat_state"] = {"m": torch.zeros_like(P), "v": torch.zeros_like(P), "base": P.data_ptr(),
+                                                 "adopted": set()}
+        if len(st["adopted"]) == len(ps):
+            return st
+        base = P.data_ptr()
+        for p in ps:
+            if id(p) in st["adopted"]:
+                continue
+            o, n = (p.data.data_ptr() - base) // 4, p.numel()
+            mv, vv = st["m"][o:o + n].view(p.shape), st["v"][o:o + n].view(p.shape)
+            ps_state = self.state[p]
+            if len(ps_state) == 0:
+                ps_state["step"] = 0
+            else:
+                mv.copy_(ps_state["exp_avg"])
+                vv.copy_(ps_state["exp_avg_sq"])
+            ps_state["exp_avg"], ps_state["exp_avg_sq"] = mv, vv
+            st["adopted"].add(id(p))
+        return st
 
     def _try_flat_step(self):
-        ops = self._flat_operands()
+        ops = self.__dict__.pop("_flat_ops_cache", None) or self._flat_operands()
         scale = self.__dict__.pop("_pending_grad_scale", None)
         if ops is None:
             assert scale is None, "a deferred clip coefficient needs the flat update path"
@@ -417,19 +535,27 @@ class AdamW(torch.optim.Optimizer):
         if not ps:
             return True
         g0 = self.param_groups[0]
-        st = self.__dict__.setdefault("_flat_state", {})
-        if "m" not in st or st["m"].numel() != P.numel():
-            st["step"], st["m"], st["v"] = 0, torch.zeros_like(P), torch.zeros_like(P)
-        st["step"] += 1
+        st = self._adopt_flat_state(ps, P)
+        steps = {int(self.state[p]["step"]) for p in (ps[0], ps[-1])}
+        if len(steps) != 1:
+            return False                      # parameters at different step counts: per-parameter update
+        step = steps.pop() + 1
         b1, b2 = g0["betas"]
         with torch.cuda.device(P.device):
             _lib.check(_lib.lib().convdr_adamw_step(_lib.ptr(P), _lib.ptr(G), _lib.ptr(st["m"]), _lib.ptr(st["v"]), P.numel(),
-                                                    g0["lr"], b1, b2, g0["eps"], g0["weight_decay"], st["step"],
+                                                    g0["lr"], b1, b2, g0["eps"], g0["weight_decay"], step,
                                                     int(g0["correct_bias"]), _lib.ptr(scale), _lib.stream_ptr()),
                        "convdr_adamw_step")
         for p in ps:
+            self.state[p]["step"] = step
             _bump_version(p)
         return True
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        st = self.__dict__.get("_flat_state")
+        if st is not None:
+            st["adopted"] = set()             # the loaded moments are fresh tensors: move them into the arenas on the next step
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -446,9 +572,10 @@ class AdamW(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p.data, dtype=torch.float32)
                     st["exp_avg_sq"] = torch.zeros_like(p.data, dtype=torch.float32)
-                st["step"] += 1
+                st["step"] = int(st["step"]) + 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 assert p.data.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32
+                assert st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()
                 with torch.cuda.device(p.device):
                     _lib.check(L.convdr_adamw_step(_lib.ptr(p.data), _lib.ptr(g), _lib.ptr(st["exp_avg"]),
                                                    _lib.ptr(st["exp_avg_sq"]), p.numel(), group["lr"], b1, b2, group["eps"],
@@ -489,11 +616,21 @@ def _side_stream(device):
 
 
 def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=None, doc_mask=None, ddp=None, doc_embs=None,
-               force_overlap=False):
+               force_overlap=False, step=None):
     """One iteration of the reference loop body (run_convdr_train.py:101-193) with pre-tokenised ranking documents
     (`doc_ids` / `doc_mask` int64 [B * (num_negatives + 1), Ld], positive first within each group).
+    batch: (concat_ids, concat_id_mask, target_ids, target_id_mask) as in the reference, optionally followed by the two
+    HOST length arrays (concat_lens, target_lens) -- the collate function knows them for free, and with them the step has
+    no device -> host round trip, so the host enqueues a whole step ahead of the GPU.
+    step: index of this micro-batch in the epoch (the reference's ``step``); clip / optimizer / scheduler / zero_grad run
+    only when (step + 1) % gradient_accumulation_steps == 0 (run_convdr_train.py:172-193).  Required when accumulating.
     Returns (loss, loss1, loss2) as device scalars."""
-    concat_ids, concat_id_mask, target_ids, target_id_mask = batch
+    concat_ids, concat_id_mask, target_ids, target_id_mask = batch[:4]
+    concat_lens, target_lens = (batch[4], batch[5]) if len(batch) >= 6 else (None, None)
+    gas = int(getattr(args, "gradient_accumulation_steps", 1) or 1)
+    if gas > 1 and step is None:
+        raise ValueError("train_step: gradient_accumulation_steps = %d needs the micro-batch index `step`" % gas)
+    do_step = gas == 1 or (step + 1) % gas == 0
     model.train()
     teacher_model.eval()
     # The frozen teacher's forward is independent of the student's and, at 64 x 64 tokens, fills barely a third of the
@@ -501,9 +638,11 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
     main = torch.cuda.current_stream()
     side = _side_stream(concat_ids.device)
     side.wait_stream(main)
+    kw_t = {} if target_lens is None else {"seq_lens": target_lens}
+    kw_s = {} if concat_lens is None else {"seq_lens": concat_lens}
     with torch.cuda.stream(side), torch.no_grad():
-        teacher_embs = teacher_model(target_ids, target_id_mask).detach()
-    embs = model(concat_ids, concat_id_mask)
+        teacher_embs = teacher_model(target_ids, target_id_mask, **kw_t).detach()
+    embs = model(concat_ids, concat_id_mask, **kw_s)
     main.wait_stream(side)
     teacher_embs.record_stream(main)
     loss1 = None if getattr(args, "no_mse", False) else mse_loss(embs, teacher_embs)
@@ -518,11 +657,11 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
             # The reference encodes the B x (K + 1) documents 8 at a time (doc_batch_size = 8, :139 -- a memory
             # measure for 16-32 GB GPUs).  Embeddings do not depend on the batching, and 8 x 512 tokens leave the chip
             # two thirds idle (640 documents: 164 ms in eights, 68 ms in chunks of 64, tools/dbg/doc_enc.py).
-            step = int(getattr(args, "doc_batch_size", 128))
+            chunk = int(getattr(args, "doc_batch_size", 128))
             outs = []
             with torch.no_grad():
-                for i in range(0, doc_ids.shape[0], step):
-                    outs.append(teacher_model(doc_ids[i:i + step], doc_mask[i:i + step], is_query=False).detach())
+                for i in range(0, doc_ids.shape[0], chunk):
+                    outs.append(teacher_model(doc_ids[i:i + chunk], doc_mask[i:i + chunk], is_query=False).detach())
             docs = torch.cat(outs, 0).view(bs, args.num_negatives + 1, -1)
         if getattr(args, "in_batch_negatives", False):
             # configs[4] variant, off by default (the reference scores a query against its own K + 1 documents only)
@@ -531,13 +670,18 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
         else:
             loss2 = ranking_loss(embs, docs)
         loss = loss1 + loss2 if loss1 is not None else loss2
-    if getattr(args, "gradient_accumulation_steps", 1) > 1:
-        loss = loss / args.gradient_accumulation_steps
+    if gas > 1:
+        loss = loss / gas
     loss.backward()
-    if ddp is not None:
-        ddp.allreduce_grads(force_overlap=force_overlap)   # per-layer collectives under the backward (parallel.py)
-    clip_grad_norm_(list(model.parameters()), args.max_grad_norm, defer_to=optimizer if isinstance(optimizer, AdamW) else None)
-    optimizer.step()
-    scheduler.step()
-    model.zero_grad()
+    if do_step:
+        scale = 1.0
+        if ddp is not None:
+            # per-layer collectives under the backward when the gradients are fresh (parallel.py); SUM over ranks --
+            # the 1 / world factor rides on the clip / AdamW pass instead of costing its own pass over 0.5 GB
+            scale = ddp.allreduce_grads(force_overlap=force_overlap, average=False)
+        clip_grad_norm_(list(model.parameters()), args.max_grad_norm, defer_to=optimizer if isinstance(optimizer, AdamW) else None,
+                        extra_scale=scale)
+        optimizer.step()
+        scheduler.step()
+        model.zero_grad()
     return loss.detach(), loss1, loss2

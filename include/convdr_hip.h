@@ -250,11 +250,13 @@ int convdr_inbatch_ce_fwd_bwd(const float* embs, const float* docs, int B, int N
                               float grad_scale, float* loss_per_query, float* d_embs, int accumulate,
                               convdr_stream_t stream);
 
-/* torch.nn.utils.clip_grad_norm_ over one flat fp32 gradient buffer: norm_and_coef[0] = ||g||_2,
- * norm_and_coef[1] = min(1, max_norm / (norm + 1e-6)); apply != 0 scales the gradients in place.
+/* torch.nn.utils.clip_grad_norm_ over one flat fp32 gradient buffer whose entries still have to be multiplied by
+ * pre_scale (1 / world size after a SUM all-reduce; 1 otherwise):  norm_and_coef[0] = ||pre_scale * g||_2,
+ * norm_and_coef[1] = pre_scale * min(1, max_norm / (norm + 1e-6)) = the factor the stored gradients are multiplied by;
+ * apply != 0 does that in place, otherwise the caller hands norm_and_coef + 1 to convdr_adamw_step (grad_scale).
  * scratch: >= 1024 floats. */
-int convdr_grad_norm_clip(float* grads, int64_t n, float max_norm, float* scratch, float* norm_and_coef, int apply,
-                          convdr_stream_t stream);
+int convdr_grad_norm_clip(float* grads, int64_t n, float max_norm, float pre_scale, float* scratch, float* norm_and_coef,
+                          int apply, convdr_stream_t stream);
 
 /* x[i] *= scale[0] (device scalar), e.g. the clip coefficient */
 int convdr_scale_f32(float* x, int64_t n, const float* scale, convdr_stream_t stream);

@@ -33,6 +33,20 @@ def main(path):
         print("queue %s: %4d kernels, busy %.3f ms, span %.3f ms, positive gaps %d (sum %.3f ms, median %.2f us)" % (
             q, len(ks), busy / 1e6, (ks[-1][1] - ks[0][0]) / 1e6, len(pos), sum(pos) / 1e6,
             (sorted(pos)[len(pos) // 2] / 1e3) if pos else 0.0))
+    prev_end = rows[ends[-2]][2]
+    print("bubble between the previous optimizer kernel and this step's first kernel: %.3f ms" % ((t0 - prev_end) / 1e6))
+    allk = sorted(step, key=lambda r: r[1])
+    # device idle: time inside the step's wall span when no kernel of any queue is running
+    idle, cur_end = 0, allk[0][1]
+    biggest = []
+    for n, s_, e_, q in allk:
+        if s_ > cur_end:
+            idle += s_ - cur_end
+            biggest.append((s_ - cur_end, n[:60]))
+        cur_end = max(cur_end, e_)
+    print("device idle inside the step: %.3f ms" % (idle / 1e6))
+    for g, n in sorted(biggest, reverse=True)[:12]:
+        print("   idle %8.1f us before %s" % (g / 1e3, n))
     agg = defaultdict(lambda: [0, 0])
     for n, s, e, q in step:
         agg[n[:70]][0] += 1
