@@ -15,3 +15,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Dump the measured-vs-bar table of the parity tests (tests/helpers.py:margin) next to the other GPU artefacts."""
+    from tests import helpers
+    if not helpers.MARGINS:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "margins.json"), "w") as f:
+            json.dump(helpers.MARGINS, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

@@ -485,7 +485,56 @@ def gen_train():
     print("train fixture written: steps", gs, "loss1", log["loss1"], "loss2", log["loss2"], "norms", log["norms"])
 
 
-GROUPS = {"encoder": gen_encoder, "search": gen_search, "encode_loop": gen_encode_loop, "train": gen_train}
+# ----------------------------------------------------------------------------
+def gen_evaluate():
+    """Query-encode loop: run_convdr_inference.py:116-154 (``evaluate``) run on a stub dataset (the reference's
+    ConvSearchDataset needs the tokenizer / raw files, which are out of scope; ``evaluate`` only needs __len__, __getitem__
+    and get_collate_fn(args, "inference") -> dict with qid / concat_ids / concat_id_mask / history_utterances).  Weights:
+    the tiny rdot_nll model already stored in encoder_rdot_nll.npz."""
+    import contextlib
+    import io
+    from types import SimpleNamespace
+    import torch
+    sys.argv = sys.argv[:1]
+    M, U, DU, T = import_reference()
+    sys.path.insert(0, os.path.join(REF, "drivers"))
+    import run_convdr_inference as R
+    z = np.load(os.path.join(HERE, "encoder_rdot_nll.npz"))
+    model = M.MSMarcoConfigDict["rdot_nll"].model_class(tiny_roberta_config())
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")})
+    rng = np.random.RandomState(77)
+    nq, L = 11, 48                                   # batches of 4 -> 4 + 4 + 3 (ragged last batch)
+    lens = [48, 7, 30, 1, 19, 48, 12, 33, 5, 41, 26]
+    ids, mask = synth_ids(rng, nq, L, lens)
+    qids = ["%d_%d" % (31 + i // 4, 1 + i % 4) for i in range(nq)]
+    hist = [["utt %d of %s" % (j, q) for j in range(1 + i % 3)] for i, q in enumerate(qids)]
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return nq
+
+        def __getitem__(self, i):
+            return i
+
+        def get_collate_fn(self, args, mode):
+            assert mode == "inference"
+
+            def fn(idx):
+                return {"qid": [qids[i] for i in idx], "concat_ids": torch.from_numpy(ids[idx]),
+                        "concat_id_mask": torch.from_numpy(mask[idx]), "history_utterances": [hist[i] for i in idx]}
+            return fn
+    args = SimpleNamespace(per_gpu_eval_batch_size=4, n_gpu=1, device=torch.device("cpu"), seed=42)
+    with contextlib.redirect_stdout(io.StringIO()):
+        emb, emb2id, raw = R.evaluate(args, DS(), model, logging.getLogger("golden"))
+    assert emb.shape == (nq, 768) and emb2id == qids and raw == hist
+    np.savez_compressed(os.path.join(HERE, "evaluate.npz"), ids=ids, mask=mask, qids=np.array(qids),
+                        hist=np.array(json.dumps(hist)), batch=np.array(4), embedding=emb,
+                        embedding2id=np.array(emb2id), raw_sequences=np.array(json.dumps(raw)))
+    print("evaluate fixture written", emb.shape, emb.dtype)
+
+
+GROUPS = {"encoder": gen_encoder, "search": gen_search, "encode_loop": gen_encode_loop, "train": gen_train,
+          "evaluate": gen_evaluate}
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

@@ -304,3 +304,35 @@ def test_ragged_large_batch_matches_oracle_on_a_sample():
         alone = model.body_emb(torch.from_numpy(ids[sample]).cuda(), torch.from_numpy(mask[sample]).cuda())
     cs = cosine(emb[sample].cpu().numpy(), alone.cpu().numpy())
     assert cs.min() > 1 - 1e-4, cs
+
+
+def test_evaluate_loop_matches_reference_fixture(golden_dir):
+    """convdr_amd.inference.evaluate against what the reference's own evaluate
+    (run_convdr_inference.py:116-154) returned for the same stub dataset: embeddings, query-id order, raw utterances."""
+    import json
+    import logging
+    from types import SimpleNamespace
+    from convdr_amd.inference import evaluate
+    z = np.load(os.path.join(golden_dir, "evaluate.npz"))
+    model = _tiny_rdot(np.load(os.path.join(golden_dir, "encoder_rdot_nll.npz")))
+    ids, mask = z["ids"], z["mask"]
+    qids = [str(q) for q in z["qids"]]
+    hist = json.loads(str(z["hist"]))
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(qids)
+
+        def __getitem__(self, i):
+            return i
+
+        def get_collate_fn(self, args, mode):
+            assert mode == "inference"
+            return lambda idx: {"qid": [qids[i] for i in idx], "concat_ids": torch.from_numpy(ids[idx]),
+                                "concat_id_mask": torch.from_numpy(mask[idx]), "history_utterances": [hist[i] for i in idx]}
+    args = SimpleNamespace(per_gpu_eval_batch_size=int(z["batch"]), n_gpu=1, device=torch.device("cuda"), seed=42)
+    emb, emb2id, raw = evaluate(args, DS(), model, logging.getLogger("test"))
+    assert emb.dtype == np.float32 and emb.shape == z["embedding"].shape
+    _check(torch.from_numpy(emb), z["embedding"], "evaluate")
+    assert emb2id == [str(q) for q in z["embedding2id"]]
+    assert raw == json.loads(str(z["raw_sequences"]))

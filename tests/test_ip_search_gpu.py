@@ -178,16 +178,17 @@ def test_device_merge_equals_reference_pointer_walk(torch_cuda):
             assert [int(x) for x in Io[q]] == [int(i) for _, i in ref]
 
 
-def test_full_size_properties_1m_x_1k(torch_cuda):
-    """BASELINE config 2 size (1M x 768, 1k queries, k=100): size-independent properties,
-    checked with an independent fp32 GEMM (torch/rocBLAS) on the same device."""
+@pytest.mark.parametrize("n", [1_000_000, 4_750_000])
+def test_full_size_properties_1m_x_1k(torch_cuda, n):
+    """BASELINE configs[1] size (1M x 768) and the configs[3] per-GPU shard (38M / 8 = 4.75M x 768), 1k queries, k = 100:
+    size-independent properties, checked with an independent fp32 GEMM (torch/rocBLAS) on the same device."""
     torch = torch_cuda
-    n, nq, k, d = 1_000_000, 1000, 100, 768
+    nq, k, d = 1000, 100, 768
     g = torch.Generator(device="cuda").manual_seed(0)
     P = torch.randn(n, d, device="cuda", generator=g)
     Q = torch.randn(nq, d, device="cuda", generator=g)
     # planted needles: passage 1000*q+17 is a copy of query q (score |q|^2 ~ 768 >> 5 sigma) -> must be rank 1
-    needles = torch.arange(nq, device="cuda") * 1000 + 17
+    needles = torch.arange(nq, device="cuda") * (n // nq) + 17
     P[needles] = Q
     idx = _index()
     idx.add(P)
@@ -259,3 +260,20 @@ def test_sharded_search_exchange_over_rccl(torch_cuda):
     assert int(st.sum()) == 0
     np.testing.assert_array_equal(I.cpu().numpy(), 5 + 3 * Ir)
     np.testing.assert_array_equal(D.cpu().numpy(), Dr)
+
+
+def test_rank_merge_on_device_equals_stable_sort(torch_cuda):
+    """parallel.merge_rank_topk on the GPU (chain of convdr_topk_merge calls, what 8 ranks' lists go through) against the
+    stable-sort definition the gloo tests use -- lists full of ties inside and across ranks, -1 / -FLT_MAX padding."""
+    torch = torch_cuda
+    from convdr_amd import parallel
+    rs = np.random.RandomState(9)
+    for W, nq, k in ((8, 33, 100), (2, 5, 10), (3, 7, 1), (8, 4, 256)):
+        D = np.sort(rs.randint(0, 60, size=(W, nq, k)).astype(np.float32) * 0.5, axis=2)[:, :, ::-1].copy()
+        I = rs.randint(0, 10 ** 12, size=(W, nq, k)).astype(np.int64)
+        D[W - 1, :, k - k // 4:] = -3.4028234663852886e38
+        I[W - 1, :, k - k // 4:] = -1
+        Dc, Ic = parallel.merge_rank_topk(torch.from_numpy(D), torch.from_numpy(I), k)
+        Dg, Ig = parallel.merge_rank_topk(torch.from_numpy(D).cuda(), torch.from_numpy(I).cuda(), k)
+        np.testing.assert_array_equal(Dg.cpu().numpy(), Dc.numpy())
+        np.testing.assert_array_equal(Ig.cpu().numpy(), Ic.numpy())

@@ -122,3 +122,40 @@ def test_multi_chunk_matches_reference(golden_dir):
     q = OE.rdot_nll_emb(sd, t("ids_q"), t("m_q"), num_layers=2, num_heads=2)
     loss = OE.multi_chunk_nll(q, a, b, t("m_a"), t("m_b"))
     assert abs(loss.item() - float(z["mc/loss"])) < 1e-4 * max(1.0, abs(float(z["mc/loss"])))
+
+
+def test_evaluate_loop_matches_reference(golden_dir):
+    """run_convdr_inference.py:116-154 run by the reference itself (make_golden.py:gen_evaluate) vs oracle/inference.py."""
+    from oracle import inference as OI
+    z = np.load(os.path.join(golden_dir, "evaluate.npz"))
+    sd = _sd(np.load(os.path.join(golden_dir, "encoder_rdot_nll.npz")))
+    hist = json.loads(str(z["hist"]))
+    emb, emb2id, raw = OI.evaluate(sd, z["ids"], z["mask"], [str(q) for q in z["qids"]], hist, int(z["batch"]),
+                                   num_layers=2, num_heads=2)
+    assert emb.dtype == np.float32 and emb.shape == z["embedding"].shape
+    np.testing.assert_allclose(emb, z["embedding"], atol=2e-5, rtol=0)
+    assert emb2id == [str(q) for q in z["embedding2id"]]
+    assert raw == json.loads(str(z["raw_sequences"]))
+
+
+def test_product_eval_dev_query_writes_the_reference_text(golden_dir, tmp_path):
+    """convdr_amd.search.EvalDevQuery (the PRODUCT result writer, host code: no GPU needed) against the .trec and .jsonl
+    text the reference's EvalDevQuery wrote for the same inputs (run_convdr_inference.py:21-113): byte-identical, incl.
+    duplicate-pid removal, the positive label and json float formatting of the scores."""
+    from convdr_amd.search import EvalDevQuery
+    z = np.load(os.path.join(golden_dir, "search.npz"))
+    topN = int(z["a/topN"])
+    qids = [str(q) for q in z["d/qids"]]
+    offset2pid = z["d/offset2pid"].tolist()
+    with open(tmp_path / "queries.raw.tsv", "w") as f:
+        for q in qids:
+            f.write("%s\tquery text %s\n" % (q, q))
+    with open(tmp_path / "collection.tsv", "w") as f:
+        for pid in sorted(set(offset2pid)):
+            f.write("%d\tpassage %d body\n" % (pid, pid))
+    raw = [["hist %s" % q, "cur %s" % q] for q in qids]
+    pos = {str(z["d/pos_qid"]): {int(z["d/pos_pid"]): int(z["d/pos_label"])}}
+    EvalDevQuery(qids, z["a/merged_D"], pos, z["a/merged_I"], topN, str(tmp_path / "o.jsonl"), str(tmp_path / "o.trec"),
+                 offset2pid, str(tmp_path), "raw", raw_sequences=raw)
+    assert open(tmp_path / "o.trec").read() == str(z["d/trec"])
+    assert open(tmp_path / "o.jsonl").read() == str(z["d/jsonl"])
