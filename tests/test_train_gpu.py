@@ -46,15 +46,30 @@ def _oracle_grads(model, ids, mask, G, layers=2):
     return emb.detach(), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
 
 
-def _compare(name, g, ref, cos_tol=0.99, norm_tol=0.03):
+_WORST = {}
+
+
+def _compare(name, g, ref, cos_tol=0.99, norm_tol=0.03, tag=None):
+    """Gradient vs reference: cosine and norm ratio.  With `tag` the worst values of the calling test are kept and
+    recorded by _record_worst (measured margins -> gpurun_out/margins.json)."""
     g, ref = g.detach().cpu().double().reshape(-1), ref.double().reshape(-1)
     rn = ref.norm().item()
     if rn < 1e-12:
         assert g.norm().item() < 1e-6, name
         return
     c = float((g @ ref) / (g.norm() * ref.norm() + 1e-300))
+    nd = abs(g.norm().item() / rn - 1)
+    if tag is not None:
+        w = _WORST.setdefault(tag, [0.0, 0.0])
+        w[0], w[1] = max(w[0], 1 - c), max(w[1], nd)
     assert c > cos_tol, "%s: cosine %.5f" % (name, c)
-    assert abs(g.norm().item() / rn - 1) < norm_tol, "%s: norm ratio %.4f" % (name, g.norm().item() / rn)
+    assert nd < norm_tol, "%s: norm ratio %.4f" % (name, g.norm().item() / rn)
+
+
+def _record_worst(tag, cos_bar, norm_bar):
+    w = _WORST[tag]
+    margin(tag + "/grad_worst_1-cos", w[0], cos_bar)
+    margin(tag + "/grad_worst_norm_dev", w[1], norm_bar)
 
 
 @pytest.mark.parametrize("B,L,lens", [(5, 40, [40, 17, 33, 1, 8]), (3, 130, [130, 64, 65])])
@@ -79,11 +94,12 @@ def test_encoder_backward_matches_autograd(B, L, lens):
                 qb = dict(model.named_parameters())[n.replace("key.bias", "query.bias")].grad
                 assert p.grad.norm().item() < 0.02 * qb.norm().item() + 1e-6, n
             else:
-                _compare(n, p.grad, ref[n])
+                _compare(n, p.grad, ref[n], cos_tol=1 - 2e-4, norm_tol=6e-3, tag="bwd_tiny_L%d" % L)
             seen += 1
         else:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n       # pooler / classifier: unused
     assert seen == len(ref)
+    _record_worst("bwd_tiny_L%d" % L, 2e-4, 6e-3)       # measured 3.6e-5 / 1.8e-3 (MI355X, r02)
 
 
 def test_backward_is_deterministic_and_accumulates():
@@ -197,13 +213,15 @@ def test_train_steps_match_reference_run(golden_dir):
             loss, l1, l2 = TR.train_step(args, student, teacher, opt, sched,
                                          (g("concat_ids"), g("concat_id_mask"), g("target_ids"), g("target_id_mask")),
                                          torch.from_numpy(doc_ids).cuda(), torch.from_numpy(doc_mask).cuda())
-            assert abs(l1.item() - z["loss1"][step]) < 2e-2 * z["loss1"][step] + 2e-5, (step, l1.item(), z["loss1"][step])
+            # (the reference's loss1 starts at 2.8e-4 -- student == teacher weights -- so the error is taken relative to
+            #  loss1 + 1e-3: bf16 noise of two different forward paths is an absolute ~1e-5 on it)
+            margin("replay/step%d_loss1_rel" % step, abs(l1.item() - z["loss1"][step]) / (z["loss1"][step] + 1e-3), 4e-2)       # measured <= 1.9e-2
             # logits are 768-d dots of ~27-norm vectors (|logit| ~ 10^2): bf16-level embedding error moves the CE by ~1e-2
-            assert abs(l2.item() - z["loss2"][step]) < 3e-2, (step, l2.item(), z["loss2"][step])
+            margin("replay/step%d_loss2_abs" % step, abs(l2.item() - z["loss2"][step]), 4e-2)   # measured <= 1.8e-2
     finally:
         TR.clip_grad_norm_ = orig
     # the ranking-loss gradient (softmax - onehot) . docs inherits the CE sensitivity above: direction cos ~0.97, norm +5 %
-    np.testing.assert_allclose(norms, z["grad_norm"], rtol=8e-2)
+    margin("replay/grad_norm_rel", float(np.max(np.abs(np.asarray(norms) / z["grad_norm"] - 1))), 0.12)   # measured 0.060
     # parameters: compare the UPDATE (w1 - w0).  Adam normalises every element's step to ~lr, so elements whose
     # gradient is rounding noise (exactly-zero true gradients such as key.bias, tiny LayerNorm terms) move by a
     # full-size pseudo-random step in BOTH implementations; the optimizer arithmetic itself is pinned bit-tight by
@@ -218,8 +236,9 @@ def test_train_steps_match_reference_run(golden_dir):
         dot += float((du * dr).sum()); nu += float((du ** 2).sum()); nr += float((dr ** 2).sum())
         if dr.abs().max() == 0:
             assert du.abs().max() < 1e-7, k          # untouched parameters (pooler / classifier) stay untouched
-    assert nr > 0 and dot / (nu * nr) ** 0.5 > 0.9, dot / (nu * nr) ** 0.5
-    assert abs((nu / nr) ** 0.5 - 1) < 0.05, (nu / nr) ** 0.5
+    assert nr > 0
+    margin("replay/update_1-cos", 1 - dot / (nu * nr) ** 0.5, 0.12)          # measured 0.051
+    margin("replay/update_norm_dev", abs((nu / nr) ** 0.5 - 1), 8e-3)         # measured 1.9e-3
 
 
 def test_flat_arena_training_matches_per_parameter_path():
@@ -293,11 +312,12 @@ def test_dpr_tower_backward_matches_autograd():
     seen = 0
     for n, p in model.named_parameters():
         if n in ref and not n.endswith("key.bias") and "pooler" not in n:
-            _compare(n, p.grad, ref[n])
+            _compare(n, p.grad, ref[n], cos_tol=1 - 2e-4, norm_tol=1e-2, tag="bwd_dpr")
             seen += 1
         elif n.startswith("ctx_model"):
             assert p.grad is None
     assert seen > 20
+    _record_worst("bwd_dpr", 2e-4, 1e-2)                  # measured 4.4e-5 / 2.9e-3
 
 
 def test_inbatch_negative_loss_matches_oracle():
@@ -437,9 +457,10 @@ def test_backward_at_256_tile_scale_matches_autograd():
     checked = 0
     for n, p in model.named_parameters():
         if n in ref and not n.endswith("attention.self.key.bias"):
-            _compare(n, p.grad, ref[n])
+            _compare(n, p.grad, ref[n], cos_tol=1 - 3e-4, norm_tol=2e-3, tag="bwd_256tile")
             checked += 1
     assert checked >= 20
+    _record_worst("bwd_256tile", 3e-4, 2e-3)              # measured 6.7e-5 / 4.6e-4
 
 
 @pytest.mark.parametrize("rows,N,K,pad", [(1000, 128, 256, 0), (77, 72, 40, 8), (4100, 768, 384, 0), (64, 8, 8, 0), (1, 136, 264, 16),
@@ -516,9 +537,10 @@ def test_nll_triple_loss_backward_matches_autograd():
         if n in ref and not n.endswith("attention.self.key.bias") and ref[n].norm() > 1e-8:
             # (sums over every token of gradients driven by |logit| ~ 1e2 scores: cancellation-limited in bf16; a
             #  workspace mix-up -- what this test is for -- gives cosines near 0)
-            _compare(n, p.grad, ref[n], cos_tol=0.95, norm_tol=0.15)
+            _compare(n, p.grad, ref[n], cos_tol=0.88, norm_tol=0.2, tag="nll_triple")
             seen += 1
     assert seen > 30
+    _record_worst("nll_triple", 0.12, 0.2)                # measured 0.050 / 0.078 (token_type sum: cancellation)
 
 
 def test_gradient_accumulation_gates_the_optimizer_step():
