@@ -49,60 +49,60 @@ def synthetic_tokens(n, L, seed, device):
     return ids
 
 
-def cpu_baseline(nq, d, k, L, budget_s=12.0):
+def cpu_baseline(nq, d, k, L, budget_s=7.0):
     """The reference's CPU path restated and timed on the host cores (bounded samples of the same workload):
     encode = the fp32 oracle forward (HF-free restatement of RobertaDot_NLL_LN.body_emb), search = exact fp32
-    Q @ P.T + top-k (what FAISS-CPU IndexFlatIP computes; FAISS is not installed anywhere)."""
+    Q @ P.T + top-k (what FAISS-CPU IndexFlatIP computes; FAISS is not installed anywhere).
+    Timed with torch.set_num_threads(os.cpu_count()) as BASELINE.md section 4 states -- `value` / `cores` -- and, because
+    a 16-passage forward does not scale to hundreds of threads, also with 64 threads (reported beside it)."""
     import torch
     from oracle import encoder as OE
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
     model = random_rdot_model()
     sd = {k_: v.detach() for k_, v in model.state_dict().items()}
     B = 16
     ids = synthetic_tokens(B, L, 0, "cpu").long()
     mask = torch.ones_like(ids)
-    with torch.no_grad():
-        OE.rdot_nll_emb(sd, ids[:2], mask[:2], num_layers=LAYERS, num_heads=HEADS)
-        t0, reps = time.perf_counter(), 0
-        while time.perf_counter() - t0 < budget_s and reps < 20:
-            OE.rdot_nll_emb(sd, ids, mask, num_layers=LAYERS, num_heads=HEADS)
-            reps += 1
-        enc_rate = B * reps / (time.perf_counter() - t0)
     n = 50_000
     g = torch.Generator().manual_seed(0)
     P, Q = torch.randn(n, d, generator=g), torch.randn(nq, d, generator=g)
-    t0, r2 = time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s and r2 < 40:
-        torch.topk(Q @ P.T, k, dim=1)
-        r2 += 1
-    ip_rate = nq * n * r2 / (time.perf_counter() - t0)
-    # "cores" = the threads the timed port actually ran on (the contract's meaning); the host's core count beside it
-    return {"value": enc_rate, "unit": "passages/s", "cores": threads, "host_cores": cores, "kind": "port",
-            "ip_pairs_per_s": ip_rate,
-            "sample": "encode: %d x %d-token passages x %d reps, fp32 torch oracle of RobertaDot_NLL_LN (12 x 768); "
-                      "search: %d queries x %d passages x %d reps, fp32 SGEMM + topk(%d)" % (B, L, reps, nq, n, r2, k)}
+
+    def run(threads):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            OE.rdot_nll_emb(sd, ids[:2], mask[:2], num_layers=LAYERS, num_heads=HEADS)
+            t0, reps = time.perf_counter(), 0
+            while time.perf_counter() - t0 < budget_s and reps < 20:
+                OE.rdot_nll_emb(sd, ids, mask, num_layers=LAYERS, num_heads=HEADS)
+                reps += 1
+            enc_rate = B * reps / (time.perf_counter() - t0)
+        t0, r2 = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s and r2 < 40:
+            torch.topk(Q @ P.T, k, dim=1)
+            r2 += 1
+        return enc_rate, nq * n * r2 / (time.perf_counter() - t0), reps, r2
+    enc_rate, ip_rate, reps, r2 = run(cores)
+    out = {"value": enc_rate, "unit": "passages/s", "cores": cores, "host_cores": cores, "kind": "port",
+           "ip_pairs_per_s": ip_rate,
+           "sample": "encode: %d x %d-token passages x %d reps, fp32 torch oracle of RobertaDot_NLL_LN (12 x 768); "
+                     "search: %d queries x %d passages x %d reps, fp32 SGEMM + topk(%d)" % (B, L, reps, nq, n, r2, k)}
+    if cores > 64:
+        e64, i64, _, _ = run(64)
+        out["with_64_threads"] = {"value": e64, "ip_pairs_per_s": i64, "cores": 64}
+    return out
 
 
-def main_train(args):
-    """configs[2]: run_convdr_train.py KD-only loop (MSE teacher-student), batch 64, seq 256, synthetic turns."""
+def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=True):
+    """configs[2]: run_convdr_train.py KD-only loop (MSE teacher-student), batch 64, seq 256, synthetic turns.
+    Returns the JSON-able result dict on rank 0 (None elsewhere); the caller owns the process group."""
     import numpy as np
     import torch
     import torch.distributed as dist
     from types import SimpleNamespace
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist_on = world > 1 or bool(os.environ.get("CONVDR_BENCH_FORCE_DIST"))   # (the latter: 1-rank rehearsal of the N > 1 path)
-    if dist_on:
-        dist.init_process_group("nccl", device_id=dev)
     from convdr_amd import _lib, train as TR
     from convdr_amd.parallel import DataParallelStudent
     L_ = _lib.lib()
-    Bt, Ls, Lt = args.train_batch, 256, 64
+    Ls, Lt = 256, 64
     student = random_rdot_model(0).to(dev)
     teacher = random_rdot_model(0).to(dev).eval()
     student.config.hidden_dropout_prob = student.config.attention_probs_dropout_prob = 0.0
@@ -113,6 +113,7 @@ def main_train(args):
     sched = TR.get_linear_schedule_with_warmup(opt, 0, 10_000)
     ddp = DataParallelStudent(student) if dist_on else None
     g = torch.Generator(device=dev).manual_seed(rank)
+
     def turns(L, lo):
         ids = torch.randint(3, 50000, (Bt, L), generator=g, device=dev)
         ids[:, 0] = 0
@@ -134,51 +135,161 @@ def main_train(args):
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     sync_all()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         loss = step(i)[0]
     sync_all()
     el = time.perf_counter() - t0
-    # per-kernel breakdown from a separate short pass: the hipEvent pair around each of the ~740 launches of a step
-    # costs the host several milliseconds per step, which at this batch size would be the thing measured
-    prof_steps = min(4, args.steps)
-    L_.convdr_prof_enable(1)
-    for i in range(prof_steps):
-        step(i)
-    sync_all()
-    names = ("gemm_qkv", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2", "gemm_dgrad", "gemm_wgrad", "attention", "attention_bwd",
-             "transpose", "layernorm_bwd")
     kern = {}
-    for nme in names:
-        ms, cnt = _lib.prof_collect(nme)
-        if cnt:
-            kern[nme] = {"ms_per_step": ms / prof_steps, "launches_per_step": cnt / prof_steps}
-    L_.convdr_prof_enable(0)
+    if with_kernels:
+        # per-kernel breakdown from a separate short pass: the hipEvent pair around each of the ~450 launches of a step
+        # costs the host several milliseconds per step, which at this batch size would be the thing measured
+        prof_steps = min(4, steps)
+        L_.convdr_prof_enable(1)
+        for i in range(prof_steps):
+            step(i)
+        sync_all()
+        names = ("gemm_qkv", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2", "gemm_dgrad", "gemm_wgrad", "attention", "attention_bwd",
+                 "dgelu_colsum", "layernorm_bwd")
+        for nme in names:
+            ms, cnt = _lib.prof_collect(nme)
+            if cnt:
+                kern[nme] = {"ms_per_step": ms / prof_steps, "launches_per_step": cnt / prof_steps}
+        L_.convdr_prof_enable(0)
     if dist_on:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
-        dist.destroy_process_group()
     if rank != 0:
-        return
+        return None
     real_tokens = float(np.mean([b[1].sum().item() for b in batches]))   # (after the timed region)
     flop_dense = Bt * (3 * flop_per_passage(Ls) + flop_per_passage(Lt))
     flop_real = 3 * LINEAR_FLOP_PER_TOKEN * real_tokens
-    sps = world * Bt * args.steps / el
-    print(json.dumps({
+    sps = world * Bt * steps / el
+    out = {
         "metric": "KD training samples/s (configs[2]: run_convdr_train.py KD-only, batch %d, seq %d/%d)" % (Bt, Ls, Lt),
-        "value": sps, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": sps, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16 compute, fp32 master weights / optimizer", "data": "synthetic OR-QuAC-shaped turns (ragged)",
         "config": {"workload": "configs[2] train_kd", "batch_per_gpu": Bt, "student_seq": Ls, "teacher_seq": Lt,
                    "parallelism": "dp%d" % world, "mean_real_student_tokens": real_tokens},
         "final_loss": float(loss),
         "TFLOPs_dense_padded_count": sps / world * flop_dense / Bt / 1e12,
-        "TFLOPs_real_token_count_linear_only": flop_real * args.steps / el / 1e12,
-        "kernels": kern}))
+        "TFLOPs_real_token_count_linear_only": flop_real * steps / el / 1e12,
+        "frac_of_bf16_mfma_peak_real_tokens": flop_real * steps / el / 1e12 / MFMA_BF16_PEAK_TFLOPS / world,
+        "kernels": kern}
+    del student, teacher, opt, batches
+    torch.cuda.empty_cache()
+    return out
+
+
+def main_train(args):
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist_on = world > 1 or bool(os.environ.get("CONVDR_BENCH_FORCE_DIST"))   # (the latter: 1-rank rehearsal of the N > 1 path)
+    if dist_on:
+        dist.init_process_group("nccl", device_id=dev)
+    out = train_kd_measure(dev, rank, world, dist_on, args.steps, args.warmup, args.train_batch)
+    if dist_on:
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+def extras(dev, index, model, tower, head, building, filled_rows, nq, k, d, Q):
+    """Legs reported beside the headline line (rank 0 of a 1-GPU run, outside the timed region)."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import torch
+    from convdr_amd import blocks
+    from convdr_amd.search import FlatIPIndex
+    out = {}
+    # ---- (1) block file -> HBM: mmap'd pickle payload, pinned double-buffered chunks, bf16 preparation under the copy ----
+    td = tempfile.mkdtemp(prefix="convdr_bench_")
+    try:
+        host = index._p32.cpu().numpy()
+        path = os.path.join(td, "passage__emb_p__data_obj_0.pb")
+        blocks.dump_block(path, host)
+        del host
+        rates = []
+        for rep in range(2):                      # rep 0 also pins the staging buffers; the file is in the page cache
+            with blocks.BlockView(path) as bv:
+                fresh = FlatIPIndex(d, device=dev)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fresh.add(bv)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                rates.append(bv.array.nbytes / dt / 1e9)
+                nb = bv.array.nbytes
+                if rep == 1:
+                    Dc, Ic = fresh.search_tensors(Q, k)
+                    Dm, Im = index.search_tensors(Q, k)
+                    same = bool((Ic == Im).all().item() and (Dc == Dm).all().item())
+                del fresh
+        out["block_load"] = {"GB_per_s": rates[-1], "GB_per_s_first_touch": rates[0], "bytes": nb,
+                             "chunk_MB": 64, "pcie_gen5_x16_GB_per_s": 63.0, "results_identical_to_resident_block": same,
+                             "host_threads": len(os.sched_getaffinity(0)),
+                             "path": "blocks.BlockView (payload offset of the pickle) -> positioned reads, 16 slices in flight, into "
+                                     "2 pinned staging buffers -> H2D on a copy stream, convdr_ip_prepare_block of chunk i under "
+                                     "the copy of chunk i + 1"}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    out.update(extras_search(dev, index, tower, head, building, filled_rows, nq, k, d))
+    return out
+
+
+def extras_search(dev, index, tower, head, building, filled_rows, nq, k, d):
+    import numpy as np
+    import torch
+    from convdr_amd.search import FlatIPIndex
+    out = {}
+    # ---- (2) search realism: what the encoder produces is clustered, which the N(0,1) corpus of the headline is not ----
+    def timed_search(idx, Qx, reps=3):
+        idx.search_tensors(Qx, k)                  # first search of the block: walks the precision ladder
+        torch.cuda.synchronize()
+        first = dict(idx.stats)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            idx.search_tensors(Qx, k)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        st = dict(idx.stats)
+        return {"ms_per_search_incl_certify": ms, "pairs_per_s": Qx.shape[0] * idx.ntotal / (ms / 1e3),
+                "queries_retried": st.get("retried"), "queries_on_split_bf16_scan": st.get("x3_queries"),
+                "frac_on_split_bf16_scan": (st.get("x3_queries") or 0) / float(Qx.shape[0]), "kernel_rounds": st.get("rounds"),
+                "started_on_split_bf16_scan": st.get("x3_first"), "first_search_of_block": first}
+    g = torch.Generator(device=dev).manual_seed(7)
+    n = index.ntotal
+    c = torch.randn(d, device=dev, generator=g)
+    Pc = 0.9 * c[None, :] + 0.12 * torch.randn(n, d, device=dev, generator=g)      # pairwise cosine ~ 0.98
+    Qc = 0.9 * c[None, :] + 0.12 * torch.randn(nq, d, device=dev, generator=g)
+    clustered = FlatIPIndex(d, device=dev)
+    clustered.add(Pc)
+    del Pc
+    out["search_clustered"] = dict(timed_search(clustered, Qc), corpus="synthetic clustered: p = 0.9 c + 0.12 N(0,1), %d x %d" % (n, d))
+    del clustered
+    # the block the encoder wrote in the timed region (random-init roberta-base: LayerNorm'ed, strongly clustered outputs),
+    # queries = freshly encoded token sequences
+    with torch.no_grad():
+        qtok = synthetic_tokens(min(nq, 1024), 32, 999, dev)
+        Qe = tower.embed(qtok, None, head=head, seq_lens=np.full(qtok.shape[0], 32, np.int32))
+    enc_idx = FlatIPIndex(d, device=dev)
+    enc_idx.add(building._p32[:filled_rows])     # (rows of the ring no step has written yet are zeros)
+    out["search_encoded_block"] = dict(timed_search(enc_idx, Qe), corpus="the %d passages this run encoded (bench ring), %d encoded queries"
+                                       % (enc_idx.ntotal, Qe.shape[0]))
+    del enc_idx
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -192,6 +303,9 @@ def main():
     ap.add_argument("--enc-batch", type=int, default=2048)
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs reported beside the headline line: block file -> HBM load rate, search over "
+                         "encoder-produced / clustered blocks, the configs[2] KD training step")
     ap.add_argument("--workload", default="encode_search", choices=["encode_search", "train_kd"],
                     help="encode_search = BASELINE configs[1] (the headline line); train_kd = configs[2]: KD-only "
                          "(MSE teacher-student) training steps, batch 64, student seq 256, teacher seq 64")
@@ -335,6 +449,17 @@ def main():
                                                     "algorithmic bytes = %d" % (rows * H * 2 + rows * I * 2 + H * I * 2))
     except Exception:
         pass
+    if world == 1 and not dist_on and not args.no_extras:
+        try:
+            line.update(extras(dev, index, model, tower, head, building, min(slots, args.steps + args.warmup) * EB, nq, k, d, Q))
+            del index, building, model
+            torch.cuda.empty_cache()
+            kd = train_kd_measure(dev, 0, 1, False, 10, 3, 64)
+            line["train_kd"] = {kk: kd[kk] for kk in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "final_loss",
+                                                      "TFLOPs_dense_padded_count", "TFLOPs_real_token_count_linear_only",
+                                                      "frac_of_bf16_mfma_peak_real_tokens", "kernels")}
+        except Exception as e:      # the extras must never cost the headline line
+            line["extras_error"] = "%s: %s" % (type(e).__name__, e)
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(nq, d, k, SL)
     print(json.dumps(line))

@@ -29,10 +29,19 @@ constexpr int IP_MODE_FULL = 0, IP_MODE_TOP2 = 1, IP_MODE_EMIT = 2;
 constexpr int IP_FULL_MAX_N = 32768;      // <= this many passages: "sample" = all scores, exact rank select
 constexpr int IP_SAMPLE_MIN = 32768;      // sampled passages (>= 1/32 of the block)
 constexpr int IP_SAMPLE_MAX = 262144;
-constexpr float IP_EPS_COEF = 0.0079f;    // bf16 scan: 2u + u^2 + K*2^-24 with u = 2^-8, rounded up (K <= 4096)
-// split-bf16 scan (hi*hi + hi*lo + lo*hi): dropped terms 3 u^2 = 4.6e-5, fp32 accumulation of 3K products
-// 3 * 4096 * 2^-24 = 7.4e-4 worst case -> rounded up
-constexpr float IP_EPS_COEF_X3 = 8.0e-4f;
+// Error-band coefficients: |scan score - exact score| <= coef * |q| * max|p - centre| for every passage of the block.
+// u = 2^-8 bounds the relative error of a bf16 rounding, the accumulation term charges 2^-23 per accumulated product
+// (gamma_K of an fp32 sum whose per-step rounding is at worst truncation: the MFMA's internal rounding is not
+// documented; it sums 8-16 products per step, so this over-counts) relative to sum |q_i p_i| <= |q| |p|.  Computed from d
+// (round 1 used constants that only covered d <= 1024 with the 2^-24 model).
+//   bf16 scan:        (1 + u)^2 - 1 = 2u + u^2          + d * 2^-23
+//   split-bf16 scan:  hi*hi + hi*lo + lo*hi leaves out lo*lo and the two second-rounding remainders,
+//                     each <= u^2 (1 + u) |q| |p|         + 3 d * 2^-23 (one accumulator chain over the three passes)
+static inline float ip_eps_coef(int d, bool x3) {
+  const double u = 1.0 / 256.0, acc = (double)d / 8388608.0;
+  const double c = x3 ? 3.0 * u * u * (1.0 + 2.0 * u) + 3.0 * acc : 2.0 * u + u * u + acc;
+  return (float)(c * 1.0001);
+}
 
 // ------------------------------------------------------------------------------------------
 // rows fp32 -> bf16 of (x - centre) (+ per-row L2 norm of the centred row, + global max norm).
@@ -895,9 +904,16 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
         r = (int64_t)R < n ? R : (int)n;
         if (int e = launch_scan<IP_MODE_FULL>(a, p.big, st)) return e;
       } else {
+        // The sample keeps the two best scores of every 64 sampled passages, so it can only represent a rank whose expected
+        // hits per 64 passages stay well below 2: R <= n / 128 (half a hit per 64).  Blocks of 32 k .. 200 k passages
+        // therefore aim at a lower rank than 16 k (n = 47,104 asked for rank 1,113 of a 1,024-value sample: no threshold,
+        // every passage emitted, every query overflowed and was re-run); a band that then reaches below the threshold
+        // comes back UNCERTAIN with the threshold to retry, as for any clustered block.
+        if ((int64_t)R > n / 128) R = (int)(n / 128 > k ? n / 128 : k);
         const double frac = (double)p.nSt * p.tr / (double)n;
         r = (int)lrint(R * frac);
         if (r < 8) r = 8;
+        if (r > p.nvals / 4) r = (int)(p.nvals / 4);
         if (int e = launch_scan<IP_MODE_TOP2>(a, p.big, st)) return e;
       }
       static DeviceOnce attr_done;
@@ -920,7 +936,7 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
   ProfScope prof("ip_cut", st);
   hipLaunchKernelGGL(k_ip_cut, dim3(nq), dim3(1024), (size_t)cap * 8, st, n, k, cap, counts,
                      (uint32_t*)(ws + p.o_counts_packed), cand_id, cand_s, tau, qnorm,
-                     p_max_norm, p_bf16_lo ? IP_EPS_COEF_X3 : IP_EPS_COEF, band, status, tau_retry);
+                     p_max_norm, ip_eps_coef(d, p_bf16_lo != nullptr), band, status, tau_retry);
   CONVDR_CHECK_LAUNCH("k_ip_cut");
   }
   if (n > 0) {

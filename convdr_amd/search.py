@@ -11,6 +11,7 @@ All scoring / selection runs in libconvdr_hip.so (csrc/ip_topk.hip).
 import json
 import os
 import pickle
+import warnings
 
 import numpy as np
 
@@ -45,6 +46,9 @@ class FlatIPIndex:
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.cap, self.rank_target = int(cap), int(rank_target)
         self.precision, self.center = precision, bool(center)
+        self.host_chunk_bytes = 64 << 20       # staging-buffer size of the streamed host -> HBM path (add); 64 MB x 16
+                                               # threads measured best on the bench host (tools/dbg/block_load_sweep.py)
+        self.host_copy_threads = 16            # file reads / memcpy slices in flight while filling a staging buffer
         self.stats = {}
         self.reset()
 
@@ -61,6 +65,9 @@ class FlatIPIndex:
         self._centre = None
         self._max_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._ws = None
+        self._x3_first = False
+        if not hasattr(self, "_copy_stream"):
+            self._copy_stream, self._stage = None, None
 
     def _prepare(self, t, want_lo):
         import torch
@@ -72,9 +79,24 @@ class FlatIPIndex:
                    "convdr_ip_prepare_block")
         return pbf, plo
 
-    def add(self, x):
-        """x: numpy / torch [n, d] float32 (host or device).  Appends to the index."""
+    def add(self, x, chunk_bytes=None):
+        """x: numpy / torch [n, d] float32 (host or device).  Appends to the index.
+        A HOST array -- typically the memory-mapped payload of a block file (blocks.BlockView) -- is streamed: chunks of
+        ~chunk_bytes (default 64 MB) go through two pinned staging buffers, the H2D copy of chunk i + 1 (copy stream) runs under the
+        centring / bf16 rounding / norm pass of chunk i (convdr_ip_prepare_block), and the host fills one staging buffer
+        (page faults on the mmap = the disk read) while the other is in flight.  The reference does pickle.load (a full
+        host copy of the 14.6 GB block) and a pageable copy (run_convdr_inference.py:164-180)."""
         import torch
+        chunk_bytes = int(chunk_bytes or self.host_chunk_bytes)
+        if hasattr(x, "read_rows_into") and hasattr(x, "array"):        # a blocks.BlockView: positioned reads from the file
+            arr = x.array
+            if arr.dtype == np.float32 and arr.ndim == 2 and arr.nbytes > chunk_bytes // 2:
+                return self._add_host_streamed(arr, chunk_bytes, reader=x.read_rows_into)
+            x = arr
+        if isinstance(x, np.ndarray) or (isinstance(x, torch.Tensor) and x.device.type == "cpu" and not x.is_pinned()):
+            arr = x if isinstance(x, np.ndarray) else x.numpy()
+            if arr.dtype == np.float32 and arr.ndim == 2 and arr.shape[0] * arr.shape[1] * 4 > chunk_bytes // 2:
+                return self._add_host_streamed(arr, chunk_bytes)
         t = torch.as_tensor(x)
         if t.dtype != torch.float32:
             t = t.float()
@@ -84,12 +106,19 @@ class FlatIPIndex:
             return
         with torch.cuda.device(self.device):
             if self._p32 is None and self.center:
-                self._centre = torch.empty(self.d, dtype=torch.float32, device=self.device)
-                scratch = torch.empty(64 * self.d, dtype=torch.float32, device=self.device)
-                _lib.check(_lib.lib().convdr_ip_column_mean(_lib.ptr(t), t.shape[0], self.d, _lib.ptr(scratch),
-                                                           _lib.ptr(self._centre), _lib.stream_ptr()),
-                           "convdr_ip_column_mean")
+                self._set_centre(t)
             pbf, plo = self._prepare(t, self.precision == "bf16x3" or self._plo is not None)
+        self._append(t, pbf, plo)
+
+    def _set_centre(self, t):
+        import torch
+        self._centre = torch.empty(self.d, dtype=torch.float32, device=self.device)
+        scratch = torch.empty(64 * self.d, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().convdr_ip_column_mean(_lib.ptr(t), t.shape[0], self.d, _lib.ptr(scratch),
+                                                   _lib.ptr(self._centre), _lib.stream_ptr()), "convdr_ip_column_mean")
+
+    def _append(self, t, pbf, plo):
+        import torch
         if self._p32 is None:
             self._p32, self._pbf, self._plo = t, pbf, plo
         else:  # FAISS semantics: add() appends (the centring vector stays the first block's mean)
@@ -97,6 +126,66 @@ class FlatIPIndex:
             self._pbf = torch.cat([self._pbf, pbf], 0)
             if plo is not None:
                 self._plo = torch.cat([self._plo, plo], 0)
+
+    def _add_host_streamed(self, arr, chunk_bytes, reader=None):
+        import time
+        import torch
+        n, d = arr.shape
+        assert d == self.d, "expected [n, %d], got %s" % (self.d, arr.shape)
+        L = _lib.lib()
+        rows_per = max(1, int(chunk_bytes) // (4 * d))
+        want_lo = self.precision == "bf16x3" or self._plo is not None
+        t0 = time.perf_counter()
+        with torch.cuda.device(self.device):
+            main = torch.cuda.current_stream()
+            if getattr(self, "_copy_stream", None) is None:
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+                self._stage = None
+            if self._stage is None or self._stage[0].shape[0] < min(rows_per, n):
+                self._stage = [torch.empty((min(rows_per, n), d), dtype=torch.float32).pin_memory() for _ in range(2)]
+            cs = self._copy_stream
+            p32 = torch.empty((n, d), dtype=torch.float32, device=self.device)
+            pbf = torch.empty((n, d), dtype=torch.bfloat16, device=self.device)
+            plo = torch.empty((n, d), dtype=torch.bfloat16, device=self.device) if want_lo else None
+            cs.wait_stream(main)                    # (p32 / pbf allocation order)
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            threads = max(1, min(int(self.host_copy_threads), avail))
+            if getattr(self, "_pool", None) is None or self._pool_threads != threads:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool, self._pool_threads = ThreadPoolExecutor(max_workers=threads), threads
+            pool = self._pool
+            freed = [None, None]                    # staging buffer i may be refilled once its H2D copy has completed
+            first = self._p32 is None
+            for ci, s in enumerate(range(0, n, rows_per)):
+                e = min(n, s + rows_per)
+                buf = self._stage[ci & 1]
+                if freed[ci & 1] is not None:
+                    freed[ci & 1].synchronize()
+                dst = buf.numpy()[:e - s]
+                if reader is not None:
+                    reader(dst, s, e, pool=pool, parts=threads)          # positioned file reads, `threads` slices in flight
+                else:                                                    # an array in host memory: parallel memcpy
+                    step = (e - s + threads - 1) // threads
+                    futs = [pool.submit(np.copyto, dst[a:a + step], arr[s + a:s + a + step]) for a in range(0, e - s, step)]
+                    for f in futs:
+                        f.result()
+                with torch.cuda.stream(cs):
+                    p32[s:e].copy_(buf[:e - s], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(cs)
+                freed[ci & 1] = ev
+                main.wait_event(ev)
+                if first and self.center and ci == 0:
+                    # centre = column mean of the first chunk (>= 40 k passages): any centre keeps the search exact -- it
+                    # shifts every score of a query by the same constant -- it only has to be close to the mean to shrink
+                    # the bf16 error band
+                    self._set_centre(p32[s:e])
+                _lib.check(L.convdr_ip_prepare_block(_lib.ptr(p32[s:e]), e - s, d, _lib.ptr(self._centre), _lib.ptr(pbf[s:e]),
+                                                     _lib.ptr(plo[s:e]) if plo is not None else None, _lib.ptr(self._max_norm),
+                                                     _lib.stream_ptr()), "convdr_ip_prepare_block")
+            self._append(p32, pbf, plo)
+        self.stats["add_host_s"] = time.perf_counter() - t0     # host time to enqueue (the last chunks are still in flight)
+        self.stats["add_host_bytes"] = n * d * 4
 
     def _ensure_lo(self):
         """Remainder copy for the split-bf16 scan, built on first use."""
@@ -193,7 +282,12 @@ class FlatIPIndex:
         return D.cpu().numpy(), I.cpu().numpy()
 
     def search_tensors(self, q, k):
-        """``search`` with the certified result left on the device (torch fp32 [nq, k], int64 [nq, k])."""
+        """``search`` with the certified result left on the device (torch fp32 [nq, k], int64 [nq, k]).
+
+        precision="auto": the bf16 scan first; queries it cannot certify are re-run -- with a lower threshold while their
+        error band still fits the candidate list, with the split-bf16 scan (10x tighter band) once the band has swallowed
+        the whole list (encoder outputs: after centring, |p - mean| ~ 1.5 against score spreads of ~0.5).  The index
+        remembers when most queries of a block ended on the split scan and starts there next time (`x3_first`)."""
         import torch
         qt = torch.as_tensor(q)
         if qt.dtype != torch.float32:
@@ -201,19 +295,41 @@ class FlatIPIndex:
         qt = qt.to(self.device).contiguous()
         assert qt.dim() == 2 and qt.shape[1] == self.d
         k = int(k)
-        x3 = self.precision == "bf16x3"
+        nq = int(qt.shape[0])
+        x3 = self.precision == "bf16x3" or (self.precision == "auto" and getattr(self, "_x3_first", False) and self.ntotal > 0)
         D, I, status, tau_retry = self.search_device(qt, k, x3=x3)
-        self.stats = {"retried": int((status != 0).sum().item()), "rounds": 1, "x3_queries": qt.shape[0] if x3 else 0}
-        bad = self._certify(qt, k, D, I, status, tau_retry, x3) if self.stats["retried"] else []
-        if len(bad) and self.precision == "auto":
+        self.stats = {"retried": int((status != 0).sum().item()), "rounds": 1, "x3_queries": nq if x3 else 0, "x3_first": bool(x3)}
+        bad = []
+        if self.stats["retried"]:
+            if self.precision == "auto" and not x3:
+                # a band that already covers every emitted candidate only grows with a lower threshold: those queries go
+                # straight to the split scan, the others get their bf16 retries
+                emitted, band = self.last_counts(nq, k)
+                st = status.cpu().numpy()
+                sat = ((band >= emitted) & (emitted > 0)).cpu().numpy() & (st == STATUS_UNCERTAIN)
+                retry_idx = np.nonzero((st != 0) & ~sat)[0]
+                bad = list(np.nonzero(sat)[0])
+                if len(retry_idx):
+                    sub = torch.as_tensor(retry_idx, device=self.device)
+                    Db, Ib, sb, tb = D[sub], I[sub], status[sub], tau_retry[sub]
+                    left = self._certify(qt[sub].contiguous(), k, Db, Ib, sb, tb, False)
+                    D[sub], I[sub] = Db, Ib
+                    bad += list(retry_idx[np.asarray(left, dtype=np.int64)]) if len(left) else []
+                bad = np.asarray(sorted(bad), dtype=np.int64)
+            else:
+                bad = self._certify(qt, k, D, I, status, tau_retry, x3)
+        if len(bad) and self.precision == "auto" and not x3:
             # second rung: split-bf16 scan for the queries the bf16 error band cannot separate
             idx = torch.as_tensor(bad, device=self.device)
             qs = qt[idx].contiguous()
             self.stats["x3_queries"] = len(bad)
             Db, Ib, sb, tb = self.search_device(qs, k, x3=True)
+            self.stats["rounds"] += 1
             bad2 = self._certify(qs, k, Db, Ib, sb, tb, True) if int((sb != 0).sum().item()) else []
             D[idx], I[idx] = Db, Ib
             bad = bad[np.asarray(bad2, dtype=np.int64)] if len(bad2) else []
+        if self.precision == "auto":
+            self._x3_first = self.stats["x3_queries"] > nq // 2
         if len(bad):
             raise _lib.ConvdrError("convdr_ip_search: %d queries could not be certified (more than 8192 passages inside the "
                                    "error band of the k-th score even with the split-bf16 scan)" % len(bad))
@@ -257,30 +373,48 @@ def merge_topk_device(merged, cand, topN):
 
 def search_one_by_one(ann_data_dir, gpu_index, query_embedding, topN, max_blocks=8):
     """Block-by-block search + merge; same contract as the reference function (float64 scores, int64 offsets,
-    2 * topN columns once two blocks have been merged).  With a FlatIPIndex the per-block results, the offset lookup
-    ``embid[I]`` and the running merge stay on the device; any other index object (``.add/.search/.reset``) takes the
-    reference's host path."""
+    2 * topN columns once two blocks have been merged).  With a FlatIPIndex the embedding block is memory-mapped
+    (blocks.BlockView: no pickle.load copy) and streamed to HBM in pinned chunks (FlatIPIndex.add), and the per-block
+    results, the offset lookup ``embid[I]`` and the running merge stay on the device; any other index object
+    (``.add/.search/.reset``) takes the reference's host path."""
+    from . import blocks
     on_device = hasattr(gpu_index, "search_tensors")
     merged = None
     for block_id in range(max_blocks):
+        emb_path = os.path.join(ann_data_dir, "passage__emb_p__data_obj_%d.pb" % block_id)
+        view = None
         try:
-            passage_embedding = load_block(os.path.join(ann_data_dir, "passage__emb_p__data_obj_%d.pb" % block_id))
+            if on_device:
+                view = blocks.BlockView(emb_path)
+                passage_embedding = view
+            else:
+                passage_embedding = load_block(emb_path)
             passage_embedding2id = load_block(os.path.join(ann_data_dir, "passage__embid_p__data_obj_%d.pb" % block_id))
         except Exception:
+            if view is not None:
+                view.close()
             break
-        gpu_index.add(passage_embedding)
-        if on_device:
-            import torch
-            D, I = gpu_index.search_tensors(query_embedding, topN)
-            embid = torch.as_tensor(np.asarray(passage_embedding2id, dtype=np.int64), device=D.device)
-            ids = torch.where(I >= 0, embid[I.clamp_min(0)], I) if embid.numel() else I   # -1 padding when n < topN
-            cand = (D, ids)
-            merged = cand if merged is None else merge_topk_device(merged, cand, topN)
-        else:
-            D, I = gpu_index.search(query_embedding, topN)
-            cand = (D.astype(np.float64), np.asarray(passage_embedding2id)[I])
-            merged = cand if merged is None else merge_topk(merged, cand, topN)
-        gpu_index.reset()
+        try:
+            gpu_index.add(passage_embedding)
+            if on_device:
+                import torch
+                D, I = gpu_index.search_tensors(query_embedding, topN)
+                embid = torch.as_tensor(np.asarray(passage_embedding2id, dtype=np.int64), device=D.device)
+                ids = torch.where(I >= 0, embid[I.clamp_min(0)], I) if embid.numel() else I   # -1 padding when n < topN
+                cand = (D, ids)
+                merged = cand if merged is None else merge_topk_device(merged, cand, topN)
+            else:
+                D, I = gpu_index.search(query_embedding, topN)
+                cand = (D.astype(np.float64), np.asarray(passage_embedding2id)[I])
+                merged = cand if merged is None else merge_topk(merged, cand, topN)
+            gpu_index.reset()
+        finally:
+            if view is not None:
+                if on_device:
+                    import torch
+                    torch.cuda.synchronize(gpu_index.device)    # the streamed copy reads the mapping until it completes
+                passage_embedding = None
+                view.close()
     if merged is None:
         raise FileNotFoundError("no passage blocks under %s" % ann_data_dir)
     if on_device:
@@ -291,22 +425,26 @@ def search_one_by_one(ann_data_dir, gpu_index, query_embedding, topN, max_blocks
 def EvalDevQuery(query_embedding2id, merged_D, dev_query_positive_id, I_nearest_neighbor, topN, output_file,
                  output_trec_file, offset2pid, raw_data_dir, output_query_type, raw_sequences=None,
                  load_collection=None):
-    """Result writer with the reference's exact text output (run_convdr_inference.py:21-113)."""
+    """Result writer with the reference's exact text output (run_convdr_inference.py:21-113).
+    The offset -> pid mapping and the first-occurrence de-duplication (:56-69) run as array operations per query (one
+    gather + one np.unique over the topN candidates) instead of the reference's Python loop over nq x topN entries."""
     ranked = {}
     raw = {}
-    for query_idx in range(len(I_nearest_neighbor)):
-        seen_pid = set()
+    o2p = np.asarray(offset2pid)
+    I_top = np.asarray(I_nearest_neighbor)[:, :topN]
+    D_top = np.asarray(merged_D)[:, :topN]
+    pids_all = o2p[I_top]                                   # offset -> pid for every candidate at once
+    for query_idx in range(len(I_top)):
         query_id = query_embedding2id[query_idx]
         if query_id not in ranked:
             ranked[query_id] = [(0, 0)] * topN
         raw[query_id] = raw_sequences[query_idx]
-        rank = 0
-        for idx, score in zip(I_nearest_neighbor[query_idx][:topN], merged_D[query_idx][:topN].tolist()):
-            pred_pid = offset2pid[idx]
-            if pred_pid not in seen_pid:
-                ranked[query_id][rank] = (pred_pid, score)
-                rank += 1
-                seen_pid.add(pred_pid)
+        row = pids_all[query_idx]
+        _, first = np.unique(row, return_index=True)        # first occurrence of every pid ...
+        first.sort()                                        # ... in rank order
+        scores = D_top[query_idx][first].tolist()
+        for rank, (pid, score) in enumerate(zip(row[first].tolist(), scores)):
+            ranked[query_id][rank] = (pid, score)
     queries = {}
     with open(os.path.join(raw_data_dir, "queries." + output_query_type + ".tsv")) as f:
         for line in f:

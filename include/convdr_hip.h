@@ -66,7 +66,7 @@ size_t convdr_ip_workspace_bytes(int nq, int64_t n, int d, int k, int cap);
  *            S~ >= tau[q] are appended to a candidate list (a [nq, n] score matrix is never written);
  *            tau comes from a bf16 scan of a 1/32 sample of the block, aimed at `rank_target` hits per
  *            query (or tau_in when given);
- *   cut      with eps = 0.0079 * ||q|| * max||p|| (rigorous bound on |S~ - exact|): the band
+ *   cut      with eps = (2u + u^2 + d 2^-23) * ||q|| * max||p||, u = 2^-8 (rigorous bound on |S~ - exact|; 0.00792 at d = 768): the band
  *            {S~ >= S~(k) - 2 eps} provably contains the exact top-k;
  *   rescore  the band is re-scored from the fp32 originals in fp64 with the canonical summation order
  *            documented in oracle/search.py, and sorted by (score desc, index asc).
@@ -77,8 +77,8 @@ size_t convdr_ip_workspace_bytes(int nq, int64_t n, int d, int k, int cap);
  * (-1 / -FLT_MAX padding when n < k, as FAISS does), status [nq] int32, tau_retry [nq] fp32.
  * tau_in: NULL, or device [nq] thresholds (retry path).  cap: candidate capacity per query
  * (power of two, 1024..8192).  rank_target: expected candidates per query (0 -> 16*k, at most cap/2).
- * p_bf16_lo: NULL = plain bf16 scan (eps = 0.0079 |q| max|p'|); non-NULL = split-bf16 scan S~ = Ph Qh + Ph Ql + Pl Qh
- * (three MFMA passes, eps = 8e-4 |q| max|p'|): the second rung for clustered embeddings whose top scores are closer
+ * p_bf16_lo: NULL = plain bf16 scan (eps = 0.00792 |q| max|p'| at d = 768); non-NULL = split-bf16 scan S~ = Ph Qh + Ph Ql + Pl Qh
+ * (three MFMA passes, eps = (3 u^2 + 3 d 2^-23) |q| max|p'| = 3.2e-4 at d = 768): the second rung for clustered embeddings whose top scores are closer
  * together than the bf16 error band. */
 int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, const void* p_bf16, const void* p_bf16_lo, int64_t n, int d,
                      int k, const float* p_max_norm, const float* tau_in, int cap, int rank_target,

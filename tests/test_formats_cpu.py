@@ -84,3 +84,68 @@ def test_plan_batches_token_budget():
         assert e == len(lens) or al[s:e + 1].sum() > 4096
     assert plan_batches([], 8, 100) == []
     assert plan_batches([700], 8, 100) == [(0, 1)]
+
+
+def test_doc_embedding_lookup_gathers_rows_by_pid(tmp_path):
+    """blocks.DocEmbeddingLookup (f-2): three ragged round-robin blocks as a 3-rank encode run writes them
+    (utils/util.py:422-424, :108-111) -> rows by passage id through pid2offset, dict and array forms, unknown ids raise."""
+    from convdr_amd import blocks
+    rs = np.random.RandomState(3)
+    total, W, d = 1000, 3, 768
+    emb_all = rs.randn(total, d).astype(np.float32)
+    for r in range(W):
+        idx = np.arange(r, total, W, dtype=np.int64)
+        blocks.dump_block(str(tmp_path / ("passage__emb_p__data_obj_%d.pb" % r)), emb_all[idx])
+        blocks.dump_block(str(tmp_path / ("passage__embid_p__data_obj_%d.pb" % r)), idx)
+    perm = rs.permutation(total)
+    pid2offset = {int(7 * p + 1): int(o) for o, p in enumerate(perm)}          # pid = 7 * perm[offset] + 1
+    want_pids = [7 * int(perm[o]) + 1 for o in (5, 999, 0, 5, 333, 334)]
+    with blocks.DocEmbeddingLookup(str(tmp_path), pid2offset) as lk:
+        got = lk.gather(want_pids)
+        np.testing.assert_array_equal(got, emb_all[[5, 999, 0, 5, 333, 334]])
+        with pytest.raises(KeyError):
+            lk.gather([12345678])
+    arr = np.zeros(7 * total + 2, np.int64)
+    for p, o in pid2offset.items():
+        arr[p] = o
+    with blocks.DocEmbeddingLookup(str(tmp_path), arr, n_blocks=3) as lk:
+        np.testing.assert_array_equal(lk.gather(want_pids), got)
+    with blocks.DocEmbeddingLookup(str(tmp_path)) as lk:                      # ids are offsets
+        np.testing.assert_array_equal(lk.gather([5, 999]), emb_all[[5, 999]])
+
+
+def test_block_larger_than_4gib_uses_binbytes8(tmp_path):
+    """utils/util.py:108-111 at CAsT scale writes 14.6 GB blocks: pickle protocol 4 stores payloads >= 4 GiB with the
+    8-byte-length BINBYTES8 opcode.  dump_block must produce that form (readable by pickle.load, what the reference does
+    at run_convdr_inference.py:164-175) and BlockView must map it.  The array is 4 GiB + 3 MB of untouched (zero) pages
+    plus planted rows, so the test costs disk I/O, not memory."""
+    import pickle
+    import shutil
+    from convdr_amd import blocks
+    if shutil.disk_usage(str(tmp_path)).free < 6 * (1 << 30):
+        pytest.skip("needs 6 GB of scratch disk")
+    n, d = (1 << 32) // (768 * 4) + 1000, 768
+    arr = np.zeros((n, d), np.float32)                      # calloc: pages are not touched until written
+    assert arr.nbytes > 0xffffffff
+    planted = {0: 1.5, 1234567: -2.25, n - 1: 3.75}
+    for r, v in planted.items():
+        arr[r, :] = v
+        arr[r, 5] = r % 1000
+    path = str(tmp_path / "passage__emb_p__data_obj_0.pb")
+    blocks.dump_block(path, arr)
+    del arr
+    with open(path, "rb") as f:
+        head = f.read(256)
+    assert b"\x8e" + (n * d * 4).to_bytes(8, "little") in head, "payload must be introduced by BINBYTES8"
+    with blocks.BlockView(path) as bv:
+        assert bv.array.shape == (n, d) and bv.array.dtype == np.float32
+        for r, v in planted.items():
+            assert bv.array[r, 0] == v and bv.array[r, 5] == r % 1000
+        assert bv.array[n // 2].max() == 0.0
+    with open(path, "rb") as f:
+        back = pickle.load(f)                               # what the reference's search driver does
+    assert back.shape == (n, d) and back.dtype == np.float32
+    for r, v in planted.items():
+        assert back[r, 0] == v and back[r, 5] == r % 1000
+    del back
+    os.remove(path)

@@ -277,3 +277,58 @@ def test_rank_merge_on_device_equals_stable_sort(torch_cuda):
         Dg, Ig = parallel.merge_rank_topk(torch.from_numpy(D).cuda(), torch.from_numpy(I).cuda(), k)
         np.testing.assert_array_equal(Dg.cpu().numpy(), Dc.numpy())
         np.testing.assert_array_equal(Ig.cpu().numpy(), Ic.numpy())
+
+
+def test_streamed_host_block_equals_resident_block(torch_cuda, tmp_path):
+    """FlatIPIndex.add of a HOST array (the mmap of a block file) goes through pinned, double-buffered chunks with the
+    bf16 preparation of chunk i under the copy of chunk i + 1; results must be bit-identical to adding the same block from
+    device memory -- including across several chunks with a ragged tail, for an appended second block, and through
+    search_one_by_one reading BlockView mappings."""
+    torch = torch_cuda
+    from convdr_amd import blocks
+    from convdr_amd.search import search_one_by_one
+    P0, P1, Q = synth_corpus(51, 30011, 768), synth_corpus(52, 7001, 768), synth_corpus(53, 23, 768)
+    ref = _index()
+    ref.add(torch.from_numpy(P0).cuda())
+    ref.add(torch.from_numpy(P1).cuda())
+    Dr, Ir = ref.search(Q, 100)
+    for r, P in enumerate((P0, P1)):
+        blocks.dump_block(str(tmp_path / ("passage__emb_p__data_obj_%d.pb" % r)), P)
+    idx = _index()
+    idx.host_chunk_bytes = 5 << 20                           # 1706 rows per chunk: 18 chunks + a ragged tail
+    views = [blocks.BlockView(str(tmp_path / ("passage__emb_p__data_obj_%d.pb" % r))) for r in range(2)]
+    for v in views:
+        assert isinstance(v.array, np.ndarray) and not v.array.flags.writeable      # the mmap, not a copy
+        idx.add(v.array)
+    D, I = idx.search(Q, 100)
+    torch.cuda.synchronize()
+    for v in views:
+        v.close()
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D, Dr)
+    # the driver function over the same files (embid = identity + 10^6 r)
+    for r, P in enumerate((P0, P1)):
+        blocks.dump_block(str(tmp_path / ("passage__embid_p__data_obj_%d.pb" % r)), np.arange(len(P), dtype=np.int64) + 10 ** 6 * r)
+    idx2 = _index()
+    idx2.host_chunk_bytes = 5 << 20
+    mD, mI = search_one_by_one(str(tmp_path), idx2, Q, 100)
+    oD, oI = OS.search_one_by_one([(P0, np.arange(len(P0), dtype=np.int64)), (P1, np.arange(len(P1), dtype=np.int64) + 10 ** 6)], Q, 100)
+    np.testing.assert_array_equal(mI, oI)
+    np.testing.assert_array_equal(mD, oD)
+
+
+@pytest.mark.parametrize("n", [33000, 47104, 70000, 150000])
+def test_mid_size_blocks_get_a_threshold(torch_cuda, n):
+    """Blocks between the exact-threshold range (<= 32 k passages) and the 1/32-sample range: the sampled threshold must
+    exist (round 2 found n = 47,104 emitting every passage for every query and certifying only through the overflow retry)
+    and the result stays bit-exact."""
+    P, Q = synth_corpus(61, n, 768), synth_corpus(62, 40, 768)
+    idx = _index()
+    idx.add(P)
+    D, I, st, _ = idx.search_device(torch_cuda.from_numpy(Q).cuda(), 100)
+    emitted, band = idx.last_counts(40, 100)
+    assert int(emitted.max()) < 4096, int(emitted.max())
+    assert int((st != 0).sum()) == 0
+    Dr, Ir = OS.flat_ip_search(Q, P, 100)
+    np.testing.assert_array_equal(I.cpu().numpy(), Ir)
+    np.testing.assert_array_equal(D.cpu().numpy(), Dr)

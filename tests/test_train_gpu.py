@@ -687,3 +687,48 @@ def test_kd_step_at_configs2_size_matches_autograd():
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in student.parameters() if p.grad is not None)).item()
     gr = np.sqrt(sum(float((v.grad.double() ** 2).sum()) for v in sd_s.values() if v.requires_grad and v.grad is not None))
     margin("cfg2/grad_norm_rel", abs(gn / gr - 1), 2e-3)            # 5.7e-4
+
+
+def test_ranking_step_with_looked_up_document_embeddings(tmp_path):
+    """the teacher's document embeddings for the ranking loss come from the corpus blocks
+    (blocks.DocEmbeddingLookup by doc_pos_id / doc_negs_id, data/gen_ranking_data.py:595-600) instead of re-encoding
+    10 documents per sample per step (run_convdr_train.py:118-159).  Lookup == re-encode (the blocks were written by the
+    same teacher), so loss2 and the student's gradients agree to rounding of the different batch compositions."""
+    from types import SimpleNamespace
+    from convdr_amd import blocks, train as TR
+    from convdr_amd.encode import StreamInferenceDoc
+    rs = np.random.RandomState(31)
+    teacher = _tiny(seed=2).cuda().eval()
+    n_pass, Ld, B, K = 300, 64, 4, 9
+    lens = rs.randint(5, Ld + 1, size=n_pass)
+    doc_ids, doc_mask = _batch(rs, n_pass, Ld, lens)
+    # corpus token cache -> blocks, written by the teacher through the product's corpus-encode loop (2 "ranks")
+    with open(tmp_path / "passages", "wb") as f:
+        for i in range(n_pass):
+            f.write(int(lens[i]).to_bytes(4, "big") + doc_ids[i].numpy().astype(np.int32).tobytes())
+    with open(tmp_path / "passages_meta", "w") as f:
+        json.dump({"type": "int32", "total_number": n_pass, "embedding_size": Ld}, f)
+    for r in range(2):
+        with blocks.TokenCache(str(tmp_path / "passages")) as cache:
+            StreamInferenceDoc(SimpleNamespace(output_dir=str(tmp_path), rank=r, world_size=2, per_gpu_eval_batch_size=64,
+                                               max_seq_length=Ld), teacher, cache)
+    pids = rs.permutation(100000)[:n_pass]                 # passage id of record offset i
+    pid2offset = {int(p): i for i, p in enumerate(pids)}
+    groups = rs.randint(0, n_pass, size=(B, K + 1))        # per sample: positive first, then the sampled negatives
+    with blocks.DocEmbeddingLookup(str(tmp_path), pid2offset) as lk:
+        looked = lk.gather_device(pids[groups.reshape(-1)], "cuda")
+    with torch.no_grad():
+        enc = teacher(doc_ids[groups.reshape(-1)].cuda(), doc_mask[groups.reshape(-1)].cuda(), is_query=False)
+    margin("lookup/doc_emb_1-cos", 1 - cosine(looked.cpu().numpy(), enc.cpu().numpy()).min(), 1e-5)
+    args = SimpleNamespace(learning_rate=1e-3, adam_epsilon=1e-8, max_grad_norm=1.0, ranking_task=True, no_mse=False,
+                           num_negatives=K, gradient_accumulation_steps=1)
+    batch = tuple(t.cuda() for t in _batch(rs, B, 32, [32, 10, 21, 5]) + _batch(rs, B, 16, [16, 7, 9, 3]))
+    out = []
+    for kw in (dict(doc_embs=looked), dict(doc_ids=doc_ids[groups.reshape(-1)].cuda(), doc_mask=doc_mask[groups.reshape(-1)].cuda())):
+        student = _tiny(seed=1).cuda()
+        opt = TR.get_optimizer(args, student)
+        sched = TR.get_linear_schedule_with_warmup(opt, 0, 10)
+        loss, l1, l2 = TR.train_step(args, student, teacher, opt, sched, batch, **kw)
+        out.append((l2.item(), student.embeddingHead.weight.detach().clone()))
+    margin("lookup/loss2_abs", abs(out[0][0] - out[1][0]), 1e-4)
+    assert torch.allclose(out[0][1], out[1][1], rtol=0, atol=2e-3 * out[1][1].abs().max().item())

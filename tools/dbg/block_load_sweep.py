@@ -1,0 +1,30 @@
+"""Block file -> HBM rate by staging-chunk size and host threads (FlatIPIndex.add of a blocks.BlockView)."""
+import sys, os, time, tempfile, shutil
+sys.path.insert(0, '.')
+import numpy as np, torch
+from convdr_amd import blocks
+from convdr_amd.search import FlatIPIndex
+n, d = 1_000_000, 768
+td = tempfile.mkdtemp()
+try:
+    path = os.path.join(td, "b.pb")
+    blocks.dump_block(path, torch.randn(n, d).numpy())
+    for chunk in (64, 128, 256):
+        for th in (8, 16, 32, 64):
+            rates = []
+            for rep in range(3):
+                with blocks.BlockView(path) as bv:
+                    idx = FlatIPIndex(d)
+                    idx.host_chunk_bytes, idx.host_copy_threads = chunk << 20, th
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    idx.add(bv); torch.cuda.synchronize()
+                    rates.append(bv.array.nbytes / (time.perf_counter() - t0) / 1e9)
+                    del idx
+            print("chunk %3d MB threads %2d: %.1f GB/s (best of 3: %.1f)" % (chunk, th, rates[-1], max(rates)), flush=True)
+    # pure H2D ceiling from pinned memory
+    pin = torch.empty((n // 4, d)).pin_memory(); dev = torch.empty((n // 4, d), device="cuda")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(4): dev.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize(); print("pinned H2D: %.1f GB/s" % (4 * pin.numel() * 4 / (time.perf_counter() - t0) / 1e9))
+finally:
+    shutil.rmtree(td, ignore_errors=True)
