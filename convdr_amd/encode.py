@@ -61,7 +61,9 @@ def encode_shard(model, cache, rank=0, world=1, batch_size=1024, is_query_infere
     L = cache.seq_len if max_seq_length is None else min(cache.seq_len, int(max_seq_length))
     lens_all = np.minimum(cache.lengths(idx), L).astype(np.int32) if len(idx) else np.zeros(0, np.int32)
     out = None
-    stage = [torch.empty((batch_size, L), dtype=torch.int32).pin_memory() for _ in range(2)]
+    on_gpu = dev.type == "cuda"       # (the encoder itself is GPU-only; a host "device" only occurs with a stand-in tower in
+    pin = (lambda t: t.pin_memory()) if on_gpu else (lambda t: t)     #  the multi-process CPU tests of the shard / file logic)
+    stage = [pin(torch.empty((batch_size, L), dtype=torch.int32)) for _ in range(2)]
     events = [None, None]
     for bi, (s, e) in enumerate(plan_batches(lens_all, batch_size, token_budget, align=8)):
         sel = idx[s:e]
@@ -71,18 +73,20 @@ def encode_shard(model, cache, rank=0, world=1, batch_size=1024, is_query_infere
         if events[bi & 1] is not None:
             events[bi & 1].synchronize()                  # its previous H2D copy has been consumed
         np.take(cache.ids[:, :lmax], sel, axis=0, out=buf.numpy()[:n, :lmax])
-        ids = buf[:n, :lmax].to(dev, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        events[bi & 1] = ev
+        ids = buf[:n, :lmax].to(dev, non_blocking=True) if on_gpu else buf[:n, :lmax].clone()
+        if on_gpu:
+            ev = torch.cuda.Event()
+            ev.record()
+            events[bi & 1] = ev
         with torch.no_grad():
             emb = tower_call(ids, lens)
         if out is None:
-            out = torch.empty((len(idx), emb.shape[1]), dtype=torch.float32).pin_memory()
+            out = pin(torch.empty((len(idx), emb.shape[1]), dtype=torch.float32))
         out[s:s + n].copy_(emb, non_blocking=True)
         if progress:
             progress(n)
-    torch.cuda.synchronize(dev)
+    if on_gpu:
+        torch.cuda.synchronize(dev)
     if out is None:
         return np.zeros((0, 768), np.float32), idx
     return out.numpy(), idx

@@ -94,14 +94,19 @@ def _ddp_job(rank, world):
     model.bias.grad = flat[32:].view(4)
     flat.fill_(float(rank + 1))
     ddp.allreduce_grads()
-    return w_after_bcast.sum().item(), model.weight.grad.mean().item(), model.bias.grad.mean().item()
+    avg = (model.weight.grad.mean().item(), model.bias.grad.mean().item())
+    # train_step's form: SUM over ranks, the 1 / W factor handed back for the clip / AdamW pass to apply
+    flat.fill_(float(rank + 1))
+    scale = ddp.allreduce_grads(average=False)
+    return w_after_bcast.sum().item(), avg[0], avg[1], scale, model.weight.grad.mean().item()
 
 
 def test_gradient_allreduce_averages_flat_arena():
     r = _run(_ddp_job, 2, 29612)
     assert r[0][0] == r[1][0]                                   # parameters broadcast from rank 0
-    for w, gw, gb in r:
+    for w, gw, gb, scale, gsum in r:
         assert gw == pytest.approx(1.5) and gb == pytest.approx(1.5)
+        assert scale == 0.5 and gsum == pytest.approx(3.0)
 
 
 def _gather_job(rank, world):
@@ -140,3 +145,87 @@ def _inbatch_job(rank, world):
 def test_inbatch_negative_gather_is_global_batch_loss():
     for mean_of_ranks, whole in _run(_inbatch_job, port=29641):
         assert abs(mean_of_ranks - whole) < 1e-5
+
+
+class _StandInTower:
+    """Deterministic stand-in for the GPU encoder in the multi-process CPU test: embedding = a fixed random projection of
+    the token-id histogram.  Only the shard / batching / file-writing / barrier logic around the encoder is under test."""
+
+    def __init__(self):
+        self.W = torch.from_numpy(np.random.RandomState(5).randn(500, 768).astype(np.float32))
+
+    def embed(self, ids, mask, head=None, seq_lens=None):
+        out = torch.zeros((ids.shape[0], 768))
+        for b in range(ids.shape[0]):
+            out[b] = self.W[ids[b, :int(seq_lens[b])].long()].sum(0)
+        return out
+
+
+class _StandInModel:
+    def __init__(self):
+        self.roberta, self.embeddingHead, self.norm = _StandInTower(), None, None
+
+    def parameters(self):
+        return iter([self.roberta.W])
+
+
+def _write_cache(path, n, L, seed):
+    import json
+    rs = np.random.RandomState(seed)
+    lens = rs.randint(1, L + 1, size=n)
+    ids = rs.randint(3, 500, size=(n, L)).astype(np.int32)
+    with open(path, "wb") as f:
+        for i in range(n):
+            ids[i, lens[i]:] = 0
+            f.write(int(lens[i]).to_bytes(4, "big") + ids[i].tobytes())
+    with open(path + "_meta", "w") as f:
+        json.dump({"type": "int32", "total_number": n, "embedding_size": L}, f)
+
+
+def _stream_doc_job(rank, world):
+    """gen_passage_embeddings.py:131-169 over two ranks: every rank encodes records i % W == rank and writes its own block
+    pair between the barriers; afterwards search_one_by_one over the two blocks equals the search over the one block a
+    single rank writes for the same token cache."""
+    from types import SimpleNamespace
+    from convdr_amd import blocks
+    from convdr_amd.encode import StreamInferenceDoc
+    from convdr_amd.search import search_one_by_one
+    from oracle import search as OS
+    root = os.environ["CONVDR_TEST_DIR"]
+    model = _StandInModel()
+    with blocks.TokenCache(os.path.join(root, "passages")) as cache:
+        emb, embid = StreamInferenceDoc(SimpleNamespace(output_dir=os.path.join(root, "w2"), per_gpu_eval_batch_size=7,
+                                                        max_seq_length=24), model, cache)
+        ok = bool(np.array_equal(embid, np.arange(rank, len(cache), world)))
+        if rank == 0:
+            one = SimpleNamespace(output_dir=os.path.join(root, "w1"), per_gpu_eval_batch_size=64, max_seq_length=24)
+            os.makedirs(one.output_dir, exist_ok=True)
+            full_emb, full_id = __import__("convdr_amd.encode", fromlist=["encode_shard"]).encode_shard(model, cache, 0, 1, 64, False, 24)
+            blocks.dump_block(os.path.join(one.output_dir, "passage__emb_p__data_obj_0.pb"), full_emb)
+            blocks.dump_block(os.path.join(one.output_dir, "passage__embid_p__data_obj_0.pb"), full_id)
+    dist.barrier()
+    if rank != 0:
+        return ok
+
+    class HostIndex:           # .add / .search / .reset (the reference's FAISS surface) played by the oracle
+        def add(self, x):
+            self.P = np.asarray(x)
+
+        def search(self, q, k):
+            return OS.flat_ip_search(q, self.P, k)
+
+        def reset(self):
+            self.P = None
+    Q = np.random.RandomState(9).randn(6, 768).astype(np.float32)
+    D2, I2 = search_one_by_one(os.path.join(root, "w2"), HostIndex(), Q, 15)
+    D1, I1 = search_one_by_one(os.path.join(root, "w1"), HostIndex(), Q, 15)
+    return ok and bool(np.array_equal(I2[:, :15], I1[:, :15]) and np.array_equal(D2[:, :15], D1[:, :15]))
+
+
+def test_two_ranks_write_two_blocks_equal_to_one_rank(tmp_path):
+    _write_cache(str(tmp_path / "passages"), 101, 24, 3)
+    os.environ["CONVDR_TEST_DIR"] = str(tmp_path)
+    try:
+        assert all(_run(_stream_doc_job, 2, 29631))
+    finally:
+        os.environ.pop("CONVDR_TEST_DIR", None)
