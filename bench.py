@@ -92,8 +92,10 @@ def cpu_baseline(nq, d, k, L, budget_s=7.0):
     return out
 
 
-def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=True):
+def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=True, dropout=0.1):
     """configs[2]: run_convdr_train.py KD-only loop (MSE teacher-student), batch 64, seq 256, synthetic turns.
+    dropout: hidden / attention-probability dropout of the student (the reference trains with model.train() and the
+    released configs' 0.1, run_convdr_train.py:107); the teacher is in eval mode.
     Returns the JSON-able result dict on rank 0 (None elsewhere); the caller owns the process group."""
     import numpy as np
     import torch
@@ -105,7 +107,7 @@ def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=
     Ls, Lt = 256, 64
     student = random_rdot_model(0).to(dev)
     teacher = random_rdot_model(0).to(dev).eval()
-    student.config.hidden_dropout_prob = student.config.attention_probs_dropout_prob = 0.0
+    student.config.hidden_dropout_prob = student.config.attention_probs_dropout_prob = float(dropout)
     TR.flatten_parameters(student)       # one fp32 arena: single-launch AdamW, single cast for the bf16 copies
     targs = SimpleNamespace(learning_rate=1e-5, adam_epsilon=1e-8, max_grad_norm=1.0, ranking_task=False, no_mse=False,
                             num_negatives=9, gradient_accumulation_steps=1)
@@ -175,7 +177,7 @@ def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=
         "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16 compute, fp32 master weights / optimizer", "data": "synthetic OR-QuAC-shaped turns (ragged)",
         "config": {"workload": "configs[2] train_kd", "batch_per_gpu": Bt, "student_seq": Ls, "teacher_seq": Lt,
-                   "parallelism": "dp%d" % world, "mean_real_student_tokens": real_tokens},
+                   "parallelism": "dp%d" % world, "mean_real_student_tokens": real_tokens, "student_dropout": float(dropout)},
         "final_loss": float(loss),
         "TFLOPs_dense_padded_count": sps / world * flop_dense / Bt / 1e12,
         "TFLOPs_real_token_count_linear_only": flop_real * steps / el / 1e12,
@@ -197,7 +199,7 @@ def main_train(args):
     dist_on = world > 1 or bool(os.environ.get("CONVDR_BENCH_FORCE_DIST"))   # (the latter: 1-rank rehearsal of the N > 1 path)
     if dist_on:
         dist.init_process_group("nccl", device_id=dev)
-    out = train_kd_measure(dev, rank, world, dist_on, args.steps, args.warmup, args.train_batch)
+    out = train_kd_measure(dev, rank, world, dist_on, args.steps, args.warmup, args.train_batch, dropout=args.train_dropout)
     if dist_on:
         dist.destroy_process_group()
     if out is not None:
@@ -310,6 +312,8 @@ def main():
                     help="encode_search = BASELINE configs[1] (the headline line); train_kd = configs[2]: KD-only "
                          "(MSE teacher-student) training steps, batch 64, student seq 256, teacher seq 64")
     ap.add_argument("--train-batch", type=int, default=64)
+    ap.add_argument("--train-dropout", type=float, default=0.1,
+                    help="student dropout of the train_kd workload (the reference's training configuration: 0.1)")
     args = ap.parse_args()
     if args.workload == "train_kd":
         return main_train(args)
@@ -454,10 +458,12 @@ def main():
             line.update(extras(dev, index, model, tower, head, building, min(slots, args.steps + args.warmup) * EB, nq, k, d, Q))
             del index, building, model
             torch.cuda.empty_cache()
-            kd = train_kd_measure(dev, 0, 1, False, 10, 3, 64)
-            line["train_kd"] = {kk: kd[kk] for kk in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "final_loss",
-                                                      "TFLOPs_dense_padded_count", "TFLOPs_real_token_count_linear_only",
-                                                      "frac_of_bf16_mfma_peak_real_tokens", "kernels")}
+            keys = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "final_loss", "TFLOPs_dense_padded_count",
+                    "TFLOPs_real_token_count_linear_only", "frac_of_bf16_mfma_peak_real_tokens", "kernels")
+            kd = train_kd_measure(dev, 0, 1, False, 10, 3, 64, dropout=0.1)       # the reference's training configuration
+            line["train_kd"] = {kk: kd[kk] for kk in keys}
+            kd0 = train_kd_measure(dev, 0, 1, False, 10, 3, 64, with_kernels=False, dropout=0.0)
+            line["train_kd_no_dropout"] = {kk: kd0[kk] for kk in ("value", "unit", "ms_per_step", "config", "final_loss")}
         except Exception as e:      # the extras must never cost the headline line
             line["extras_error"] = "%s: %s" % (type(e).__name__, e)
     if not args.no_cpu_baseline:

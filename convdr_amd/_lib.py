@@ -121,12 +121,17 @@ class EncoderGrads(C.Structure):
                [(n, C.c_void_p) for n in ("head_w", "head_b", "head_ln_g", "head_ln_b")]
 
 
+class Dropout(C.Structure):
+    _fields_ = [("p_hidden", C.c_float), ("p_attention", C.c_float), ("seed", C.c_uint32)]
+
+
 register("convdr_encoder_train_workspace_bytes", C.c_size_t, [C.POINTER(EncoderConfig), C.c_int64, C.c_int])
 register("convdr_encoder_train_forward", C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), _p, C.c_int, _p,
-                                                   C.c_int, C.c_int, _p, _p, C.c_int64, C.c_int, _p, C.c_size_t, _p, _p])
+                                                   C.c_int, C.c_int, _p, _p, C.c_int64, C.c_int, _p, C.c_size_t, _p,
+                                                   C.POINTER(Dropout), _p])
 register("convdr_encoder_backward", C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), C.POINTER(LayerWeightsT),
                                               _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, C.c_size_t, _p,
-                                              C.POINTER(EncoderGrads), _p])
+                                              C.POINTER(EncoderGrads), C.POINTER(Dropout), _p])
 register("convdr_backward_wait_layer", C.c_int, [C.c_int, _p])
 register("convdr_wgrad", C.c_int, [_p, C.c_int, C.c_int64, _p, C.c_int, C.c_int64, C.c_int64, _p, C.c_size_t, _p, _p])
 register("convdr_transpose_f32_bf16", C.c_int, [_p, C.c_int, C.c_int, _p, _p])

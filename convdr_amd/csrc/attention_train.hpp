@@ -116,6 +116,7 @@ struct AttnTrainArgs {
   const int32_t *cu, *lens;
   int H;
   bf16_t* ctx;         // [rows, H]
+  DropSite drop;       // attention-probability dropout (thresh 0 = off); heads = gridDim.y
   float* lse;          // [heads, ldt]: log2 of the softmax denominator, log2(sum_k exp(s_k * scale)) (base 2: the backward's exp2 argument)
   int64_t ldt;
   float scale;
@@ -213,6 +214,18 @@ static __global__ void __launch_bounds__(256, 3) k_attention_train_fwd(const Att
     l = l * alpha + ps;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+    if (a.drop.thresh) {   // dropout on the probabilities (the softmax denominator above is that of the undropped row)
+      const uint32_t db = drop_att_base(base + qc, gridDim.y, h);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
+          float m0, m1;
+          drop_pair(a.drop, db + (uint32_t)(key >> 1), m0, m1);
+          st[kt][r] *= m0; st[kt][r + 1] *= m1;
+        }
+    }
 #define CONVDR_PV_STEP(S4, NEXT_ROW0, WAITN)                                                                    \
     {                                                                                                            \
       constexpr int kt = (S4) >> 1, r0 = ((S4) & 1) * 8, cur = (S4) & 1;                                         \
@@ -261,6 +274,7 @@ struct AttnBwdArgs {
   int H;
   bf16_t* dQKV;        // [rows, 3H]
   float scale;
+  DropSite drop;       // attention-probability dropout of the forward (thresh 0 = off)
 };
 
 constexpr int ATTB_DQ_SMEM = 2 * 2 * ATT_TILE;            // two sets of (K tile | V tile)
@@ -333,6 +347,18 @@ static __global__ void __launch_bounds__(256, 3) k_attention_bwd_dq(const AttnBw
     TrFrag kt_f[2][2];   // K^T fragments, two register sets (first one returns under the elementwise pass)
     tr_frag<0>(tK, trl, 0, kt_f[0][0]);  tr_frag<0>(tK, trl, 1, kt_f[0][1]);
     const bool ragged = kv0 + 64 > len;   // workgroup-uniform
+    if (a.drop.thresh) {   // dP = dP_dropped * mask: one hash per pair of consecutive keys (registers r, r + 1)
+      const uint32_t db = drop_att_base(base + qc, gridDim.y, h);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
+          float m0, m1;
+          drop_pair(a.drop, db + (uint32_t)(key >> 1), m0, m1);
+          dp[kt][r] *= m0; dp[kt][r + 1] *= m1;
+        }
+    }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -468,13 +494,21 @@ static __global__ void __launch_bounds__(256, 2) k_attention_bwd_dkv(const AttnB
       for (int r = 0; r < 16; ++r) {
         const int qi = 32 * qt + 16 * (r >> 3) + 8 * hi + (r & 7);
         float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -sLse[qi]));
-        float ds = p * (dp[r] - sD[qi]) * a.scale;
+        float dpr = dp[r], pd = p;
+        if (a.drop.thresh) {   // this lane's key, the register's query: P_dropped = P * m feeds dV, dP = dP_dropped * m feeds dS
+          float m0, m1;
+          drop_pair(a.drop, drop_att_base(base + q0 + qi, gridDim.y, h) + (uint32_t)(kc >> 1), m0, m1);
+          const float m = (kc & 1) ? m1 : m0;
+          dpr *= m;
+          pd *= m;
+        }
+        float ds = p * (dpr - sD[qi]) * a.scale;
         if (ragged) {
           const bool ok = q0 + qi < len;
-          p = ok ? p : 0.f;
+          pd = ok ? pd : 0.f;
           ds = ok ? ds : 0.f;
         }
-        s[r] = p;
+        s[r] = pd;
         dp[r] = ds;
       }
 #pragma unroll

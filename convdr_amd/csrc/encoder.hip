@@ -180,7 +180,7 @@ extern "C" int convdr_encoder_forward(const convdr_encoder_config* cfg, const co
   {
     ProfScope prof("embed_ln", st);
     hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.tok_id, p.tok_pos, rows, H,
-                       w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, cfg->ln_eps, p.X);
+                       w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, cfg->ln_eps, p.X, DropSite{0u, 0u, 1.f});
     CONVDR_CHECK_LAUNCH("k_embed_ln");
   }
   for (int l = 0; l < cfg->layers; ++l) {

@@ -17,6 +17,7 @@
 //   ctx  [rows, H]  bf16   attention output
 //   Hm   [rows, I]  bf16   gelu(FFN1)
 #pragma once
+#include "dropout.hpp"
 #include "gemm_nt.hpp"
 
 namespace convdr {
@@ -127,7 +128,8 @@ static __global__ void __launch_bounds__(256) k_embed_ln(const int32_t* __restri
                                                   const int32_t* __restrict__ tok_pos, int64_t rows, int H,
                                                   const float* __restrict__ word, const float* __restrict__ pos,
                                                   const float* __restrict__ type0, const float* __restrict__ g,
-                                                  const float* __restrict__ b, float eps, bf16_t* __restrict__ X) {
+                                                  const float* __restrict__ b, float eps, bf16_t* __restrict__ X,
+                                                  const DropSite drop) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -150,6 +152,17 @@ static __global__ void __launch_bounds__(256) k_embed_ln(const int32_t* __restri
     }
   }
   ln_normalize(x, H, lane, eps, g, b);
+  if (drop.thresh) {   // embedding dropout (training)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e0 = 256 * j + 4 * lane;
+      if (e0 < H) {
+        float m0, m1, m2, m3;
+        drop_hidden4(drop, row, e0, H, m0, m1, m2, m3);
+        x.v[j].x *= m0; x.v[j].y *= m1; x.v[j].z *= m2; x.v[j].w *= m3;
+      }
+    }
+  }
   ln_store(x, H, lane, X + row * H, nullptr);
 }
 
@@ -218,6 +231,7 @@ struct GemmArgs {
   int dbg_same_tile;  // experiment: every workgroup reads tile (0, 0) (all-L2-hit upper bound); results are garbage
   int dbg_skip_epi;   // experiment: 1 no epilogue, 3 no global stores of bf16 tiles, 4 every tile stores to tile 0 (garbage results)
   unsigned long long* trace;   // experiment: [workgroup][64 tiles][16 phases] s_memtime stamps of wave 0 (or null)
+  DropSite drop;      // EPI_RESID_F32 (training): dropout on the dense output (bias included) before the residual add; thresh 0 = off
 };
 
 
@@ -593,6 +607,11 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                   }
                 }
                 if constexpr (EPI == EPI_RESID_F32) {
+                  if (a.drop.thresh) {   // workgroup-uniform: hidden dropout of the training forward (BertSelfOutput / BertOutput)
+                    float m0, m1, m2, m3;
+                    drop_hidden4(a.drop, t, f, a.N, m0, m1, m2, m3);
+                    y0 *= m0; y1 *= m1; y2 *= m2; y3 *= m3;
+                  }
                   if (a.Rf) {
                     const int fc = (full_n || f < a.N) ? f : a.N - 4;
                     const float4 r = *(const float4*)(a.Rf + tc * a.N + fc);

@@ -159,6 +159,16 @@ struct WgradFork {
   }
 };
 
+static int check_dropout(const convdr_dropout* d, const convdr_encoder_config* c, int64_t rows) {
+  if (!d) return 0;
+  CONVDR_REQUIRE(d->p_hidden >= 0.f && d->p_hidden < 1.f && d->p_attention >= 0.f && d->p_attention < 1.f,
+                 "dropout probabilities must be in [0, 1) (hidden %g, attention %g)", d->p_hidden, d->p_attention);
+  // 32-bit element counters (csrc/dropout.hpp): rows * H / 2 and (rows * heads) << 9 must not wrap
+  CONVDR_REQUIRE((double)rows * c->hidden / 2 < 4.0e9 && (double)rows * c->heads * 512 < 4.0e9,
+                 "dropout: %lld packed rows overflow the 32-bit mask counters", (long long)rows);
+  return 0;
+}
+
 static int check_train_config(const convdr_encoder_config* c) {
   CONVDR_REQUIRE(c->hidden % 128 == 0 && c->hidden <= 1024 && c->heads * 64 == c->hidden,
                  "train: hidden must be a multiple of 128 (<= 1024) with head_dim 64 (hidden=%d heads=%d)", c->hidden,
@@ -257,10 +267,11 @@ static int colsum_chunks(int64_t rows) { return rows >= 2048 ? COLSUM_CHUNKS : 8
 // LayerNorm backward of `rows` rows, incoming gradient dY (fp32) + dYadd (bf16, optional).  Partial sums of
 // (dense bias = column sums of dX, dgamma, dbeta) go to part[blocks][3][H]; returns the number of blocks.
 static int ln_bwd_kernel(const float* dY, const bf16_t* dYadd, const float* Yin, int64_t rows, int H, const float* g, float eps,
-                         float* dXf, bf16_t* dXb, float* part, int* blocks_out, hipStream_t st) {
+                         float* dXf, bf16_t* dXb, float* part, int* blocks_out, hipStream_t st,
+                         const DropSite drop = DropSite{0u, 0u, 1.f}) {
   const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
   ProfScope prof("layernorm_bwd", st);
-  hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, dYadd, Yin, rows, H, g, eps, dXf, dXb, part);
+  hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, dYadd, Yin, rows, H, g, eps, dXf, dXb, part, drop);
   CONVDR_CHECK_LAUNCH("k_layernorm_bwd");
   *blocks_out = blocks;
   return 0;
@@ -320,9 +331,12 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
                                             const void* input_ids, int ids_are_int32, const int64_t* attention_mask, int B,
                                             int L, const int32_t* cu_seqlens, const int32_t* seq_lens, int64_t rows,
                                             int max_len, void* workspace, size_t workspace_bytes, float* out,
-                                            convdr_stream_t stream) {
+                                            const convdr_dropout* dropout, convdr_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (int e = check_train_config(cfg)) return e;
+  if (int e = check_dropout(dropout, cfg, rows)) return e;
+  const float p_hid = dropout ? dropout->p_hidden : 0.f, p_att = dropout ? dropout->p_attention : 0.f;
+  const uint32_t dseed = dropout ? dropout->seed : 0u;
   CONVDR_REQUIRE(B > 0 && L > 0 && rows > 0 && rows % 8 == 0 && max_len > 0 && max_len <= L,
                  "convdr_encoder_train_forward: bad sizes B=%d L=%d rows=%lld max_len=%d", B, L, (long long)rows, max_len);
   TrainPlan P;
@@ -335,7 +349,8 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
                      cu_seqlens, cfg->kind, cfg->pad_idx, cfg->max_pos, p.tok_id, p.tok_pos);
   CONVDR_CHECK_LAUNCH("k_seq_pack");
   hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.tok_id, p.tok_pos, rows, H,
-                     w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, cfg->ln_eps, P.layers[0].Xin);
+                     w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, cfg->ln_eps, P.layers[0].Xin,
+                     drop_site(dseed, DROP_SITE_EMB, 0, p_hid));
   CONVDR_CHECK_LAUNCH("k_embed_ln");
   for (int l = 0; l < cfg->layers; ++l) {
     const convdr_layer_weights* lw = &w->layers[l];
@@ -344,13 +359,14 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
     g.rows = rows; g.W = (const bf16_t*)lw->wqkv; g.X = s.Xin; g.N = 3 * H; g.K = H; g.bias = lw->bqkv; g.Cb = s.QKV;
     if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_qkv")) return e;
     {
-      AttnTrainArgs a{s.QKV, rows, cu_seqlens, seq_lens, H, s.ctx, s.LSE, p.ldt, 0.125f};
+      AttnTrainArgs a{s.QKV, rows, cu_seqlens, seq_lens, H, s.ctx, drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att), s.LSE, p.ldt, 0.125f};
       ProfScope prof("attention", st);
       hipLaunchKernelGGL(k_attention_train_fwd, dim3((max_len + 127) / 128, cfg->heads, B), dim3(256), 4 * ATT_TILE, st, a);
       CONVDR_CHECK_LAUNCH("k_attention_train_fwd");
     }
     g = GemmArgs{};
     g.rows = rows; g.W = (const bf16_t*)lw->wo; g.X = s.ctx; g.N = H; g.K = H; g.bias = lw->bo; g.Cf = s.Y1; g.R = s.Xin;
+    g.drop = drop_site(dseed, DROP_SITE_ATTN_OUT, l, p_hid);
     if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_attn_out")) return e;
     hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, s.Y1, rows, H, lw->ln1_g, lw->ln1_b,
                        cfg->ln_eps, s.X1, (float*)nullptr);
@@ -360,6 +376,7 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
     if (int e = launch_gemm<EPI_GELU_SAVE>(g, st, "gemm_ffn1")) return e;
     g = GemmArgs{};
     g.rows = rows; g.W = (const bf16_t*)lw->w2; g.X = s.Hm; g.N = H; g.K = I; g.bias = lw->b2; g.Cf = s.Y2; g.R = s.X1;
+    g.drop = drop_site(dseed, DROP_SITE_FFN_OUT, l, p_hid);
     if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_ffn2")) return e;
     if (l + 1 < cfg->layers) {
       hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, s.Y2, rows, H, lw->ln2_g, lw->ln2_b,
@@ -389,9 +406,12 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
                                        const convdr_layer_weights_t* wt, const int32_t* cu_seqlens, const int32_t* seq_lens,
                                        const void* head_w_t, int B, int64_t rows, int max_len, void* workspace,
                                        size_t workspace_bytes, const float* d_out, const convdr_encoder_grads* gr,
-                                       convdr_stream_t stream) {
+                                       const convdr_dropout* dropout, convdr_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (int e = check_train_config(cfg)) return e;
+  if (int e = check_dropout(dropout, cfg, rows)) return e;
+  const float p_hid = dropout ? dropout->p_hidden : 0.f, p_att = dropout ? dropout->p_attention : 0.f;
+  const uint32_t dseed = dropout ? dropout->seed : 0u;
   TrainPlan P;
   train_plan(cfg, rows, B, (char*)workspace, P);
   const TrainBufs& p = P.b;
@@ -417,8 +437,8 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
   }
   // ---- last layer's LayerNorm2 on the CLS rows only, scattered into a zero [rows, H] gradient ----
   // (its dbias output is the last layer's FFN2 bias gradient: only the CLS rows of that layer carry gradient)
-  if (int e = ln_bwd(dcls, nullptr, p.cls_y, B, H, w->layers[NL - 1].ln2_g, cfg->ln_eps, p.dcls_y, (bf16_t*)nullptr, p, lg_last->b2,
-                     lg_last->ln2_g, lg_last->ln2_b, st))
+  if (int e = ln_bwd(dcls, nullptr, p.cls_y, B, H, w->layers[NL - 1].ln2_g, cfg->ln_eps, p.dcls_y, (bf16_t*)nullptr, p,
+                     p_hid > 0.f ? nullptr : lg_last->b2, lg_last->ln2_g, lg_last->ln2_b, st))
     return e;
   CONVDR_CHECK_HIP(hipMemsetAsync(p.G0, 0, (size_t)rows * H * 4, st));
   hipLaunchKernelGGL(k_scatter_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, p.dcls_y, p.G0);
@@ -445,9 +465,17 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     float* dY2;
     int blocks_ln2 = 0, blocks_ln1 = 0;
     if (!last) {
-      if (int e = ln_bwd_kernel(cur_f, cur_b, s.Y2, rows, H, lw->ln2_g, cfg->ln_eps, other, d.dYb, d.part_ln2, &blocks_ln2, st))
+      if (int e = ln_bwd_kernel(cur_f, cur_b, s.Y2, rows, H, lw->ln2_g, cfg->ln_eps, other, d.dYb, d.part_ln2, &blocks_ln2, st,
+                                drop_site(dseed, DROP_SITE_FFN_OUT, l, p_hid)))
         return e;
       dY2 = other; other = cur_f;
+    } else if (p_hid > 0.f) {
+      // (the CLS-row LayerNorm backward above indexed its rows 0..B-1, not by packed row: with dropout the mask is applied
+      //  here, and the FFN2 bias gradient -- column sums of the MASKED gradient -- comes from a column-sum pass)
+      hipLaunchKernelGGL(k_cast_drop_f32_bf16, dim3(1024), dim3(256), 0, st, cur_f, d.dYb, rows, H,
+                         drop_site(dseed, DROP_SITE_FFN_OUT, l, p_hid));
+      CONVDR_CHECK_LAUNCH("k_cast_drop_f32_bf16");
+      dY2 = cur_f;
     } else {
       hipLaunchKernelGGL(k_cast_f32_bf16, dim3(1024), dim3(256), 0, st, cur_f, d.dYb, (int64_t)rows * H / 4);
       CONVDR_CHECK_LAUNCH("k_cast_f32_bf16");
@@ -468,7 +496,8 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
     // ---- LayerNorm1: dY1 = LN'(dY2 + dXb1) ----
     float* dY1 = other;
-    if (int e = ln_bwd_kernel(dY2, p.dXb1, s.Y1, rows, H, lw->ln1_g, cfg->ln_eps, dY1, d.dYb2, d.part_ln1, &blocks_ln1, st))
+    if (int e = ln_bwd_kernel(dY2, p.dXb1, s.Y1, rows, H, lw->ln1_g, cfg->ln_eps, dY1, d.dYb2, d.part_ln1, &blocks_ln1, st,
+                              drop_site(dseed, DROP_SITE_ATTN_OUT, l, p_hid)))
       return e;
     other = dY2;
     // ---- attention output projection: Y1 = ctx Wo^T + bo + Xin ----
@@ -480,7 +509,8 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
                        p.ldt);
     CONVDR_CHECK_LAUNCH("k_attn_rowdot");
     {
-      AttnBwdArgs a{s.QKV, p.dctx, rows, s.LSE, cfg->heads, p.Drow, p.ldt, cu_seqlens, seq_lens, H, d.dQKV, 0.125f};
+      AttnBwdArgs a{s.QKV, p.dctx, rows, s.LSE, cfg->heads, p.Drow, p.ldt, cu_seqlens, seq_lens, H, d.dQKV, 0.125f,
+                    drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att)};
       ProfScope prof("attention_bwd", st);
       const dim3 grid((max_len + 127) / 128, cfg->heads, B);
       hipLaunchKernelGGL(k_attention_bwd_dq, grid, dim3(256), ATTB_DQ_SMEM, st, a);
@@ -495,6 +525,11 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       CONVDR_CHECK_LAUNCH("k_colsum_bf16");
       ReduceList r;
       if (!last) r.add_ln(d.part_ln2, blocks_ln2, H, lg->b2, lg->ln2_g, lg->ln2_b);
+      if (last && p_hid > 0.f) {   // see the k_cast_drop_f32_bf16 branch above (part_ln2 is free in the last layer)
+        hipLaunchKernelGGL(k_colsum_bf16, dim3((H + 255) / 256, chunks), dim3(256), 0, ss, d.dYb, rows, H, d.part_ln2);
+        CONVDR_CHECK_LAUNCH("k_colsum_bf16");
+        r.add(d.part_ln2, chunks, H, H, lg->b2);
+      }
       r.add_ln(d.part_ln1, blocks_ln1, H, lg->bo, lg->ln1_g, lg->ln1_b);
       r.add(d.part_b1, chunks, I, I, lg->b1);
       r.add(d.part_bqkv, chunks, 3 * H, 3 * H, lg->bqkv);
@@ -519,7 +554,8 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
   {
     const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
     hipLaunchKernelGGL(k_embed_bwd, dim3(blocks), dim3(256), 0, st, cur_f, cur_b, p.tok_id, p.tok_pos, rows, H, w->word_emb, w->pos_emb,
-                       w->type_emb, w->emb_ln_g, cfg->ln_eps, gr->word_emb, gr->pos_emb, p.part);
+                       w->type_emb, w->emb_ln_g, cfg->ln_eps, gr->word_emb, gr->pos_emb, p.part,
+                       drop_site(dseed, DROP_SITE_EMB, 0, p_hid));
     CONVDR_CHECK_LAUNCH("k_embed_bwd");
     float* outs[3] = {gr->emb_ln_g, gr->emb_ln_b, gr->type_emb};
     ReduceList r;

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
                                                        const float* __restrict__ Yin,
                                                        int64_t rows, int H, const float* __restrict__ g, float eps,
                                                        float* __restrict__ dXf, bf16_t* __restrict__ dXb,
-                                                       float* __restrict__ part) {
+                                                       float* __restrict__ part, const DropSite drop) {
   __shared__ float red[4][3][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 ag[4], ab[4], ax[4];
@@ -103,8 +103,13 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
         o.y = rstd * (d[j].y - m1 - y[j].y * m2);
         o.z = rstd * (d[j].z - m1 - y[j].z * m2);
         o.w = rstd * (d[j].w - m1 - y[j].w * m2);
+        if (dXf) *(float4*)(dXf + row * H + e0) = o;   // residual branch: not dropped
+        if (drop.thresh) {   // the dense output feeding this LayerNorm went through dropout: its gradient (and its bias') is masked
+          float k0, k1, k2, k3;
+          drop_hidden4(drop, row, e0, H, k0, k1, k2, k3);
+          o.x *= k0; o.y *= k1; o.z *= k2; o.w *= k3;
+        }
         ax[j].x += o.x; ax[j].y += o.y; ax[j].z += o.z; ax[j].w += o.w;
-        if (dXf) *(float4*)(dXf + row * H + e0) = o;
         if (dXb) {
           uint2 p;
           p.x = pack_bf16x2(o.x, o.y);
@@ -321,6 +326,24 @@ static __global__ void __launch_bounds__(256) k_reduce_multi(const ReduceJobs a)
   }
 }
 
+// y = bf16(x * dropout mask) for a [rows, H] matrix: the last layer's FFN-output gradient (only its CLS rows are non-zero)
+// on its way to the FFN2 dgrad / wgrad operands when hidden dropout is on
+static __global__ void __launch_bounds__(256) k_cast_drop_f32_bf16(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t rows,
+                                                                   int H, const DropSite drop) {
+  const int64_t n4 = rows * H / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = (4 * i) / H;
+    const int col = (int)(4 * i - row * H);
+    float4 v = *(const float4*)(x + 4 * i);
+    float m0, m1, m2, m3;
+    drop_hidden4(drop, row, col, H, m0, m1, m2, m3);
+    uint2 o;
+    o.x = pack_bf16x2(v.x * m0, v.y * m1);
+    o.y = pack_bf16x2(v.z * m2, v.w * m3);
+    *(uint2*)(y + 4 * i) = o;
+  }
+}
+
 // dst[cu[b], :] = src[b, :] for b < B (dst pre-zeroed): scatter CLS-row gradients into a [rows, H] matrix
 __global__ void __launch_bounds__(256) k_scatter_cls(const int32_t* __restrict__ cu, int B, int H,
                                                      const float* __restrict__ src, float* __restrict__ dst) {
@@ -342,7 +365,7 @@ __global__ void __launch_bounds__(256) k_embed_bwd(const float* __restrict__ dX,
                                                    const float* __restrict__ word, const float* __restrict__ pos,
                                                    const float* __restrict__ type0, const float* __restrict__ g,
                                                    float eps, float* __restrict__ d_word, float* __restrict__ d_pos,
-                                                   float* __restrict__ part) {
+                                                   float* __restrict__ part, const DropSite drop) {
   __shared__ float red[4][3][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 ag[4], ab[4], at[4];
@@ -362,6 +385,11 @@ __global__ void __launch_bounds__(256) k_embed_bwd(const float* __restrict__ dX,
                      t = *(const float4*)(type0 + e0);
         y[j] = make_float4(a.x + c.x + t.x, a.y + c.y + t.y, a.z + c.z + t.z, a.w + c.w + t.w);
         d[j] = grad_in(dX, dXb, row * H + e0);
+        if (drop.thresh) {   // embedding dropout sits between this LayerNorm and the first layer
+          float k0, k1, k2, k3;
+          drop_hidden4(drop, row, e0, H, k0, k1, k2, k3);
+          d[j].x *= k0; d[j].y *= k1; d[j].z *= k2; d[j].w *= k3;
+        }
         s += y[j].x + y[j].y + y[j].z + y[j].w;
       }
     }

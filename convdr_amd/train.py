@@ -10,8 +10,11 @@ activations inside a device workspace and whose backward runs the hand-written b
 parameter gradients (views of one flat fp32 buffer), so ``loss.backward()``, ``.grad``, ``zero_grad`` and any
 ``torch.optim`` optimizer keep working -- as do the fused ``clip_grad_norm_`` / ``AdamW`` below.
 
-Deviation (documented, SURVEY.md §7 hard part 4): dropout is the identity.  The reference trains the student with
-hidden / attention dropout 0.1 whose RNG streams cannot be reproduced; parity is therefore defined at p = 0.
+Dropout (run_convdr_train.py:107 ``model.train()``: hidden / attention-probability dropout inside the HF encoder, 0.1 in
+the released configs): torch's RNG stream cannot be reproduced by any other implementation, so the masks are a documented
+counter-based function of (seed, site, layer, element) -- csrc/dropout.hpp, restated bit for bit in oracle/dropout.py.  A
+forward draws ``seed`` from ``model.dropout_seed`` (default: torch.initial_seed()) plus a per-call counter, the backward
+regenerates the masks from it; parity tests replay the same seed through the oracle.
 """
 import ctypes as C
 import math
@@ -193,7 +196,7 @@ def _lens_and_check(ids, mask, vocab, seq_lens=None):
 
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tower, head, input_ids, attention_mask, seq_lens, *params):
+    def forward(ctx, tower, head, input_ids, attention_mask, seq_lens, dropout, *params):
         L_ = _lib.lib()
         ids = input_ids.long().contiguous()
         mask = attention_mask.long().contiguous()
@@ -215,9 +218,10 @@ class _EncoderFn(torch.autograd.Function):
             need = L_.convdr_encoder_train_workspace_bytes(C.byref(c), rows, B)
             ent, token = _take_workspace(tower, need, dev)
             ws = ent.ws
+            drop = None if dropout is None else C.byref(_lib.Dropout(float(dropout[0]), float(dropout[1]), int(dropout[2]) & 0xffffffff))
             _lib.check(L_.convdr_encoder_train_forward(C.byref(c), C.byref(w), _lib.ptr(ids), 0, _lib.ptr(mask), B, L,
                                                        _lib.ptr(cu), _lib.ptr(seq_lens_dev), rows, max_len, _lib.ptr(ws),
-                                                       ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
+                                                       ws.numel(), _lib.ptr(out), drop, _lib.stream_ptr()),
                        "convdr_encoder_train_forward")
             # the transposed weight copies are needed by the backward only: pack them on the side stream, under this
             # forward (0.6 ms of small transposes per step that would otherwise sit in front of the backward)
@@ -227,7 +231,7 @@ class _EncoderFn(torch.autograd.Function):
             with torch.cuda.stream(side):
                 ctx.packed_t = _packed_t(tower, head)
                 ctx.packed_t_ready = side.record_event()
-        ctx.tower, ctx.head = tower, head
+        ctx.tower, ctx.head, ctx.dropout = tower, head, dropout
         ctx.packed = (c, w, _keep)           # the weights cannot change between a forward and its backward
         ctx.saved = (cu, seq_lens_dev, B, rows, max_len, ent, ent.gen, token)
         ctx.shapes = [p.shape for p in params]
@@ -271,12 +275,42 @@ class _EncoderFn(torch.autograd.Function):
             if head is not None:
                 b = 5 + 16 * nl
                 gr.head_w, gr.head_b, gr.head_ln_g, gr.head_ln_b = ptr[b], ptr[b + 1], ptr[b + 2], ptr[b + 3]
+            dropout = ctx.dropout
+            drop = None if dropout is None else C.byref(_lib.Dropout(float(dropout[0]), float(dropout[1]), int(dropout[2]) & 0xffffffff))
             _lib.check(L_.convdr_encoder_backward(C.byref(c), C.byref(w), wt, _lib.ptr(cu), _lib.ptr(seq_lens),
                                                   C.c_void_p(head_t) if head_t else None, B, rows, max_len, _lib.ptr(ws),
-                                                  ws.numel(), _lib.ptr(go), C.byref(gr), _lib.stream_ptr()),
+                                                  ws.numel(), _lib.ptr(go), C.byref(gr), drop, _lib.stream_ptr()),
                        "convdr_encoder_backward")
         token.done = True      # (stream order: a later forward on this stream overwrites the workspace after these kernels)
-        return (None, None, None, None, None) + tuple(views)
+        return (None, None, None, None, None, None) + tuple(views)
+
+
+def _mix32(a):
+    """csrc/dropout.hpp: drop_mix32 (per-call seed derivation only; the masks themselves are generated on the device)."""
+    a &= 0xffffffff
+    a = ((a + 0x7ed55d16) + (a << 12)) & 0xffffffff
+    a = ((a ^ 0xc761c23c) ^ (a >> 19)) & 0xffffffff
+    a = ((a + 0x165667b1) + (a << 5)) & 0xffffffff
+    a = ((a + 0xd3a2646c) ^ (a << 9)) & 0xffffffff
+    a = ((a + 0xfd7046c5) + (a << 3)) & 0xffffffff
+    a = ((a ^ 0xb55a4f09) ^ (a >> 16)) & 0xffffffff
+    return a
+
+
+def next_dropout_seed(model):
+    """Seed of the next differentiable forward of `model`: mix32(base + number of forwards so far), base =
+    ``model.dropout_seed`` (set it for reproducible / replayable masks) or torch.initial_seed().  Exposed so that a parity
+    test can read the seed a step will use (``peek=True`` semantics: call dropout_seed_of(model, n))."""
+    n = model.__dict__.get("_dropout_calls", 0)
+    model.__dict__["_dropout_calls"] = n + 1
+    return dropout_seed_of(model, n)
+
+
+def dropout_seed_of(model, call_index):
+    base = getattr(model, "dropout_seed", None)
+    if base is None:
+        base = torch.initial_seed()
+    return _mix32((int(base) + int(call_index)) & 0xffffffff)
 
 
 def encoder_autograd(model, tower, head, input_ids, attention_mask, seq_lens=None):
@@ -284,13 +318,12 @@ def encoder_autograd(model, tower, head, input_ids, attention_mask, seq_lens=Non
     seq_lens: optional HOST int array of the rows' token counts (right padding); with it the forward has no device ->
     host round trip, so the host can run a whole step ahead of the GPU."""
     cfg = tower.config
-    if head is None and tower is model:
-        pass  # BERT tower of the BiEncoder (no projection head)
-    if model.training and (cfg.hidden_dropout_prob or cfg.attention_probs_dropout_prob):
-        if not getattr(model, "_dropout_notice", False):
-            model._dropout_notice = True
-            print("convdr_amd: training without dropout (p treated as 0; see convdr_amd/train.py)")
-    return _EncoderFn.apply(tower, head, input_ids, attention_mask, seq_lens, *_tower_params(tower, head))
+    dropout = None
+    p_h, p_a = float(cfg.hidden_dropout_prob or 0.0), float(cfg.attention_probs_dropout_prob or 0.0)
+    if model.training and (p_h > 0.0 or p_a > 0.0):
+        dropout = (p_h, p_a, next_dropout_seed(model))
+        model.__dict__["_last_dropout"] = dropout          # (instrumentation: what the most recent forward used)
+    return _EncoderFn.apply(tower, head, input_ids, attention_mask, seq_lens, dropout, *_tower_params(tower, head))
 
 
 # --------------------------------------------------------------------------------------------

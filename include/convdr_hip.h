@@ -169,8 +169,16 @@ int convdr_encoder_forward(const convdr_encoder_config* cfg, const convdr_encode
  *   loss.backward()                       :178         -> convdr_encoder_backward
  *   clip_grad_norm_(.., max_grad_norm)    :188-189     -> convdr_grad_norm_clip
  *   optimizer.step()  (HF AdamW, utils/dpr_utils.py:80-87) -> convdr_adamw_step
- * Dropout is the identity (p = 0): train-mode RNG streams cannot match torch's (SURVEY.md §7 hard part 4).
+ * Dropout (run_convdr_train.py:107 model.train(): hidden / attention-probability dropout inside the HF encoder): torch's
+ * RNG stream cannot be matched, so the mask is a documented counter-based function of (seed, site, layer, element)
+ * (csrc/dropout.hpp, restated in oracle/dropout.py); the backward regenerates it.  NULL / p = 0: identity.
  * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  float p_hidden;      /* config.hidden_dropout_prob: embeddings output, attention-output dense, FFN-output dense */
+  float p_attention;   /* config.attention_probs_dropout_prob: softmax probabilities */
+  uint32_t seed;       /* the SAME value for a forward and its backward */
+} convdr_dropout;
+
 typedef struct {   /* bf16 transposed weights for the data-gradient GEMMs (device pointers) */
   const void* wqkv_t;  /* [H, 3H] */
   const void* wo_t;    /* [H, H]  */
@@ -196,7 +204,8 @@ size_t convdr_encoder_train_workspace_bytes(const convdr_encoder_config* cfg, in
 int convdr_encoder_train_forward(const convdr_encoder_config* cfg, const convdr_encoder_weights* w,
                                  const void* input_ids, int ids_are_int32, const int64_t* attention_mask, int B, int L,
                                  const int32_t* cu_seqlens, const int32_t* seq_lens, int64_t rows, int max_len,
-                                 void* workspace, size_t workspace_bytes, float* out, convdr_stream_t stream);
+                                 void* workspace, size_t workspace_bytes, float* out, const convdr_dropout* dropout,
+                                 convdr_stream_t stream);
 
 /* d_out: fp32 [B, out_dim or hidden] gradient of the loss w.r.t. the embeddings.  wt: HOST array of `layers`
  * entries; head_w_t: bf16 [hidden, out_dim] (NULL when out_dim == 0). */
@@ -204,7 +213,7 @@ int convdr_encoder_backward(const convdr_encoder_config* cfg, const convdr_encod
                             const convdr_layer_weights_t* wt, const int32_t* cu_seqlens, const int32_t* seq_lens,
                             const void* head_w_t, int B, int64_t rows, int max_len, void* workspace,
                             size_t workspace_bytes, const float* d_out, const convdr_encoder_grads* grads,
-                            convdr_stream_t stream);
+                            const convdr_dropout* dropout, convdr_stream_t stream);
 
 /* One weight gradient of the backward above, exposed for parity tests at arbitrary shapes:
  *   dW[n, k] += sum_t dy[t, n] * x[t, k]     (what autograd's Linear backward computes for

@@ -49,9 +49,12 @@ def gelu_erf(x):
 
 
 def encoder_hidden(sd, prefix, input_ids, attention_mask, *, kind, num_layers,
-                   num_heads, eps, return_all=False):
+                   num_heads, eps, return_all=False, dropout=None):
     """Last-layer hidden states [B, L, H] of the BERT/RoBERTa tower stored under
-    ``prefix`` (e.g. 'roberta.' or 'question_model.') in state dict ``sd``."""
+    ``prefix`` (e.g. 'roberta.' or 'question_model.') in state dict ``sd``.
+    dropout = (p_hidden, p_attention, seed): train-mode forward with the counter-based masks of the HIP kernels
+    (oracle/dropout.py) at the four sites HF applies dropout (embeddings output, attention probabilities,
+    attention-output dense, FFN-output dense); None: eval mode."""
     ids = input_ids.long()
     B, L = ids.shape
     g = lambda n: sd[prefix + n].float()
@@ -66,6 +69,12 @@ def encoder_hidden(sd, prefix, input_ids, attention_mask, *, kind, num_layers,
          + g("embeddings.token_type_embeddings.weight")[0])
     x = _ln(x, g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"), eps)
     H = x.shape[-1]
+    if dropout is not None:
+        from . import dropout as OD
+        p_h, p_a, seed = dropout
+        lens = attention_mask.sum(1).numpy()
+        hid = lambda site, layer: torch.from_numpy(OD.hidden_mask(seed, site, layer, p_h, lens, L, H))
+        x = x * hid(OD.SITE_EMB, 0)
     d = H // num_heads
     add_mask = (1.0 - attention_mask.float())[:, None, None, :] * -10000.0
     hs = [x]
@@ -76,12 +85,21 @@ def encoder_hidden(sd, prefix, input_ids, attention_mask, *, kind, num_layers,
         k = lin(x, "attention.self.key").view(B, L, num_heads, d).transpose(1, 2)
         v = lin(x, "attention.self.value").view(B, L, num_heads, d).transpose(1, 2)
         s = q @ k.transpose(-1, -2) / math.sqrt(d) + add_mask
-        ctx = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, L, H)
-        x = _ln(lin(ctx, "attention.output.dense") + x,
+        probs = torch.softmax(s, dim=-1)
+        if dropout is not None:
+            probs = probs * torch.from_numpy(OD.attention_mask(seed, i, p_a, lens, L, num_heads))
+        ctx = (probs @ v).transpose(1, 2).reshape(B, L, H)
+        ao = lin(ctx, "attention.output.dense")
+        if dropout is not None:
+            ao = ao * hid(OD.SITE_ATTN_OUT, i)
+        x = _ln(ao + x,
                 g(p + "attention.output.LayerNorm.weight"),
                 g(p + "attention.output.LayerNorm.bias"), eps)
         h = gelu_erf(lin(x, "intermediate.dense"))
-        x = _ln(lin(h, "output.dense") + x, g(p + "output.LayerNorm.weight"),
+        fo = lin(h, "output.dense")
+        if dropout is not None:
+            fo = fo * hid(OD.SITE_FFN_OUT, i)
+        x = _ln(fo + x, g(p + "output.LayerNorm.weight"),
                 g(p + "output.LayerNorm.bias"), eps)
         hs.append(x)
     return hs if return_all else x
@@ -94,10 +112,10 @@ def masked_mean(t, mask):
 
 
 def rdot_nll_emb(sd, input_ids, attention_mask, *, num_layers, num_heads,
-                 eps=1e-5, use_mean=False):
+                 eps=1e-5, use_mean=False, dropout=None):
     """RobertaDot_NLL_LN.query_emb == body_emb (models.py:140-148)."""
     h = encoder_hidden(sd, "roberta.", input_ids, attention_mask, kind="roberta",
-                       num_layers=num_layers, num_heads=num_heads, eps=eps)
+                       num_layers=num_layers, num_heads=num_heads, eps=eps, dropout=dropout)
     full = masked_mean(h, attention_mask) if use_mean else h[:, 0]
     y = F.linear(full, sd["embeddingHead.weight"].float(), sd["embeddingHead.bias"].float())
     return _ln(y, sd["norm.weight"].float(), sd["norm.bias"].float(), 1e-5)  # nn.LayerNorm(768) default eps

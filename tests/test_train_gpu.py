@@ -290,6 +290,7 @@ def test_dpr_tower_backward_matches_autograd():
     cfg = BertConfig(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                      max_position_embeddings=64, type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     model = MSMarcoConfigDict["dpr"].model_class(type("A", (), {"bert_config": cfg})())
+    cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.0      # init_encoder(dropout=0.1) set them (models.py:198-203)
     with torch.no_grad():
         for n, p in model.named_parameters():
             if n.endswith("bias"):
@@ -732,3 +733,81 @@ def test_ranking_step_with_looked_up_document_embeddings(tmp_path):
         out.append((l2.item(), student.embeddingHead.weight.detach().clone()))
     margin("lookup/loss2_abs", abs(out[0][0] - out[1][0]), 1e-4)
     assert torch.allclose(out[0][1], out[1][1], rtol=0, atol=2e-3 * out[1][1].abs().max().item())
+
+
+def _tiny_dropout(p_h, p_a, seed=0, layers=2):
+    m = _tiny(layers=layers, seed=seed)
+    m.config.hidden_dropout_prob, m.config.attention_probs_dropout_prob = p_h, p_a
+    return m
+
+
+@pytest.mark.parametrize("p_h,p_a", [(0.1, 0.1), (0.0, 0.3), (0.25, 0.0)])
+def test_dropout_forward_backward_match_oracle_with_replayed_mask(p_h, p_a):
+    """run_convdr_train.py:107 trains with dropout ON.  The kernels' masks are a counter-based function of
+    (seed, site, layer, element) (csrc/dropout.hpp); oracle/dropout.py restates it, so the train-mode forward and the
+    gradients must match autograd on the oracle run with the SAME masks: embeddings-output, attention-probability,
+    attention-output and FFN-output dropout, ragged lengths over one / two / three key tiles."""
+    from convdr_amd import train as TR
+    rs = np.random.RandomState(41)
+    B, L, lens = 4, 130, [130, 64, 65, 7]
+    model = _tiny_dropout(p_h, p_a)
+    model.dropout_seed = 1234
+    ids, mask = _batch(rs, B, L, lens)
+    G = torch.from_numpy(rs.randn(B, 768).astype(np.float32))
+    seed = TR.dropout_seed_of(model, 0)
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    ref_emb = OE.rdot_nll_emb(sd, ids, mask, num_layers=2, num_heads=2, dropout=(p_h, p_a, seed))
+    (ref_emb * G).sum().backward()
+    ref = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    with torch.no_grad():
+        eval_emb = OE.rdot_nll_emb(sd, ids, mask, num_layers=2, num_heads=2)
+    assert (eval_emb - ref_emb.detach()).abs().max().item() > 1e-3                # the masks do change the embeddings
+    model = model.cuda().train()
+    emb = model(ids.cuda(), mask.cuda())
+    assert model._last_dropout == (p_h, p_a, seed)
+    tag = "dropout_%g_%g" % (p_h, p_a)
+    margin(tag + "/emb_1-cos", 1 - cosine(emb.detach().cpu().numpy(), ref_emb.detach().numpy()).min(), 5e-5)    # measured 9.3e-6
+    (emb * G.cuda()).sum().backward()
+    for n, p in model.named_parameters():
+        if n in ref and not n.endswith("attention.self.key.bias"):
+            _compare(n, p.grad, ref[n], cos_tol=1 - 3e-4, norm_tol=0.01, tag=tag)
+    _record_worst(tag, 3e-4, 0.01)            # measured 7.9e-5 / 3.0e-3
+    # a second forward draws a new mask; eval mode draws none
+    emb2 = model(ids.cuda(), mask.cuda())
+    assert not torch.equal(emb2, emb)
+    with torch.no_grad():
+        e1 = model.eval()(ids.cuda(), mask.cuda())
+    margin(tag + "/eval_emb_1-cos", 1 - cosine(e1.cpu().numpy(), eval_emb.numpy()).min(), 5e-5)
+
+
+def test_dropout_statistics():
+    """Keep rate, inverted scaling and independence of the device masks, read back through a model whose activations make
+    the mask observable: with all-ones LayerNorm-free probes this would need kernel hooks, so the check goes through the
+    oracle restatement (bit-identical to the kernels by the parity test above) for the statistics, and through the device
+    for determinism: same seed -> same embeddings and gradients, different seed -> different."""
+    from oracle import dropout as OD
+    for p in (0.1, 0.5):
+        m = OD.hidden_mask(77, OD.SITE_FFN_OUT, 5, p, [256] * 8, 256, 768)
+        keep = (m > 0).mean()
+        assert abs(keep - (1 - p)) < 3e-3, keep
+        assert abs(m.mean() - 1.0) < 5e-3                          # inverted dropout: E[mask] = 1
+        assert np.unique(m).size == 2
+        a = OD.attention_mask(77, 3, p, [200, 56], 200, 12)
+        assert abs((a[0] > 0).mean() - (1 - p)) < 3e-3
+    k1 = OD.hidden_mask(1, OD.SITE_ATTN_OUT, 0, 0.5, [64], 64, 768) > 0
+    for other in (OD.hidden_mask(2, OD.SITE_ATTN_OUT, 0, 0.5, [64], 64, 768) > 0,        # another seed
+                  OD.hidden_mask(1, OD.SITE_FFN_OUT, 0, 0.5, [64], 64, 768) > 0,         # another site
+                  OD.hidden_mask(1, OD.SITE_ATTN_OUT, 1, 0.5, [64], 64, 768) > 0):       # another layer
+        assert abs(np.corrcoef(k1.ravel(), other.ravel())[0, 1]) < 0.02
+    rs = np.random.RandomState(43)
+    ids, mask = _batch(rs, 3, 40, [40, 11, 25])
+    ids, mask = ids.cuda(), mask.cuda()
+    outs = []
+    for seed in (5, 5, 6):
+        model = _tiny_dropout(0.1, 0.1).cuda().train()
+        model.dropout_seed = seed
+        e = model(ids, mask)
+        e.sum().backward()
+        outs.append((e.detach().clone(), model.embeddingHead.weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert not torch.equal(outs[0][0], outs[2][0])
