@@ -84,7 +84,7 @@ def prof_collect(name):
 class EncoderConfig(C.Structure):
     _fields_ = [("kind", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32), ("layers", C.c_int32),
                 ("intermediate", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("pad_idx", C.c_int32),
-                ("out_dim", C.c_int32), ("ln_eps", C.c_float), ("head_ln_eps", C.c_float)]
+                ("out_dim", C.c_int32), ("ln_eps", C.c_float), ("head_ln_eps", C.c_float), ("pool_mean", C.c_int32)]
 
 
 class LayerWeights(C.Structure):

@@ -186,8 +186,14 @@ extern "C" int convdr_encoder_forward(const convdr_encoder_config* cfg, const co
   for (int l = 0; l < cfg->layers; ++l) {
     const convdr_layer_weights* lw = &w->layers[l];
     const bool last = l + 1 == cfg->layers;
-    if (int e = encoder_layer_forward(cfg, lw, p, cu_seqlens, seq_lens, rows, B, max_len, nullptr, last, st)) return e;
-    if (last) {
+    if (int e = encoder_layer_forward(cfg, lw, p, cu_seqlens, seq_lens, rows, B, max_len, nullptr, last && !cfg->pool_mean, st))
+      return e;
+    if (last && cfg->pool_mean) {
+      // use_mean = True (models.py:32-35, :40-41): the whole last layer is live; p.X holds its LayerNorm'ed output
+      hipLaunchKernelGGL(k_masked_mean, dim3(B), dim3(256), 0, st, p.X, cu_seqlens, seq_lens, H, p.cls_b,
+                         cfg->out_dim > 0 ? p.cls_f : out);
+      CONVDR_CHECK_LAUNCH("k_masked_mean");
+    } else if (last) {
       // the last layer ran its tail on the CLS rows only: p.Y[0..B) are their pre-LN sums
       float* cls_out = cfg->out_dim > 0 ? p.cls_f : out;
       hipLaunchKernelGGL(k_layernorm, dim3((B + 3) / 4), dim3(256), 0, st, p.Y, (int64_t)B, H, lw->ln2_g, lw->ln2_b,

@@ -197,6 +197,32 @@ static __global__ void __launch_bounds__(256) k_gather_cls(const int32_t* __rest
   }
 }
 
+// EmbeddingMixin.masked_mean (models.py:32-35): out[b, :] = sum over the sequence's tokens of X[row, :] / len[b].
+// One workgroup per sequence; thread t owns columns 4 t .. 4 t + 3 (H <= 1024); rows are read whole (coalesced).
+static __global__ void __launch_bounds__(256) k_masked_mean(const bf16_t* __restrict__ X, const int32_t* __restrict__ cu,
+                                                     const int32_t* __restrict__ lens, int H, bf16_t* __restrict__ Ob,
+                                                     float* __restrict__ Of) {
+  const int b = blockIdx.x, c = 4 * threadIdx.x;
+  if (c >= H) return;
+  const int64_t base = cu[b];
+  const int len = lens[b];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < len; ++t) {
+    const uint2 v = *(const uint2*)(X + (base + t) * H + c);
+    s.x += __uint_as_float(v.x << 16); s.y += __uint_as_float(v.x & 0xffff0000u);
+    s.z += __uint_as_float(v.y << 16); s.w += __uint_as_float(v.y & 0xffff0000u);
+  }
+  const float inv = 1.f / (float)len;
+  s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+  if (Of) *(float4*)(Of + (int64_t)b * H + c) = s;
+  if (Ob) {
+    uint2 o;
+    o.x = pack_bf16x2(s.x, s.y);
+    o.y = pack_bf16x2(s.z, s.w);
+    *(uint2*)(Ob + (int64_t)b * H + c) = o;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // GEMM with fused epilogues.  The engine computes a 128 x 128 tile  acc[r][l] = sum_k Rm[r0+r][k] Lm[l0+l][k]
 // where the "R" operand's index lands on accumulator REGISTERS (4 consecutive r per register quad) and the

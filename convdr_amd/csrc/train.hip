@@ -382,6 +382,12 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
       hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, s.Y2, rows, H, lw->ln2_g, lw->ln2_b,
                          cfg->ln_eps, P.layers[l + 1].Xin, (float*)nullptr);
       CONVDR_CHECK_LAUNCH("k_layernorm");
+    } else if (cfg->pool_mean) {   // use_mean = True: masked mean of the whole last layer's output
+      hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, s.Y2, rows, H, lw->ln2_g, lw->ln2_b,
+                         cfg->ln_eps, p.Xout, (float*)nullptr);
+      hipLaunchKernelGGL(k_masked_mean, dim3(B), dim3(256), 0, st, p.Xout, cu_seqlens, seq_lens, H, p.cls_b,
+                         cfg->out_dim > 0 ? p.cls_f : out);
+      CONVDR_CHECK_LAUNCH("k_masked_mean");
     } else {
       hipLaunchKernelGGL(k_gather_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, (const bf16_t*)nullptr, s.Y2,
                          (bf16_t*)nullptr, p.cls_y);
@@ -436,13 +442,20 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     dcls = p.dcls_f;
   }
   // ---- last layer's LayerNorm2 on the CLS rows only, scattered into a zero [rows, H] gradient ----
-  // (its dbias output is the last layer's FFN2 bias gradient: only the CLS rows of that layer carry gradient)
-  if (int e = ln_bwd(dcls, nullptr, p.cls_y, B, H, w->layers[NL - 1].ln2_g, cfg->ln_eps, p.dcls_y, (bf16_t*)nullptr, p,
-                     p_hid > 0.f ? nullptr : lg_last->b2, lg_last->ln2_g, lg_last->ln2_b, st))
-    return e;
-  CONVDR_CHECK_HIP(hipMemsetAsync(p.G0, 0, (size_t)rows * H * 4, st));
-  hipLaunchKernelGGL(k_scatter_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, p.dcls_y, p.G0);
-  CONVDR_CHECK_LAUNCH("k_scatter_cls");
+  const bool pool_mean = cfg->pool_mean != 0;
+  if (pool_mean) {
+    // use_mean = True: d(last layer output)[row] = d pooled[b] / len[b]; the last layer is then an ordinary layer
+    hipLaunchKernelGGL(k_masked_mean_bwd, dim3(B), dim3(256), 0, st, dcls, cu_seqlens, seq_lens, H, p.G0);
+    CONVDR_CHECK_LAUNCH("k_masked_mean_bwd");
+  } else {
+    // (its dbias output is the last layer's FFN2 bias gradient: only the CLS rows of that layer carry gradient)
+    if (int e = ln_bwd(dcls, nullptr, p.cls_y, B, H, w->layers[NL - 1].ln2_g, cfg->ln_eps, p.dcls_y, (bf16_t*)nullptr, p,
+                       p_hid > 0.f ? nullptr : lg_last->b2, lg_last->ln2_g, lg_last->ln2_b, st))
+      return e;
+    CONVDR_CHECK_HIP(hipMemsetAsync(p.G0, 0, (size_t)rows * H * 4, st));
+    hipLaunchKernelGGL(k_scatter_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, p.dcls_y, p.G0);
+    CONVDR_CHECK_LAUNCH("k_scatter_cls");
+  }
 
   WgradFork& wf = WgradFork::get();
   static const bool fork_wgrad = !(getenv("CONVDR_NO_WGRAD_FORK") && atoi(getenv("CONVDR_NO_WGRAD_FORK")));
@@ -460,7 +473,7 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     const convdr_layer_grads* lg = &gr->layers[l];
     const LayerSave& s = P.layers[l];
     const LayerBwd& d = P.bwd[l];
-    const bool last = l == NL - 1;
+    const bool last = l == NL - 1 && !pool_mean;   // "last" = the CLS-only shortcut of the last layer
     // d(pre-LN2 sum Y2): for the last layer cur_f already is that (CLS rows only), else LayerNorm2 backward
     float* dY2;
     int blocks_ln2 = 0, blocks_ln1 = 0;

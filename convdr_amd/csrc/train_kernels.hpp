@@ -326,6 +326,20 @@ static __global__ void __launch_bounds__(256) k_reduce_multi(const ReduceJobs a)
   }
 }
 
+// backward of k_masked_mean: dX[row, :] = dpool[b, :] / len[b] for the sequence's tokens, 0 for its alignment rows
+static __global__ void __launch_bounds__(256) k_masked_mean_bwd(const float* __restrict__ dpool, const int32_t* __restrict__ cu,
+                                                                const int32_t* __restrict__ lens, int H, float* __restrict__ dX) {
+  const int b = blockIdx.x, c = 4 * threadIdx.x;
+  if (c >= H) return;
+  const int64_t base = cu[b], end = cu[b + 1];
+  const int len = lens[b];
+  const float inv = 1.f / (float)len;
+  float4 g = *(const float4*)(dpool + (int64_t)b * H + c);
+  g.x *= inv; g.y *= inv; g.z *= inv; g.w *= inv;
+  for (int64_t r = base; r < end; ++r)
+    *(float4*)(dX + r * H + c) = r < base + len ? g : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // y = bf16(x * dropout mask) for a [rows, H] matrix: the last layer's FFN-output gradient (only its CLS rows are non-zero)
 // on its way to the FFN2 dgrad / wgrad operands when hidden dropout is on
 static __global__ void __launch_bounds__(256) k_cast_drop_f32_bf16(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t rows,

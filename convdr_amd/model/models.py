@@ -248,7 +248,8 @@ class EncoderTower(nn.Module):
                                heads=cfg.num_attention_heads, layers=cfg.num_hidden_layers,
                                intermediate=cfg.intermediate_size, vocab=e.word_embeddings.num_embeddings,
                                max_pos=cfg.max_position_embeddings, pad_idx=cfg.pad_token_id if self.kind == "roberta" else 0,
-                               out_dim=out_dim, ln_eps=cfg.layer_norm_eps, head_ln_eps=head_eps)
+                               out_dim=out_dim, ln_eps=cfg.layer_norm_eps, head_ln_eps=head_eps,
+                               pool_mean=int(bool(getattr(self, "pool_mean", False))))
         keep.append(layers)
         self._packed, self._packed_key = (c, w, keep), key
         return self._packed
@@ -294,7 +295,8 @@ class EncoderTower(nn.Module):
                                heads=cfg.num_attention_heads, layers=cfg.num_hidden_layers,
                                intermediate=cfg.intermediate_size, vocab=e.word_embeddings.num_embeddings,
                                max_pos=cfg.max_position_embeddings, pad_idx=cfg.pad_token_id if self.kind == "roberta" else 0,
-                               out_dim=out_dim, ln_eps=cfg.layer_norm_eps, head_ln_eps=head_eps)
+                               out_dim=out_dim, ln_eps=cfg.layer_norm_eps, head_ln_eps=head_eps,
+                               pool_mean=int(bool(getattr(self, "pool_mean", False))))
         return (c, w, [layers, P, Pb])
 
     def _ensure_kslice(self, c, w, keep, rows, dev):
@@ -480,9 +482,12 @@ class RobertaDot_NLL_LN(NLL, _PretrainedMixin, nn.Module):
         self.apply(self._init_weights)
 
     def query_emb(self, input_ids, attention_mask, seq_lens=None):
-        """seq_lens (extension): optional host int array of token counts; saves the forward's device -> host round trip."""
-        if self.use_mean:
-            raise NotImplementedError("use_mean=True is not registered by any reference config (models.py:295-307)")
+        """seq_lens (extension): optional host int array of token counts; saves the forward's device -> host round trip.
+        use_mean (models.py:40-41): masked mean over the tokens instead of the CLS row -- the pooling runs inside the
+        library (k_masked_mean), so ``self.roberta`` carries the flag."""
+        if bool(self.use_mean) != bool(getattr(self.roberta, "pool_mean", False)):
+            self.roberta.pool_mean = bool(self.use_mean)
+            self.roberta.invalidate_packed()
         if _wants_autograd(self):
             from ..train import encoder_autograd
             return encoder_autograd(self, self.roberta, (self.embeddingHead, self.norm), input_ids, attention_mask, seq_lens)

@@ -111,6 +111,8 @@ typedef struct {
   int32_t out_dim;     /* 768 for rdot_nll (embeddingHead + norm, models.py:136-137); 0 = raw CLS (dpr, models.py:210) */
   float ln_eps;        /* encoder LayerNorms (1e-5 RoBERTa, 1e-12 BERT) */
   float head_ln_eps;   /* nn.LayerNorm(768) default 1e-5 */
+  int32_t pool_mean;   /* 0 = CLS pooling emb_all[0][:, 0] (every registered config, models.py:43); 1 = masked mean over the
+                        * sequence's tokens (EmbeddingMixin.masked_mean, models.py:32-35, use_mean = True) */
 } convdr_encoder_config;
 
 typedef struct {       /* device pointers; w* are bf16 [out, in] row-major (nn.Linear layout), the rest fp32 */

@@ -533,8 +533,30 @@ def gen_evaluate():
     print("evaluate fixture written", emb.shape, emb.dtype)
 
 
+def gen_use_mean():
+    """EmbeddingMixin with use_mean = True (models.py:19-23, :32-41): masked mean over the tokens instead of the CLS row.
+    No registered config sets it (models.py:295-307) and no driver passes model_argobj, so this is surface only -- pinned
+    here with the tiny rdot_nll weights of encoder_rdot_nll.npz."""
+    from types import SimpleNamespace
+    import torch
+    M, U, DU, T = import_reference()
+    z = np.load(os.path.join(HERE, "encoder_rdot_nll.npz"))
+    model = M.RobertaDot_NLL_LN(tiny_roberta_config(), model_argobj=SimpleNamespace(use_mean=True))
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")})
+    model.eval()
+    assert model.use_mean is True
+    rng = np.random.RandomState(88)
+    ids, mask = synth_ids(rng, 5, 70, [70, 9, 1, 64, 33], pad1_at=(3, 7))
+    with torch.no_grad():
+        emb = model(torch.from_numpy(ids), torch.from_numpy(mask))
+        body = model(torch.from_numpy(ids), torch.from_numpy(mask), is_query=False)
+    assert torch.equal(emb, body)
+    np.savez_compressed(os.path.join(HERE, "use_mean.npz"), ids=ids, mask=mask, emb=emb.numpy())
+    print("use_mean fixture written", emb.shape)
+
+
 GROUPS = {"encoder": gen_encoder, "search": gen_search, "encode_loop": gen_encode_loop, "train": gen_train,
-          "evaluate": gen_evaluate}
+          "evaluate": gen_evaluate, "use_mean": gen_use_mean}
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(GROUPS)

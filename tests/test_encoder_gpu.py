@@ -336,3 +336,40 @@ def test_evaluate_loop_matches_reference_fixture(golden_dir):
     _check(torch.from_numpy(emb), z["embedding"], "evaluate")
     assert emb2id == [str(q) for q in z["embedding2id"]]
     assert raw == json.loads(str(z["raw_sequences"]))
+
+
+def test_use_mean_pooling_matches_reference_fixture(golden_dir):
+    """EmbeddingMixin.masked_mean (models.py:32-41, use_mean = True): forward vs the reference-run fixture, and the training
+    path (k_masked_mean / k_masked_mean_bwd, the last layer computed for every token) vs autograd on the oracle."""
+    from types import SimpleNamespace
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    import json
+    z = np.load(os.path.join(golden_dir, "use_mean.npz"))
+    zw = np.load(os.path.join(golden_dir, "encoder_rdot_nll.npz"))
+    cfg = json.loads(str(zw["config"]))
+    model = MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **cfg),
+                                                      model_argobj=SimpleNamespace(use_mean=True))
+    model.load_state_dict(_sd(zw), strict=False)
+    model = model.cuda().eval()
+    ids, mask = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    with torch.no_grad():
+        emb = model(ids.cuda(), mask.cuda())
+    _check(emb, z["emb"], "use_mean")
+    # training path
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in _sd(zw).items()}
+    G = torch.from_numpy(np.random.RandomState(1).randn(5, 768).astype(np.float32))
+    ref = OE.rdot_nll_emb(sd, ids, mask, num_layers=2, num_heads=2, use_mean=True)
+    (ref * G).sum().backward()
+    model.train()
+    out = model(ids.cuda(), mask.cuda())
+    _check(out.detach(), ref.detach().numpy(), "use_mean(train)")
+    (out * G.cuda()).sum().backward()
+    worst = 1.0
+    for n, p in model.named_parameters():
+        r = sd[n].grad if n in sd else None
+        if r is None or p.grad is None or n.endswith("attention.self.key.bias") or r.norm() < 1e-9:
+            continue
+        g = p.grad.detach().cpu().double().reshape(-1)
+        r = r.double().reshape(-1)
+        worst = min(worst, float((g @ r) / (g.norm() * r.norm())))
+    assert worst > 1 - 1e-3, worst

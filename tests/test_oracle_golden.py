@@ -159,3 +159,11 @@ def test_product_eval_dev_query_writes_the_reference_text(golden_dir, tmp_path):
                  offset2pid, str(tmp_path), "raw", raw_sequences=raw)
     assert open(tmp_path / "o.trec").read() == str(z["d/trec"])
     assert open(tmp_path / "o.jsonl").read() == str(z["d/jsonl"])
+
+
+def test_use_mean_pooling_matches_reference(golden_dir):
+    """models.py:32-41 with use_mean = True, run by the reference (make_golden.py:gen_use_mean) vs the oracle."""
+    z = np.load(os.path.join(golden_dir, "use_mean.npz"))
+    sd = _sd(np.load(os.path.join(golden_dir, "encoder_rdot_nll.npz")))
+    emb = OE.rdot_nll_emb(sd, torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"]), num_layers=2, num_heads=2, use_mean=True)
+    np.testing.assert_allclose(emb.numpy(), z["emb"], atol=2e-5, rtol=0)
