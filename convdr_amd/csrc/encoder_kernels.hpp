@@ -233,7 +233,7 @@ static __global__ void __launch_bounds__(256) k_masked_mean(const bf16_t* __rest
 // ---------------------------------------------------------------------------------------------
 enum { EPI_BF16 = 0, EPI_GELU_BF16 = 1, EPI_RESID_F32 = 2, EPI_QKV = 3, EPI_F32 = 4,
        EPI_GELU_SAVE = 5,   // training FFN1: Cb = gelu(y) and Cb2 = y (pre-activation, for the backward)
-       EPI_DGELU_BF16 = 6,  // backward of FFN1's activation: Cb = bf16(acc) * gelu'(R[t, f])
+       /* 6 was the gelu'-multiplying dgrad epilogue of round 1; that pass is k_dgelu_colsum now */
        EPI_SLAB_F32 = 7 };  // wgrad partial: Cf[split][rows][N] = acc (no bias)
 
 struct GemmArgs {
@@ -247,7 +247,7 @@ struct GemmArgs {
   bf16_t* Cb;         // EPI_BF16 / EPI_GELU_BF16: [rows, N]
   bf16_t* Cb2;        // EPI_GELU_SAVE: pre-activation [rows, N]
   float* Cf;          // EPI_RESID_F32 / EPI_F32:  [rows, N]
-  const bf16_t* R;    // EPI_RESID_F32: residual [rows, N] bf16 (EPI_DGELU_BF16: the pre-activation)
+  const bf16_t* R;    // EPI_RESID_F32: residual [rows, N] bf16
   const float* Rf;    // EPI_RESID_F32: fp32 residual instead of R when non-null (gradient residual stream)
   bf16_t *Qo, *Ko, *Vt;  // EPI_QKV (N = 3H): Q [rows, H], K [rows, H], Vt [H, ldt]
   int third0;            // EPI_QKV: 1 = W / bias start at the K third and N = 2H (last layer: Q is needed for the CLS rows only)
@@ -329,13 +329,8 @@ struct CTile {
   // Thread t owns 16-byte chunk t % CH of rows t / CH + 16 i: all LDS reads are issued before the first store, the
   // per-iteration row offsets are compile-time, and a tile that lies fully inside the matrix takes no bound checks
   // (the store tail was issue-bound: 325 cycles per store with the generic index arithmetic, measured by s_memtime).
-  // DGELU: the parked values are multiplied by gelu'(aux) on their way out, aux = the bf16 element at the same [row, col]
-  // of a second matrix `aux_delta` BYTES away from dst (EPI_DGELU_BF16: the saved FFN1 pre-activation).  Here a thread
-  // owns 8 consecutive columns of a row, so the aux tile is read in whole 512-byte rows; in the accumulator layout of the
-  // epilogue proper the same reads were 8-byte pieces of 32 different rows per instruction.
-  template <bool DGELU = false>
   __device__ static __forceinline__ void store(Base sC, int pass, bf16_t* dst, int64_t ld, int64_t row_limit,
-                                               int64_t col_limit, int tid, int64_t aux_delta = 0) {
+                                               int64_t col_limit, int tid) {
     constexpr int RPI = T::THREADS / CH;   // rows covered per iteration
     constexpr int BATCH = 4;               // LDS reads in flight before their stores (16 VGPRs; the kernel is at the cap)
     static_assert(RPI * CH == T::THREADS && (32 * NTP) % RPI == 0 && ROWS % RPI == 0 && STORES_PER_WAVE % BATCH == 0 &&
@@ -354,28 +349,6 @@ struct CTile {
         return (row >= HALF ? sC.hi : sC.lo) + addr((row >= HALF ? row - HALF : row) + r0, c);
       };
       lds_read4_b128_hidden(at(i0 + 0), at(i0 + 1), at(i0 + 2), at(i0 + 3), v[0], v[1], v[2], v[3]);
-      if constexpr (DGELU) {
-        u32x4_t r[BATCH];
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-          constexpr int blk = 32 * NTP;
-          const int i = i0 + j;
-          const int rowc = ((i * RPI) / blk * T::NT + pass * NTP) * 32 + (i * RPI) % blk;
-          const bool ok = inside || (rowc + r0 < row_limit && nv >= 8);
-          r[j] = ok ? *(const u32x4_t*)((const char*)(p + (int64_t)rowc * ld) + aux_delta) : (u32x4_t){0u, 0u, 0u, 0u};
-        }
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-          const uint32_t* pv = (const uint32_t*)&v[j];
-          const uint32_t* pa = (const uint32_t*)&r[j];
-          uint32_t o[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            o[q] = pack_bf16x2(__uint_as_float(pv[q] << 16) * gelu_grad(__uint_as_float(pa[q] << 16)),
-                               __uint_as_float(pv[q] & 0xffff0000u) * gelu_grad(__uint_as_float(pa[q] & 0xffff0000u)));
-          v[j] = (u32x4_t){o[0], o[1], o[2], o[3]};
-        }
-      }
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         constexpr int blk = 32 * NTP;
@@ -592,8 +565,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
       lds_barrier();     // every wave is done with the last K step's stage (and the next tile's sbias is visible)
       CONVDR_TRACE(2)
       const bool full_n = n0 + T::TR <= a.N;  // workgroup-uniform: no per-quad feature bound checks on the fast path
-      constexpr bool BF16_OUT = EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV || EPI == EPI_GELU_SAVE ||
-                                EPI == EPI_DGELU_BF16;
+      constexpr bool BF16_OUT = EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV || EPI == EPI_GELU_SAVE;
       constexpr int NOUT = EPI == EPI_GELU_SAVE ? 2 : 1;   // second output: the pre-activation
 #pragma unroll
       for (int out = 0; out < NOUT; ++out)
@@ -677,11 +649,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                 bf16_t* dst = na < a.H ? a.Qo + t0 * a.H + na : a.Ko + t0 * a.H + (na - a.H);
                 CT::store(sC, pass, dst, a.H, a.rows - t0, T::TR, tid_e);
               } else {
-                if constexpr (EPI == EPI_DGELU_BF16)   // x gelu'(pre-activation), applied in the store layout
-                  CT::template store<true>(sC, pass, a.Cb + t0 * a.N + n0, a.N, a.rows - t0, a.N - n0, tid_e,
-                                           (int64_t)((const char*)a.R - (const char*)a.Cb));
-                else
-                  CT::store(sC, pass, a.dbg_skip_epi == 4 ? a.Cb : (out ? a.Cb2 : a.Cb) + t0 * a.N + n0, a.N, a.rows - t0, a.N - n0, tid_e);
+                CT::store(sC, pass, a.dbg_skip_epi == 4 ? a.Cb : (out ? a.Cb2 : a.Cb) + t0 * a.N + n0, a.N, a.rows - t0, a.N - n0, tid_e);
               }
             }
             CONVDR_TRACE(6 + 4 * pass)

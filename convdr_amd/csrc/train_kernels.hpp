@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) k_transpose_f32_bf16(const float* __restr
 //   xhat = (y - mean) * rstd;  gdy = g * dy;  dx = rstd * (gdy - mean(gdy) - xhat * mean(gdy * xhat))
 // Per-workgroup partial sums go to part[block][3][H] = (sum dx, dgamma = sum dy * xhat, dbeta = sum dy); sum dx is the
 // bias gradient of the dense layer whose output (+ residual) this LayerNorm normalises -- the arena keeps
-// [dense.bias, LayerNorm.weight, LayerNorm.bias] adjacent, so one k_reduce_partials_small launch finishes all three
+// [dense.bias, LayerNorm.weight, LayerNorm.bias] adjacent, so one k_reduce_multi job finishes all three
 // (fixed order: deterministic).
 // ---------------------------------------------------------------------------------------------
 // The incoming gradient is dYa (fp32, optional) + dYb (bf16, optional): the residual stream stays fp32 while the
@@ -165,34 +165,6 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict
   }
 }
 
-// same contract for few outputs / many partials (LayerNorm and bias gradients): 16 outputs per block, the partials
-// are split over 16 thread rows (each with four loads in flight) and folded in LDS in a fixed order (deterministic)
-static __global__ void __launch_bounds__(256) k_reduce_partials_small(const float* __restrict__ part, int nparts,
-                                                                      int64_t stride, int64_t n, float* __restrict__ out,
-                                                                      int accumulate) {
-  __shared__ float red[16][17];
-  const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
-  const int64_t i = (int64_t)blockIdx.x * 16 + c;
-  float s = 0.f;
-  if (i < n) {
-    int p = r;
-    for (; p + 48 < nparts; p += 64) {
-      const float a = part[(int64_t)p * stride + i], b = part[(int64_t)(p + 16) * stride + i];
-      const float c2 = part[(int64_t)(p + 32) * stride + i], d = part[(int64_t)(p + 48) * stride + i];
-      s += a; s += b; s += c2; s += d;
-    }
-    for (; p < nparts; p += 16) s += part[(int64_t)p * stride + i];
-  }
-  red[r][c] = s;
-  __syncthreads();
-  if (r == 0 && i < n) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][c];
-    out[i] = accumulate ? out[i] + t : t;
-  }
-}
-
 // column sums of a bf16 matrix [rows, C] (C % 8 == 0): part[chunk][C]; grid (ceil(C / 256), chunks).
 // 256 threads = 32 column groups of 8 (one 16-byte load each) x 8 row lanes, two rows in flight per lane; each block sums
 // its row chunk, then folds the 8 row lanes in LDS in a fixed order.
@@ -282,7 +254,8 @@ static __global__ void __launch_bounds__(256) k_dgelu_colsum(bf16_t* __restrict_
   }
 }
 
-// Several k_reduce_partials_small jobs in one launch (all of a layer's LayerNorm / bias partial sums are finished by ONE
+// Several small partial-sum reductions in one launch: 16 outputs per block, the partials split over 16 thread rows (four
+// loads in flight each) and folded in LDS in a fixed order -- deterministic (all of a layer's LayerNorm / bias partial sums are finished by ONE
 // kernel on the weight-gradient stream instead of one launch each on the activation-gradient chain).
 constexpr int REDUCE_MAX_JOBS = 8;
 struct ReduceJob {

@@ -87,3 +87,19 @@ def test_abstract_and_error_conventions():
     t = torch.arange(24.).view(2, 3, 4)
     mask = torch.tensor([[1, 1, 0], [1, 0, 0]])
     np.testing.assert_allclose(x.masked_mean(t, mask).numpy(), [[2, 3, 4, 5], [12, 13, 14, 15]])
+
+
+def test_linear_schedule_matches_oracle():
+    """run_convdr_train.py:71-74 (transformers.get_linear_schedule_with_warmup): the product's LambdaLR factor against the
+    oracle's restatement, incl. the warm-up ramp, the decay and the clamp at zero past the last step."""
+    import torch
+    from convdr_amd import train as TR
+    from oracle import train as OT
+    p = torch.nn.Parameter(torch.zeros(1))
+    for warm, total in ((0, 10), (3, 10), (5, 5), (1, 3)):
+        opt = torch.optim.SGD([p], lr=1.0)
+        sched = TR.get_linear_schedule_with_warmup(opt, warm, total)
+        for step in range(total + 3):
+            assert abs(opt.param_groups[0]["lr"] - OT.linear_schedule(step, warm, total)) < 1e-12, (warm, total, step)
+            opt.step()
+            sched.step()
