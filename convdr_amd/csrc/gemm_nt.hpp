@@ -323,6 +323,9 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
   char* sL = smem + 3 * T::R_BYTES;
   if (!prologue_in_flight) gemm_r3_prologue<T>(src, K, smem, w, st, !r1_deferred);
   int rs = st.rs, ls = st.ls;
+#if defined(CONVDR_R3_STATIC_PRIO)   // experiment (cdna guide T5, static form): the younger half of the workgroup at priority 1
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= T::THREADS / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     // (r1_deferred: at step 0 only chunks 0 are in flight -- there is no newer R group to leave outstanding;
     //  stage0_landed: the caller has already waited for them, ahead of its epilogue's stores)
@@ -359,6 +362,9 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
     for (int s = 0; s < 4; ++s) {
       if (s + 1 < 4) load_frags(s + 1, (s + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
+#if defined(CONVDR_R3_SETPRIO)   // experiment (cdna guide T5): priority 1 around each MFMA cluster
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int i = 0; i < T::MT; ++i) {
 #pragma unroll
@@ -375,6 +381,9 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
                                                    i * src.R.round_pitch + (kt + 2) * (GEMM_BK * 2), 0, 0);
 #endif
       }
+#if defined(CONVDR_R3_SETPRIO)
+      __builtin_amdgcn_s_setprio(0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
 #if CONVDR_R3_VARIANT == 0
@@ -383,6 +392,9 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
     rs = rs == 2 ? 0 : rs + 1;
     ls ^= 1;
   }
+#if defined(CONVDR_R3_STATIC_PRIO)
+  __builtin_amdgcn_s_setprio(0);
+#endif
   return R3Slots{rs, ls};
 }
 

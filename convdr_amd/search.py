@@ -166,7 +166,7 @@ class FlatIPIndex:
                     reader(dst, s, e, pool=pool, parts=threads)          # positioned file reads, `threads` slices in flight
                 else:                                                    # an array in host memory: parallel memcpy
                     step = (e - s + threads - 1) // threads
-                    futs = [pool.submit(np.copyto, dst[a:a + step], arr[s + a:s + a + step]) for a in range(0, e - s, step)]
+                    futs = [pool.submit(np.copyto, dst[a:a + step], arr[s + a:min(e, s + a + step)]) for a in range(0, e - s, step)]
                     for f in futs:
                         f.result()
                 with torch.cuda.stream(cs):

@@ -320,15 +320,19 @@ def test_streamed_host_block_equals_resident_block(torch_cuda, tmp_path):
 @pytest.mark.parametrize("n", [33000, 47104, 70000, 150000])
 def test_mid_size_blocks_get_a_threshold(torch_cuda, n):
     """Blocks between the exact-threshold range (<= 32 k passages) and the 1/32-sample range: the sampled threshold must
-    exist (round 2 found n = 47,104 emitting every passage for every query and certifying only through the overflow retry)
-    and the result stays bit-exact."""
+    exist (round 2 found n = 47,104 asking for rank 1,113 of a 1,024-value sample: no threshold, every passage emitted for
+    every query, certification only through the overflow retry).  The two-best-of-64 sample can only aim at rank n / 128
+    here, so the first pass may come back UNCERTAIN with a retry threshold -- one more round, never an overflow -- and the
+    result stays bit-exact."""
     P, Q = synth_corpus(61, n, 768), synth_corpus(62, 40, 768)
     idx = _index()
     idx.add(P)
     D, I, st, _ = idx.search_device(torch_cuda.from_numpy(Q).cuda(), 100)
     emitted, band = idx.last_counts(40, 100)
-    assert int(emitted.max()) < 4096, int(emitted.max())
-    assert int((st != 0).sum()) == 0
+    assert 100 <= int(emitted.min()) and int(emitted.max()) < 4096, (int(emitted.min()), int(emitted.max()))
+    assert int((st == 1).sum()) == 0                       # no overflow
+    D, I = idx.search(Q, 100)
+    assert idx.stats["rounds"] <= 2, idx.stats
     Dr, Ir = OS.flat_ip_search(Q, P, 100)
-    np.testing.assert_array_equal(I.cpu().numpy(), Ir)
-    np.testing.assert_array_equal(D.cpu().numpy(), Dr)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D, Dr)
