@@ -171,6 +171,13 @@ __device__ __forceinline__ void gemm_stage(const StageSrc& s, int kt, char* lds_
                                              i * s.round_pitch + kt * (GEMM_BK * 2), 0, 0);
 }
 
+// one DMA instruction of a chunk (round i of gemm_stage), for the loops that thread the issue between their MFMAs
+template <int WAVES>
+__device__ __forceinline__ void gemm_stage_round(const StageSrc& s, int i, int kt, char* lds_tile, int wave) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds_tile + (i * WAVES + wave) * 8 * 128), 16, s.voff,
+                                           i * s.round_pitch + kt * (GEMM_BK * 2), 0, 0);
+}
+
 // LDS image: two stages of STAGE_BYTES = R_BYTES + L_BYTES, each [R tile | L tile] (a whole stage is one contiguous
 // region, so the idle stage can serve as epilogue scratch while the other already receives the next tile).
 template <class T>
@@ -280,10 +287,20 @@ __device__ __forceinline__ int gemm_nt_mainloop(const TileSrc<T>& src, int K, ch
 // a SIMD is the critical path of the step: 1.15 k cycles of issue, then its MFMAs, while its partner idles), and the two
 // waves of a SIMD run their MFMA phases together.  Measured on the scan (same box, A/B): 1.600 -> 1.502 ms emitting,
 // 1.327 -> 1.266 ms with +inf thresholds; the variants that ride the DMA instructions between the MFMA rows
-// (CONVDR_R3_VARIANT 1 / 2) are 1-2 % behind the two blocks.
+// (CONVDR_R3_VARIANT 1 / 2) are 1-2 % behind the two blocks -- re-measured in round 2 on the encoder GEMMs for every
+// placement (L sub-step, R sub-step) in {0,1} x {2,3}: 48.4-49.7 ms per 2048-passage forward against 47.8 for the blocks.
+// (gemm_stage_round exists because hipcc's host pass silently drops a template that calls the LDS-DMA builtin directly
+// inside the doubly nested unrolled MFMA loop; through a helper it instantiates.)
 #ifndef CONVDR_R3_VARIANT
 #define CONVDR_R3_VARIANT 0
 #endif
+#ifndef CONVDR_R3_LSUB   // variant 1: the sub-steps (0..3) whose MFMA rows carry the L / the R chunk's DMA instructions
+#define CONVDR_R3_LSUB 0
+#endif
+#ifndef CONVDR_R3_RSUB
+#define CONVDR_R3_RSUB 3
+#endif
+static_assert(CONVDR_R3_LSUB <= CONVDR_R3_RSUB, "the L chunk must be issued before the R chunk (counted vmcnt)");
 template <class T>
 struct TileSrcAll {   // all waves issue
   StageSrc R, L;
@@ -371,14 +388,12 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
         for (int j = 0; j < T::NT; ++j)
           acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc.c[i][j], 0, 0, 0);
 #if CONVDR_R3_VARIANT == 1
-        if (s == 0 && issue_l && i < L_DPW)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(src.L.rsrc, (lptr_t)(l_dst + (i * T::WAVES + w.wave) * 8 * 128), 16, src.L.voff,
-                                                   i * src.L.round_pitch + (kt + 1) * (GEMM_BK * 2), 0, 0);
+        if (s == CONVDR_R3_LSUB && r1_deferred && kt == 0 && issue_l && i < R_DPW)
+          gemm_stage_round<T::WAVES>(src.R, i, 1, sR + (rs == 2 ? 0 : rs + 1) * T::R_BYTES, w.wave);
+        if (s == CONVDR_R3_LSUB && issue_l && i < L_DPW) gemm_stage_round<T::WAVES>(src.L, i, kt + 1, l_dst, w.wave);
 #endif
-#if CONVDR_R3_VARIANT >= 1
-        if (s == 3 && issue_r && i < R_DPW)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(src.R.rsrc, (lptr_t)(r_dst + (i * T::WAVES + w.wave) * 8 * 128), 16, src.R.voff,
-                                                   i * src.R.round_pitch + (kt + 2) * (GEMM_BK * 2), 0, 0);
+#if CONVDR_R3_VARIANT == 1 || CONVDR_R3_VARIANT == 2
+        if (s == CONVDR_R3_RSUB && issue_r && i < R_DPW) gemm_stage_round<T::WAVES>(src.R, i, kt + 2, r_dst, w.wave);
 #endif
       }
 #if defined(CONVDR_R3_SETPRIO)
