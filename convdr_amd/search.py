@@ -42,7 +42,9 @@ class FlatIPIndex:
             raise _lib.ConvdrError("FlatIPIndex needs a GPU (no CPU fallback)")
         assert precision in ("auto", "bf16", "bf16x3")
         _lib.lib()
-        self.d = int(d)
+        # the scan contracts in 64-wide K steps: other widths get zero columns, which add exact zeros to every score
+        self.d_in = int(d)
+        self.d = (self.d_in + 63) // 64 * 64
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.cap, self.rank_target = int(cap), int(rank_target)
         self.precision, self.center = precision, bool(center)
@@ -88,6 +90,8 @@ class FlatIPIndex:
         host copy of the 14.6 GB block) and a pageable copy (run_convdr_inference.py:164-180)."""
         import torch
         chunk_bytes = int(chunk_bytes or self.host_chunk_bytes)
+        if self.d != self.d_in:
+            x = self._pad_columns(x.array if hasattr(x, "array") else x)
         if hasattr(x, "read_rows_into") and hasattr(x, "array"):        # a blocks.BlockView: positioned reads from the file
             arr = x.array
             if arr.dtype == np.float32 and arr.ndim == 2 and arr.nbytes > chunk_bytes // 2:
@@ -109,6 +113,13 @@ class FlatIPIndex:
                 self._set_centre(t)
             pbf, plo = self._prepare(t, self.precision == "bf16x3" or self._plo is not None)
         self._append(t, pbf, plo)
+
+    def _pad_columns(self, x):
+        import torch
+        t = torch.as_tensor(x)
+        t = (t if t.dtype == torch.float32 else t.float()).to(self.device)
+        assert t.dim() == 2 and t.shape[1] == self.d_in, "expected [n, %d], got %s" % (self.d_in, tuple(t.shape))
+        return torch.nn.functional.pad(t, (0, self.d - self.d_in))
 
     def _set_centre(self, t):
         import torch
@@ -203,7 +214,7 @@ class FlatIPIndex:
         assert emb.dtype == torch.float32 and emb.is_contiguous() and row0 + m <= self.ntotal
         dst32, dstbf = self._p32[row0:row0 + m], self._pbf[row0:row0 + m]
         dstlo = None if self._plo is None else self._plo[row0:row0 + m]
-        dst32.copy_(emb)
+        dst32[:, :self.d_in].copy_(emb)      # (zero columns of a padded width stay zero)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().convdr_ip_prepare_block(_lib.ptr(dst32), m, self.d, _lib.ptr(self._centre), _lib.ptr(dstbf),
                                                          _lib.ptr(dstlo), _lib.ptr(self._max_norm), _lib.stream_ptr()),
@@ -292,7 +303,7 @@ class FlatIPIndex:
         qt = torch.as_tensor(q)
         if qt.dtype != torch.float32:
             qt = qt.float()
-        qt = qt.to(self.device).contiguous()
+        qt = (self._pad_columns(qt) if self.d != self.d_in else qt.to(self.device)).contiguous()
         assert qt.dim() == 2 and qt.shape[1] == self.d
         k = int(k)
         nq = int(qt.shape[0])

@@ -31,6 +31,8 @@ def _index(d=768, **kw):
     (5000, 5, 10, 64),        # small d (one k-step), small k
     (40000, 24, 100, 768),    # sampled threshold pass, ragged last tile
     (33000, 130, 7, 128),     # two query tiles, ragged both ways
+    (5000, 4, 100, 72),       # width that is not a multiple of the 64-wide K step (zero columns inside the index)
+    (3000, 3, 50, 32),
 ])
 def test_search_matches_oracle_bit_exact(torch_cuda, n, nq, k, d):
     P, Q = synth_corpus(100 + n % 97, n, d), synth_corpus(7, nq, d)

@@ -280,6 +280,12 @@ def test_flat_arena_training_matches_per_parameter_path():
             # Adam normalises each element's step to ~lr: an element whose gradient is rounding noise may move by a
             # full 3e-3 in either run, so compare the bulk
             d = (v - results[3][1][k]).abs()
+            if k.endswith("attention.self.key.bias"):
+                # softmax is invariant to a key bias: the true gradient is 0, what arrives is rounding noise, and Adam
+                # turns noise into full +-lr steps whose signs may differ between the runs (seen 1 run in 3 on the
+                # soak): bounded by 3 steps x lr each way
+                assert d.max().item() <= 2 * 3 * args.learning_rate * 1.05, (k, d.max().item())
+                continue
             assert d.mean().item() < 1e-5 + 1e-4 * v.abs().mean().item(), (k, d.mean().item())
 
 
