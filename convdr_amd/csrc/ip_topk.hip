@@ -318,6 +318,115 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan(const ScanArgs a) {
   }
 }
 
+// Emission with the slot reservation off the critical path (k_ip_scan_r3).  scan_epilogue<EMIT> counts a lane's hits,
+// reserves their list slots with a returning atomic and has to WAIT for it (~1.5 us of a ~20 us tile, plus the counting
+// sweep) before it can write them.  Here one sweep both counts and keeps a lane's first two hits in registers (hits
+// are ~0.2 per lane and tile; a lane with more than two -- one in several thousand -- takes the old reserve-and-wait
+// route for the rest), the reservation is issued and NOT waited for, and the two hits are written after the NEXT
+// tile's main loop, by which time it has long returned.
+template <class T>
+struct EmitPending {
+  uint32_t cnt[T::NT], slot[T::NT], id0[T::NT], id1[T::NT];
+  float s0[T::NT], s1[T::NT];
+  int64_t n0;
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int nt = 0; nt < T::NT; ++nt) { cnt[nt] = 0; slot[nt] = 0; id0[nt] = id1[nt] = 0; s0[nt] = s1[nt] = 0.f; }
+    n0 = 0;
+  }
+};
+
+template <class T>
+__device__ __forceinline__ void scan_emit_capture(const ScanArgs& a, GemmAcc<T>& acc, const WavePos<T>& w, int64_t m0, int64_t n0,
+                                                  const float (&tau_lane)[T::NT], EmitPending<T>& pd) {
+  const int rows_left = (int)(a.n - m0 < (int64_t)T::TR ? a.n - m0 : (int64_t)T::TR);
+  if (rows_left < T::TR) {   // the last passage tile: rows past n scored 0 (zero-filled operand) and must never hit
+#pragma unroll
+    for (int nt = 0; nt < T::NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < T::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (w.r_index(mt, r) >= rows_left) acc.c[mt][nt][r] = -INFINITY;
+  }
+  const uint32_t row0 = (uint32_t)m0;
+  pd.n0 = n0;
+  // per accumulator register: one compare and one wave-uniform branch when no lane hits (9 registers in 10); the
+  // capture itself is predicated, not branched (nested divergent branches cost hipcc an exec-mask stack in SGPR spills)
+#pragma unroll
+  for (int nt = 0; nt < T::NT; ++nt) {
+    const float tau = tau_lane[nt];
+    uint32_t c = 0, i0 = 0, i1 = 0;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < T::MT; ++mt) {
+      const f32x16 v = acc.c[mt][nt];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool hit = v[r] >= tau;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit) != 0ull, 0)) {
+          const uint32_t id = row0 + (uint32_t)w.r_index(mt, r);
+          const bool f0 = hit && c == 0, f1 = hit && c == 1;
+          s0 = f0 ? v[r] : s0; i0 = f0 ? id : i0;
+          s1 = f1 ? v[r] : s1; i1 = f1 ? id : i1;
+          c += hit ? 1u : 0u;
+        }
+      }
+    }
+    pd.cnt[nt] = c; pd.id0[nt] = i0; pd.id1[nt] = i1; pd.s0[nt] = s0; pd.s1[nt] = s1;
+  }
+#pragma unroll
+  for (int nt = 0; nt < T::NT; ++nt) {
+    const int q = (int)n0 + w.l_index(nt);
+    pd.slot[nt] = pd.cnt[nt] ? atomicAdd(&a.counts[(int64_t)q * IP_COUNT_STRIDE], pd.cnt[nt]) : 0u;
+  }
+#pragma unroll
+  for (int nt = 0; nt < T::NT; ++nt) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(pd.cnt[nt] > 2) == 0ull, 1)) continue;   // no lane of the wave overflowed
+    asm volatile("" : "+v"(pd.slot[nt]));   // hipcc: wait for the reservation once, not in front of every store
+    const int q = (int)n0 + w.l_index(nt);
+    float tau = tau_lane[nt];
+    asm volatile("" : "+v"(tau));   // opaque copy: or hipcc keeps all 128 compare masks of the sweep above alive (in spilled SGPRs) for this one
+    uint32_t* ids = a.cand_id + (int64_t)q * a.cap;
+    float* sc = a.cand_s + (int64_t)q * a.cap;
+    uint32_t k = 0;
+    const uint32_t base = pd.slot[nt];
+#pragma unroll
+    for (int mt = 0; mt < T::MT; ++mt) {
+      const f32x16 v = acc.c[mt][nt];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool hit = v[r] >= tau;
+        if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+          if (hit && k >= 2 && base + k < (uint32_t)a.cap) {
+            ids[base + k] = row0 + (uint32_t)w.r_index(mt, r);
+            sc[base + k] = v[r];
+          }
+          k += hit ? 1u : 0u;
+        }
+      }
+    }
+  }
+}
+
+template <class T>
+__device__ __forceinline__ void scan_emit_flush(const ScanArgs& a, const WavePos<T>& w, EmitPending<T>& pd) {
+  // hipcc: retire the reservations HERE, once (nothing else is in flight at the two call sites)
+#pragma unroll
+  for (int nt = 0; nt < T::NT; ++nt) asm volatile("" : "+v"(pd.slot[nt]));
+#pragma unroll
+  for (int nt = 0; nt < T::NT; ++nt) {
+    if (pd.cnt[nt] == 0) continue;
+    const int q = (int)pd.n0 + w.l_index(nt);
+    uint32_t* ids = a.cand_id + (int64_t)q * a.cap;
+    float* sc = a.cand_s + (int64_t)q * a.cap;
+    const uint32_t sl = pd.slot[nt];
+    if (sl < (uint32_t)a.cap) { ids[sl] = pd.id0[nt]; sc[sl] = pd.s0[nt]; }
+    if (pd.cnt[nt] > 1 && sl + 1 < (uint32_t)a.cap) { ids[sl + 1] = pd.id1[nt]; sc[sl + 1] = pd.s1[nt]; }
+    pd.cnt[nt] = 0;
+  }
+}
+
 // The emitting scan of 256 x 256 tiles on the 3 R-slot / 2 L-slot main loop (gemm_nt_mainloop_r3); same persistent walk,
 // next-tile prologue under the epilogue and one-tile-ahead thresholds as k_ip_scan.  (The split-bf16 scan and the
 // sampling modes stay on the two-stage loop.)
@@ -354,6 +463,8 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan_r3(const ScanArgs a) 
     }
   };
   load_tau(n0);
+  EmitPending<T> pend;
+  pend.clear();
   for (;;) {
     GemmAcc<T> acc;
     acc.zero();
@@ -363,9 +474,12 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan_r3(const ScanArgs a) 
     slots = gemm_nt_mainloop_r3<T>(src, a.d, smem, acc, w, slots, true);
 #pragma unroll
     for (int nt = 0; nt < T::NT; ++nt) asm volatile("" : "+v"(tau_lane[nt]));
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const WavePos<T> we(tid_e);
+    scan_emit_flush<T>(a, we, pend);   // the previous tile's hits: their reservations came back under this main loop
     const uint32_t next = idx + stride;
     const bool has_next = next < chunk_len;
-    const int ts_cur = ts;
     const int64_t m0_cur = m0, n0_cur = n0;
     if (has_next) {
       coords(next, ts, m0, n0);
@@ -373,13 +487,11 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan_r3(const ScanArgs a) 
       src = TileSrcAll<T>(a.P, a.d, a.n, a.Qb, a.d, a.nq_pad, m0, n0, w);
       gemm_r3_prologue<T>(src, a.d, smem, w, slots);
     }
-    int tid_e = threadIdx.x;
-    asm volatile("" : "+v"(tid_e));
-    const WavePos<T> we(tid_e);
-    scan_epilogue<IP_MODE_EMIT, T>(a, acc, we, ts_cur, m0_cur, n0_cur, tau_lane);
+    scan_emit_capture<T>(a, acc, we, m0_cur, n0_cur, tau_lane, pend);
     if (!has_next) break;
     idx = next;
   }
+  scan_emit_flush<T>(a, w, pend);
 }
 
 // ------------------------------------------------------------------------------------------
