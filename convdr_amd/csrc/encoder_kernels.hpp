@@ -510,6 +510,28 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
       }
     }
     float bias_next = has_next ? bias_slice(cn) : 0.f;
+    // EPI_RESID_F32 on the 128^2 tiles (training forward at a few thousand rows: one wave of tiles, so a tile's latency
+    // IS the kernel's): the bf16 residual fragments are fetched here, under the main loop, instead of in the epilogue
+    // where each of the two column blocks exposed a full memory round trip (32 VGPRs; the 256^2 form has none to spare)
+    constexpr bool RES_PRE = EPI == EPI_RESID_F32 && T::WAVES == 4;
+    uint2 res_pre[RES_PRE ? T::NT : 1][T::MT][4];
+    if constexpr (RES_PRE) {
+      if (a.Rf == nullptr) {
+#pragma unroll
+        for (int nt = 0; nt < T::NT; ++nt) {
+          const int64_t t = c.t0 + w.l_index(nt);
+          const int64_t tc = t < a.rows ? t : a.rows - 1;
+#pragma unroll
+          for (int mt = 0; mt < T::MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              int f = c.n0 + w.r_base(mt, g);
+              f = f < a.N ? f : a.N - 4;
+              res_pre[nt][mt][g] = *(const uint2*)(a.R + tc * a.N + f);
+            }
+        }
+      }
+    }
     CONVDR_TRACE(0)
     int idle;   // the stage the last K step did not read
     if constexpr (R3) {
@@ -524,6 +546,14 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
     // hipcc does not see the main loop's inline-asm waits: make it retire the bias loads HERE (a no-op wait, nothing
     // is in flight), not at their first use further down
     asm volatile("" : "+v"(bias_next));
+    if constexpr (RES_PRE) {
+#pragma unroll
+      for (int nt = 0; nt < T::NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < T::MT; ++mt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(res_pre[nt][mt][g].x), "+v"(res_pre[nt][mt][g].y));
+    }
 #pragma unroll
     for (int i = 0; i < T::NT; ++i) asm volatile("" : "+v"(bias_lane[i]));
     if (threadIdx.x < T::TR) sbias[threadIdx.x] = bias_next;   // (every wave has read this tile's slice before its
@@ -611,9 +641,13 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                 for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
                   for (int g = 0; g < 4; ++g) {
-                    int f = n0 + we.r_base(mt, g);
-                    f = (full_n || f < a.N) ? f : a.N - 4;
-                    res[mt][g] = *(const uint2*)(a.R + tc * a.N + f);
+                    if constexpr (RES_PRE) {
+                      res[mt][g] = res_pre[nt][mt][g];
+                    } else {
+                      int f = n0 + we.r_base(mt, g);
+                      f = (full_n || f < a.N) ? f : a.N - 4;
+                      res[mt][g] = *(const uint2*)(a.R + tc * a.N + f);
+                    }
                   }
               }
             }
