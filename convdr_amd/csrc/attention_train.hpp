@@ -243,19 +243,12 @@ static __global__ void __launch_bounds__(256, 3) k_attention_train_fwd(const Att
 #undef CONVDR_PV_STEP
   }
   l += __shfl_xor(l, 32, 64);
-  if (q < plen) {
+  __syncthreads();   // the K / V tiles are dead: their LDS takes the output tiles (whole-line stores, attn_park_store)
+  {
     const float inv = q < len ? 1.f / l : 0.f;   // alignment rows [len, plen): zeros
-    bf16_t* dst = a.ctx + (base + q) * H + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 ov;
-        ov.x = pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
-        ov.y = pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-        *(uint2*)(dst + dt * 32 + 8 * g + 4 * hi) = ov;
-      }
-    if (hi == 0) a.lse[(int64_t)h * a.ldt + base + q] = q < len ? m * c + __log2f(l) : 0.f;
+    const int r0 = q - (lane & 31);
+    attn_park_store(smem + wave * 4096, o, inv, lane, a.ctx + (base + r0) * H + h * 64, H, plen - r0);
+    if (q < plen && hi == 0) a.lse[(int64_t)h * a.ldt + base + q] = q < len ? m * c + __log2f(l) : 0.f;
   }
 }
 
@@ -387,18 +380,11 @@ static __global__ void __launch_bounds__(256, 3) k_attention_bwd_dq(const AttnBw
     CONVDR_DQ_STEP(3, 48, 0)
 #undef CONVDR_DQ_STEP
   }
-  if (q < plen) {
+  __syncthreads();   // the K / V tiles are dead
+  {
     const float keep = q < len ? 1.f : 0.f;
-    bf16_t* dst = a.dQKV + (base + q) * H3 + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 ov;
-        ov.x = pack_bf16x2(dq[dt][4 * g + 0] * keep, dq[dt][4 * g + 1] * keep);
-        ov.y = pack_bf16x2(dq[dt][4 * g + 2] * keep, dq[dt][4 * g + 3] * keep);
-        *(uint2*)(dst + dt * 32 + 8 * g + 4 * hi) = ov;
-      }
+    const int r0 = q - (lane & 31);
+    attn_park_store(smem + wave * 4096, dq, keep, lane, a.dQKV + (base + r0) * H3 + h * 64, H3, plen - r0);
   }
 }
 
@@ -539,22 +525,12 @@ static __global__ void __launch_bounds__(256, 2) k_attention_bwd_dkv(const AttnB
       }
     }
   }
-  if (key < plen) {
+  __syncthreads();   // the Q / dO tiles are dead
+  {
     const float keep = key < len ? 1.f : 0.f;
-    bf16_t* dstk = a.dQKV + (base + key) * H3 + H + h * 64;
-    bf16_t* dstv = a.dQKV + (base + key) * H3 + 2 * H + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 ok, ov;
-        ok.x = pack_bf16x2(dk[dt][4 * g + 0] * keep, dk[dt][4 * g + 1] * keep);
-        ok.y = pack_bf16x2(dk[dt][4 * g + 2] * keep, dk[dt][4 * g + 3] * keep);
-        ov.x = pack_bf16x2(dv[dt][4 * g + 0] * keep, dv[dt][4 * g + 1] * keep);
-        ov.y = pack_bf16x2(dv[dt][4 * g + 2] * keep, dv[dt][4 * g + 3] * keep);
-        *(uint2*)(dstk + dt * 32 + 8 * g + 4 * hi) = ok;
-        *(uint2*)(dstv + dt * 32 + 8 * g + 4 * hi) = ov;
-      }
+    const int r0 = key - (lane & 31);
+    attn_park_store(smem + wave * 4096, dk, keep, lane, a.dQKV + (base + r0) * H3 + H + h * 64, H3, plen - r0);
+    attn_park_store(smem + wave * 4096, dv, keep, lane, a.dQKV + (base + r0) * H3 + 2 * H + h * 64, H3, plen - r0);
   }
 }
 

@@ -755,11 +755,38 @@ struct AttnArgs {
 #define CONVDR_ATT_TRACE(i)
 #endif
 
-#ifndef CONVDR_ATT_O_LDS
-#define CONVDR_ATT_O_LDS 1   // output rows through LDS (whole-line stores); 0: 8-byte pieces straight from the registers
-#endif
 constexpr int ATT_TILE_PAIR = 2 * 64 * 128;   // K tile + V^T tile, 8 KB each
 constexpr int ATT_SMEM_BYTES = 2 * ATT_TILE_PAIR;  // double buffered
+
+// A wave's 32 x 64 output tile (MFMA layout: lane (li, hi) holds 8-byte pieces of row li) -> global rows in whole
+// 128-byte lines.  Stored straight from the registers a wave instruction touches 32 rows with 16 bytes each (256
+// partial-line operations per wave against 32 for its K / V^T tiles); here the wave parks the tile in 4 KB of dead LDS
+// (16-byte chunk index XOR row & 7) and each store instruction writes 8 whole rows.  `so`: the wave's 4 KB (every wave
+// of the workgroup must be done with whatever lived there); dst: element (row 0, column 0) of the tile; rows < nvalid
+// are written.  Attention forward 4.08 -> 3.86 ms per 12 layers.
+__device__ __forceinline__ void attn_park_store(char* so, const f32x16 (&o)[2], float scale, int lane, bf16_t* dst,
+                                                int64_t pitch, int nvalid) {
+  const int li = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint2 ov;
+      ov.x = pack_bf16x2(o[dt][4 * g + 0] * scale, o[dt][4 * g + 1] * scale);
+      ov.y = pack_bf16x2(o[dt][4 * g + 2] * scale, o[dt][4 * g + 3] * scale);
+      *(uint2*)(so + li * 128 + (((dt * 4 + g) ^ (li & 7)) << 4) + hi * 8) = ov;
+    }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a wave's LDS operations execute in order; this pins the compiler's)
+  const int c8 = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (lane >> 3) + 8 * i;
+    const uint4 v = *(const uint4*)(so + row * 128 + ((c8 ^ (row & 7)) << 4));
+    if (row < nvalid) *(uint4*)(dst + row * pitch + c8 * 8) = v;
+  }
+  __builtin_amdgcn_wave_barrier();   // (the region may be parked into again)
+}
 
 // CLS_Q (last layer of an inference pass): only the CLS row of every sequence is needed downstream.  Q is then a
 // [B, H] matrix of CLS queries (row b), the workgroup still streams the sequence's K / V^T tiles, wave 0 alone does the
@@ -906,53 +933,14 @@ static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs 
     }
     return;
   }
-#if CONVDR_ATT_O_LDS
-  // A lane holds 8-byte pieces of its query's 128-byte output row: stored directly, a wave instruction touches 32 rows
-  // with 16 bytes each (256 partial-line operations per wave against 32 for its K / V^T tiles).  The wave parks its
-  // 32 x 64 tile in the dead K / V^T buffers instead (16-byte chunk index XOR row & 7) and writes whole lines.
-  __syncthreads();   // every wave is done with the last K / V^T tile
+  __syncthreads();   // every wave is done with the last K / V^T tile: its buffers take the output tiles (attn_park_store)
   {
     // alignment rows [len, plen) get zeros: they feed later GEMMs / V^T columns and must stay finite
     const float inv = q < len ? 1.f / l : 0.f;
-    char* so = smem + wave * 4096;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 ov;
-        ov.x = pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
-        ov.y = pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-        *(uint2*)(so + li * 128 + (((dt * 4 + g) ^ (li & 7)) << 4) + hi * 8) = ov;
-      }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a wave's LDS operations execute in order; this pins the compiler's)
-    const int c8 = lane & 7;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (lane >> 3) + 8 * i;
-      const uint4 v = *(const uint4*)(so + row * 128 + ((c8 ^ (row & 7)) << 4));
-      const int qr = q0 + wave * 32 + row;
-      if (qr < plen) *(uint4*)(a.ctx + (base + qr) * H + h * 64 + c8 * 8) = v;
-    }
+    const int r0 = q0 + wave * 32;
+    attn_park_store(smem + wave * 4096, o, inv, lane, a.ctx + (base + r0) * H + h * 64, H, plen - r0);
     if (q < plen && a.lse && hi == 0) a.lse[(int64_t)h * a.ldt + base + q] = q < len ? m * a.scale + logf(l) : 0.f;
   }
-#else
-  if (q < plen) {
-    // alignment rows [len, plen) get zeros: they feed later GEMMs / V^T columns and must stay finite
-    const float inv = q < len ? 1.f / l : 0.f;
-    bf16_t* dst = a.ctx + (base + q) * H + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 ov;
-        ov.x = pack_bf16x2(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
-        ov.y = pack_bf16x2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-        *(uint2*)(dst + dt * 32 + 8 * g + 4 * hi) = ov;
-      }
-    if (a.lse && hi == 0) a.lse[(int64_t)h * a.ldt + base + q] = q < len ? m * a.scale + logf(l) : 0.f;
-  }
-#endif
   CONVDR_ATT_TRACE(5)
 }
 
