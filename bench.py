@@ -9,7 +9,9 @@ top-100, bf16 MFMA".  One step = one pass of the hot path over one batch:
   (iii) run the exact 1k-query x 1M-passage inner-product top-100 search over the resident block.
 `value` = passages encoded per second of whole-step time (search and fold included); the search rate is
 reported beside it.  With N > 1 every rank owns a model replica and its own 1M-passage shard (weak scaling: the
-corpus and the passage stream partition by rank); no collective inside the timed region.
+corpus and the passage stream partition by rank).  The encode leg has no collective; the search leg has
+the path's one real exchange step: the query embeddings are all-gathered, every rank searches its shard, the per-rank
+top-k lists are all-gathered and merged on the device (parallel.search_sharded_device, BASELINE configs[3]).
 """
 import argparse
 import json
