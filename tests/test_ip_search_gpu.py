@@ -338,3 +338,35 @@ def test_mid_size_blocks_get_a_threshold(torch_cuda, n):
     Dr, Ir = OS.flat_ip_search(Q, P, 100)
     np.testing.assert_array_equal(I, Ir)
     np.testing.assert_array_equal(D, Dr)
+
+
+def test_randomised_cases_match_the_oracle(torch_cuda):
+    """A slice of tools/dbg/search_fuzz.py (60 cases there, 0 mismatches): random sizes and widths, duplicated rows
+    (exact ties), a dominant common component, wildly different norms, half-integer values (many tied scores), several
+    add() calls per index."""
+    for c in range(14):
+        rs = np.random.RandomState(1000 + c)
+        d = int(rs.choice([64, 768, 768, 40, 200]))
+        n = int(rs.choice([1, 64, 300, 4097, 9000, 33000]))
+        nq, k, kind = int(rs.choice([1, 3, 130])), int(rs.choice([1, 10, 100, 333])), c % 5
+        P = rs.randn(n, d).astype(np.float32)
+        if kind == 1:
+            P[rs.randint(0, n, size=n // 2 + 1)] = P[rs.randint(0, n, size=n // 2 + 1)]
+        elif kind == 2:
+            P = (0.05 * P + rs.randn(1, d).astype(np.float32) * 3).astype(np.float32)
+        elif kind == 3:
+            P *= np.exp(rs.randn(n, 1) * 2).astype(np.float32)
+        elif kind == 4:
+            P = np.round(P * 2) / 2
+        Q = rs.randn(nq, d).astype(np.float32)
+        if kind == 4:
+            Q = np.round(Q * 2) / 2
+        idx = _index(d)
+        cut = int(rs.randint(0, n + 1))
+        for a, b in ((0, cut), (cut, n)):
+            if b > a:
+                idx.add(P[a:b])
+        D, I = idx.search(Q, k)
+        Dr, Ir = OS.flat_ip_search(Q, P, k)
+        np.testing.assert_array_equal(I, Ir, err_msg="case %d" % c)
+        np.testing.assert_array_equal(D, Dr, err_msg="case %d" % c)
