@@ -154,6 +154,7 @@ class FlatIPIndex:
                 self._stage = None
             if self._stage is None or self._stage[0].shape[0] < min(rows_per, n):
                 self._stage = [torch.empty((min(rows_per, n), d), dtype=torch.float32).pin_memory() for _ in range(2)]
+                self._stage_ev = [None, None]
             cs = self._copy_stream
             p32 = torch.empty((n, d), dtype=torch.float32, device=self.device)
             pbf = torch.empty((n, d), dtype=torch.bfloat16, device=self.device)
@@ -165,7 +166,11 @@ class FlatIPIndex:
                 from concurrent.futures import ThreadPoolExecutor
                 self._pool, self._pool_threads = ThreadPoolExecutor(max_workers=threads), threads
             pool = self._pool
-            freed = [None, None]                    # staging buffer i may be refilled once its H2D copy has completed
+            # staging buffer i may be refilled once its H2D copy has completed.  The events outlive the call: the buffers do
+            # too, and the last copies of one add() are still in flight when the next add() starts filling them (found by
+            # tests/test_ip_search_gpu.py::test_randomised_cases_match_the_oracle: 1 run in ~500 put rows of the second
+            # block into the first)
+            freed = self._stage_ev
             first = self._p32 is None
             for ci, s in enumerate(range(0, n, rows_per)):
                 e = min(n, s + rows_per)

@@ -370,3 +370,19 @@ def test_randomised_cases_match_the_oracle(torch_cuda):
         Dr, Ir = OS.flat_ip_search(Q, P, k)
         np.testing.assert_array_equal(I, Ir, err_msg="case %d" % c)
         np.testing.assert_array_equal(D, Dr, err_msg="case %d" % c)
+
+
+def test_back_to_back_streamed_adds_keep_their_rows(torch_cuda):
+    """Two host blocks added one right after the other both go through the same two pinned staging buffers: the second
+    add() must not refill a buffer whose copy from the first is still in flight (it did, once in ~500 runs, until the
+    buffers' completion events outlived the call).  Checks the resident block bit for bit, many times."""
+    torch = torch_cuda
+    rs = np.random.RandomState(3)
+    A = rs.randn(20515, 768).astype(np.float32)
+    B = rs.randn(12485, 768).astype(np.float32)
+    want = torch.from_numpy(np.concatenate([A, B], 0))
+    for rep in range(25):
+        idx = _index(768)
+        idx.add(A)
+        idx.add(B)
+        assert torch.equal(idx._p32.cpu(), want), "rep %d" % rep
