@@ -328,6 +328,9 @@ __device__ __forceinline__ float gelu_grad(float x) {
 // One stage holds TL / PASSES rows, so the tile leaves in PASSES passes of NT / PASSES MFMA column blocks.
 // LDS rows are TR * 2 bytes; the 16-byte chunk index is XOR-swizzled with the row so that both the 8-byte column
 // writes and the row-major 16-byte reads spread over all banks.
+#ifndef CONVDR_EPI_WAVE_LOCAL
+#define CONVDR_EPI_WAVE_LOCAL 1   // bf16 tile outputs of the token-major epilogue: 1 = each wave parks and stores its own part (no pass barriers)
+#endif
 template <class T>
 struct CTile {
   static constexpr int CH = T::TR / 8;                                   // 16-byte chunks per row
@@ -384,6 +387,50 @@ struct CTile {
         if (inside) {
           *(u32x4_t*)pr = v[j];
         } else if (rowc + r0 < row_limit && nv > 0) {
+          if (nv >= 8) *(u32x4_t*)pr = v[j];
+          else *(uint2*)pr = make_uint2(v[j].x, v[j].y);
+        }
+      }
+    }
+  }
+  // Wave-local form: a wave parks ITS OWN part of the pass -- 32 NTP token rows x the 32 MT features it computed, 8 KB,
+  // rows of MT * 64 bytes, 16-byte chunk index XOR row -- and writes it out itself, 64 / CW whole rows per instruction.
+  // No workgroup barrier between a pass's arithmetic and its stores, so the two waves of a SIMD drift apart and one
+  // computes while the other sits in its (~175-cycle-per-instruction) store issue; with the cooperative form both
+  // waves reached the stores together and the VALU idled through them (1.4 + 1.1 k cycles of a 49 k-cycle FFN1 tile).
+  static constexpr int CW = T::MT * 4;            // 16-byte chunks per wave row
+  static constexpr int RW = NTP * 32;             // rows per wave and pass
+  static constexpr int W_BYTES = RW * CW * 16;    // 8 KB
+  static constexpr int W_STORES = RW * CW / 64;
+  static_assert(W_BYTES * T::WAVES <= 2 * HALF_BYTES && (64 % CW) == 0, "wave-local park must fit the pass image");
+  __device__ static __forceinline__ uint32_t wave_base(Base sC, int wave) {
+    constexpr int PER_HALF = HALF_BYTES / W_BYTES;
+    return (wave >= PER_HALF ? sC.hi + (wave - PER_HALF) * W_BYTES : sC.lo + wave * W_BYTES);
+  }
+  __device__ static __forceinline__ void put_w(uint32_t wb, const WavePos<T>& w, int mt, int ntl, int g, uint2 o) {
+    const int row = ntl * 32 + w.li;
+    lds_write_b64_hidden(wb + row * (CW * 16) + (((mt * 4 + g) ^ (row & (CW - 1))) << 4) + w.hi * 8, (u32x2_t){o.x, o.y});
+  }
+  // dst -> element (row 0, column 0) of the WAVE's part of the pass; rows < row_limit and columns < col_limit are written
+  __device__ static __forceinline__ void store_w(uint32_t wb, int lane, bf16_t* dst, int64_t ld, int64_t row_limit,
+                                                 int64_t col_limit) {
+    constexpr int RPI = 64 / CW;
+    const int r0 = lane / CW, c = lane - r0 * CW;
+    const int64_t nv = col_limit - c * 8;
+    static_assert(W_STORES % 4 == 0, "lds_read4_b128_hidden reads four chunks");
+#pragma unroll
+    for (int i0 = 0; i0 < W_STORES; i0 += 4) {
+      u32x4_t v[4];
+      auto at = [&](int i) {
+        const int row = i * RPI + r0;
+        return wb + row * (CW * 16) + ((c ^ (row & (CW - 1))) << 4);
+      };
+      lds_read4_b128_hidden(at(i0), at(i0 + 1), at(i0 + 2), at(i0 + 3), v[0], v[1], v[2], v[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = (i0 + j) * RPI + r0;
+        bf16_t* pr = dst + (int64_t)row * ld + c * 8;
+        if (row < row_limit && nv > 0) {
           if (nv >= 8) *(u32x4_t*)pr = v[j];
           else *(uint2*)pr = make_uint2(v[j].x, v[j].y);
         }
@@ -627,7 +674,10 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
       for (int out = 0; out < NOUT; ++out)
 #pragma unroll
         for (int pass = 0; pass < CT::PASSES; ++pass) {
+#if !CONVDR_EPI_WAVE_LOCAL
           if (BF16_OUT && (pass || out)) lds_barrier();   // the previous pass has been read out
+#endif
+          const uint32_t wb = CT::wave_base(sC, we.wave);   // (wave-local park: a wave re-reads only what it wrote)
 #pragma unroll
           for (int ntl = 0; ntl < CT::NTP; ++ntl) {
             const int nt = pass * CT::NTP + ntl;
@@ -684,7 +734,11 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                   uint2 o;
                   o.x = pack_bf16x2(y0, y1);
                   o.y = pack_bf16x2(y2, y3);
+#if CONVDR_EPI_WAVE_LOCAL
+                  CT::put_w(wb, we, mt, ntl, g, o);
+#else
                   CT::put(sC, we, mt, nt, g, o);
+#endif
                 } else if (t_ok && (full_n || f < a.N)) {
                   if constexpr (EPI == EPI_SLAB_F32) {
                     *(float4*)(a.Cf + ((int64_t)blockIdx.y * a.rows + t) * a.N + f) = make_float4(y0, y1, y2, y3);
@@ -696,7 +750,9 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
           }
           CONVDR_TRACE(3 + 4 * pass)
           if constexpr (BF16_OUT) {
+#if !CONVDR_EPI_WAVE_LOCAL
             lds_barrier();
+#endif
             CONVDR_TRACE(4 + 4 * pass)
             if (out == NOUT - 1 && pass == CT::PASSES - 1 && has_next) {   // see the V third above
               lds_dma_wait_all();
@@ -704,13 +760,24 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
             }
             CONVDR_TRACE(5 + 4 * pass)
             if (a.dbg_skip_epi != 3) {
+              bf16_t* dst;
+              int64_t ldo, cols;
               if constexpr (EPI == EPI_QKV) {   // the tile lies inside the Q or the K third (H % TR == 0)
                 const int na = n0 + a.third0 * a.H;
-                bf16_t* dst = na < a.H ? a.Qo + t0 * a.H + na : a.Ko + t0 * a.H + (na - a.H);
-                CT::store(sC, pass, dst, a.H, a.rows - t0, T::TR, tid_e);
+                dst = na < a.H ? a.Qo + t0 * a.H + na : a.Ko + t0 * a.H + (na - a.H);
+                ldo = a.H; cols = T::TR;
               } else {
-                CT::store(sC, pass, a.dbg_skip_epi == 4 ? a.Cb : (out ? a.Cb2 : a.Cb) + t0 * a.N + n0, a.N, a.rows - t0, a.N - n0, tid_e);
+                dst = a.dbg_skip_epi == 4 ? a.Cb : (out ? a.Cb2 : a.Cb) + t0 * a.N + n0;
+                ldo = a.N; cols = a.N - n0;
               }
+#if CONVDR_EPI_WAVE_LOCAL
+              {
+                const int row0 = (we.wl * T::NT + pass * CT::NTP) * 32, col0 = we.wr * T::MT * 32;
+                CT::store_w(wb, we.lane, dst + (int64_t)row0 * ldo + col0, ldo, a.rows - t0 - row0, cols - col0);
+              }
+#else
+              CT::store(sC, pass, dst, ldo, a.rows - t0, cols, tid_e);
+#endif
             }
             CONVDR_TRACE(6 + 4 * pass)
           }
