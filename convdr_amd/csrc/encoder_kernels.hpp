@@ -328,6 +328,9 @@ __device__ __forceinline__ float gelu_grad(float x) {
 // One stage holds TL / PASSES rows, so the tile leaves in PASSES passes of NT / PASSES MFMA column blocks.
 // LDS rows are TR * 2 bytes; the 16-byte chunk index is XOR-swizzled with the row so that both the 8-byte column
 // writes and the row-major 16-byte reads spread over all banks.
+#ifndef CONVDR_EPI_HALVES
+#define CONVDR_EPI_HALVES 1   // 256^2 tiles: the two 128-byte halves of a pass row are stored as soon as each is parked (FFN1 -0.8 %)
+#endif
 #ifndef CONVDR_EPI_WAVE_LOCAL
 #define CONVDR_EPI_WAVE_LOCAL 1   // bf16 tile outputs of the token-major epilogue: 1 = each wave parks and stores its own part (no pass barriers)
 #endif
@@ -410,6 +413,33 @@ struct CTile {
   __device__ static __forceinline__ void put_w(uint32_t wb, const WavePos<T>& w, int mt, int ntl, int g, uint2 o) {
     const int row = ntl * 32 + w.li;
     lds_write_b64_hidden(wb + row * (CW * 16) + (((mt * 4 + g) ^ (row & (CW - 1))) << 4) + w.hi * 8, (u32x2_t){o.x, o.y});
+  }
+  // chunks [C0, C0 + CN) of every row only (CN * 16 bytes per row, 64 / CN rows per instruction)
+  template <int C0, int CN>
+  __device__ static __forceinline__ void store_w_part(uint32_t wb, int lane, bf16_t* dst, int64_t ld, int64_t row_limit,
+                                                      int64_t col_limit) {
+    constexpr int RPI = 64 / CN, N_ST = RW / RPI;
+    static_assert(64 % CN == 0 && N_ST % 4 == 0, "store_w_part geometry");
+    const int r0 = lane / CN, c = C0 + (lane - r0 * CN);
+    const int64_t nv = col_limit - c * 8;
+#pragma unroll
+    for (int i0 = 0; i0 < N_ST; i0 += 4) {
+      u32x4_t v[4];
+      auto at = [&](int i) {
+        const int row = i * RPI + r0;
+        return wb + row * (CW * 16) + ((c ^ (row & (CW - 1))) << 4);
+      };
+      lds_read4_b128_hidden(at(i0), at(i0 + 1), at(i0 + 2), at(i0 + 3), v[0], v[1], v[2], v[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = (i0 + j) * RPI + r0;
+        bf16_t* pr = dst + (int64_t)row * ld + c * 8;
+        if (row < row_limit && nv > 0) {
+          if (nv >= 8) *(u32x4_t*)pr = v[j];
+          else *(uint2*)pr = make_uint2(v[j].x, v[j].y);
+        }
+      }
+    }
   }
   // dst -> element (row 0, column 0) of the WAVE's part of the pass; rows < row_limit and columns < col_limit are written
   __device__ static __forceinline__ void store_w(uint32_t wb, int lane, bf16_t* dst, int64_t ld, int64_t row_limit,
@@ -678,6 +708,23 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
           if (BF16_OUT && (pass || out)) lds_barrier();   // the previous pass has been read out
 #endif
           const uint32_t wb = CT::wave_base(sC, we.wave);   // (wave-local park: a wave re-reads only what it wrote)
+          constexpr bool HALVES = CONVDR_EPI_WAVE_LOCAL && CONVDR_EPI_HALVES && BF16_OUT && T::MT >= 4 && CT::NTP == 1;
+          bf16_t* wdst = nullptr;
+          int64_t wld = 0, wrows = 0, wcols = 0;
+          if constexpr (HALVES) {
+            bf16_t* dst;
+            int64_t cols;
+            if constexpr (EPI == EPI_QKV) {
+              const int na = n0 + a.third0 * a.H;
+              dst = na < a.H ? a.Qo + t0 * a.H + na : a.Ko + t0 * a.H + (na - a.H);
+              wld = a.H; cols = T::TR;
+            } else {
+              dst = (out ? a.Cb2 : a.Cb) + t0 * a.N + n0;
+              wld = a.N; cols = a.N - n0;
+            }
+            const int row0 = (we.wl * T::NT + pass * CT::NTP) * 32, col0 = we.wr * T::MT * 32;
+            wdst = dst + (int64_t)row0 * wld + col0; wrows = a.rows - t0 - row0; wcols = cols - col0;
+          }
 #pragma unroll
           for (int ntl = 0; ntl < CT::NTP; ++ntl) {
             const int nt = pass * CT::NTP + ntl;
@@ -736,6 +783,12 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                   o.y = pack_bf16x2(y2, y3);
 #if CONVDR_EPI_WAVE_LOCAL
                   CT::put_w(wb, we, mt, ntl, g, o);
+                  if constexpr (HALVES) {
+                    if (mt == T::MT / 2 - 1 && g == 3) {   // the first half of the row is parked: send it off
+                      if (out == NOUT - 1 && pass == CT::PASSES - 1 && has_next) { lds_dma_wait_all(); landed = true; }
+                      CT::template store_w_part<0, CT::CW / 2>(wb, we.lane, wdst, wld, wrows, wcols);
+                    }
+                  }
 #else
                   CT::put(sC, we, mt, nt, g, o);
 #endif
@@ -771,7 +824,9 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                 ldo = a.N; cols = a.N - n0;
               }
 #if CONVDR_EPI_WAVE_LOCAL
-              {
+              if constexpr (HALVES) {
+                CT::template store_w_part<CT::CW / 2, CT::CW / 2>(wb, we.lane, wdst, wld, wrows, wcols);
+              } else {
                 const int row0 = (we.wl * T::NT + pass * CT::NTP) * 32, col0 = we.wr * T::MT * 32;
                 CT::store_w(wb, we.lane, dst + (int64_t)row0 * ldo + col0, ldo, a.rows - t0 - row0, cols - col0);
               }
