@@ -193,7 +193,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
   float* sRed = sBet + 768;              // [128 tokens][8 partial slots]
   float* sStat = sRed + 128 * 8;         // [128] mean, [128] rstd
   char* sC = smem + 16384;               // [64][1536 B] residual / output image (96 KB; 112 KB in all)
-  for (int i = threadIdx.x; i < 768; i += 512) { sBias[i] = a.bias[i]; sGam[i] = a.gamma[i]; sBet[i] = a.beta[i]; }
   const int slot = w.wr * 2 + w.hi;
   // residual window [t0, rows) as a buffer: rows past the end read as zeros
   const StageSrc srcR = ln_stage_src(a.R, 768, t0, a.rows, w.wave, w.lane);   // (only .rsrc is used)
@@ -221,7 +220,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srcR.rsrc, (lptr_t)(sC + (i * 512 + w.wave * 64) * 16), 16,
                                                (uint32_t)(tok * 1536 + c * 16), 0, 0, 0);
     }
-    if (nt == 0) { CONVDR_LN_TRACE(8) }
+    if (nt == 0) {
+      // the LayerNorm parameters ride under the first residual half's flight (staged before it, their loads and the
+      // residual's round trip were two exposed latencies in a row)
+      for (int i = threadIdx.x; i < 768; i += 512) { sBias[i] = a.bias[i]; sGam[i] = a.gamma[i]; sBet[i] = a.beta[i]; }
+      CONVDR_LN_TRACE(8)
+    }
     lds_dma_wait_all();
     if (nt == 0) { CONVDR_LN_TRACE(9) }
     __syncthreads();           // (first half: also publishes the LayerNorm parameters)
