@@ -1,0 +1,105 @@
+"""world_size-2 rehearsal of the N > 1 paths with the REAL kernels: two processes share cuda:0 and talk over gloo (RCCL
+refuses two ranks on one device), so everything but the transport is what `bench.py --gpus N` / a DDP run executes:
+the device-side sharded search + merge chain, and the data-parallel training step with the summed-gradient all-reduce
+and the 1 / W folded into the clip pass."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, fn, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2, port=29641):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _search_job(rank, world):
+    from convdr_amd import blocks, parallel
+    from convdr_amd.search import FlatIPIndex
+    from oracle import search as OS
+    rs = np.random.RandomState(0)
+    N, d, k, nq = 20011, 768, 100, 37
+    P = rs.randn(N, d).astype(np.float32)
+    P[301] = P[7]                                # an exact duplicate that lands on the other rank: the tie rule
+    Q = rs.randn(nq, d).astype(np.float32)
+    mine = blocks.shard_indices(N, world, rank)  # records i % W == rank, like the encode loop writes them
+    dev = torch.device("cuda", 0)
+    index = FlatIPIndex(d, device=dev)
+    index.add(P[mine])
+    per = (nq + world - 1) // world              # every rank "encoded" a slice of the queries
+    Ql = torch.zeros(per, d, device=dev)
+    Ql[:max(0, min(per, nq - rank * per))] = torch.from_numpy(Q[rank * per:(rank + 1) * per]).to(dev)
+    Qall = parallel.all_gather_rows(Ql)[:nq]
+    D, I, status = parallel.search_sharded_device(index, Qall, k, torch.from_numpy(mine).to(dev))
+    blocks_all = [(P[blocks.shard_indices(N, world, r)], blocks.shard_indices(N, world, r)) for r in range(world)]
+    mD, mI = OS.search_one_by_one(blocks_all, Q, k)
+    return bool(int((status != 0).sum()) == 0 and np.array_equal(I.cpu().numpy(), mI[:, :k]) and
+                np.array_equal(D.cpu().numpy(), mD[:, :k].astype(np.float32)))
+
+
+def test_two_ranks_sharded_search_on_device_equals_search_one_by_one():
+    assert all(_run(_search_job, 2, 29641))
+
+
+def _train_job(rank, world):
+    from types import SimpleNamespace
+    from convdr_amd import parallel
+    from convdr_amd import train as TR
+    from tests.test_train_gpu import _batch, _tiny
+    rs = np.random.RandomState(11)
+    B = 8
+    ids, mask = _batch(rs, B, 40, [40, 17, 33, 1, 8, 25, 40, 12])
+    tid, tmask = _batch(rs, B, 16, [16, 9, 4, 16, 7, 3, 11, 16])
+    args = SimpleNamespace(learning_rate=1e-3, adam_epsilon=1e-8, max_grad_norm=1.0, ranking_task=False, no_mse=False,
+                           num_negatives=0, gradient_accumulation_steps=1)
+    dev = torch.device("cuda", 0)
+
+    def run(sel, ddp_on):
+        student, teacher = _tiny(seed=3).to(dev).train(), _tiny(seed=4).to(dev).eval()
+        TR.flatten_parameters(student)
+        opt = TR.get_optimizer(args, student, weight_decay=0.0)
+        sched = TR.get_linear_schedule_with_warmup(opt, 0, 10)
+        ddp = parallel.DataParallelStudent(student) if ddp_on else None
+        batch = tuple(x[sel].to(dev) for x in (ids, mask, tid, tmask))
+        loss = TR.train_step(args, student, teacher, opt, sched, batch, ddp=ddp)[0]
+        return loss.item(), {k: v.detach().cpu().clone() for k, v in student.state_dict().items()}
+
+    half = slice(rank * B // world, (rank + 1) * B // world)
+    loss_dp, sd_dp = run(half, True)                 # this rank's half of the batch, gradients all-reduced
+    loss_1, sd_1 = run(slice(0, B), False)           # the whole batch in one process
+    worst = 0.0
+    for k, v in sd_1.items():
+        if v.dtype.is_floating_point and "key.bias" not in k:
+            # the first Adam step moves every element with a gradient by +-lr: the two runs can differ only where the
+            # sign of a rounding-noise gradient flips, i.e. in a vanishing fraction of the elements
+            worst = max(worst, (v - sd_dp[k]).abs().mean().item() / args.learning_rate)
+    return worst, loss_dp, loss_1
+
+
+def test_two_ranks_data_parallel_step_equals_one_process_on_the_whole_batch():
+    out = _run(_train_job, 2, 29643)
+    # the mean-over-batch loss of the whole batch is the mean of the two halves' losses
+    assert abs(0.5 * (out[0][1] + out[1][1]) - out[0][2]) < 2e-5 * max(1.0, abs(out[0][2])), out
+    for worst, _, _ in out:
+        assert worst < 0.02, out     # mean |difference| per tensor, in units of the step size
