@@ -28,6 +28,23 @@ H, I, LAYERS, HEADS, D_OUT = 768, 3072, 12, 12, 768
 LINEAR_FLOP_PER_TOKEN = LAYERS * 2 * (4 * H * H + 2 * H * I)   # 169,869,312
 
 
+def _rehearsal_device(local_rank):
+    """CONVDR_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box only): every rank uses cuda:0."""
+    return 0 if os.environ.get("CONVDR_BENCH_SHARE_GPU") else local_rank
+
+
+def _init_group(dev):
+    """RCCL ("nccl" on ROCm).  CONVDR_BENCH_BACKEND=gloo is the companion of CONVDR_BENCH_SHARE_GPU: RCCL refuses two ranks
+    on one device, gloo moves the same CUDA tensors through the host -- the launch line, the rank logic and every kernel
+    are the N > 1 run's, only the transport (and so the timing) is not."""
+    import torch.distributed as dist
+    backend = os.environ.get("CONVDR_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+
+
 def flop_per_passage(L):
     return LINEAR_FLOP_PER_TOKEN * L + 36864 * L * L + 2 * H * D_OUT
 
@@ -198,12 +215,12 @@ def main_train(args):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = _rehearsal_device(int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist_on = world > 1 or bool(os.environ.get("CONVDR_BENCH_FORCE_DIST"))   # (the latter: 1-rank rehearsal of the N > 1 path)
     if dist_on:
-        dist.init_process_group("nccl", device_id=dev)
+        _init_group(dev)
     out = train_kd_measure(dev, rank, world, dist_on, args.steps, args.warmup, args.train_batch, dropout=args.train_dropout)
     if dist_on:
         dist.destroy_process_group()
@@ -328,12 +345,12 @@ def main():
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = _rehearsal_device(int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist_on = world > 1 or bool(os.environ.get("CONVDR_BENCH_FORCE_DIST"))   # (the latter: 1-rank rehearsal of the N > 1 path)
     if dist_on:
-        dist.init_process_group("nccl", device_id=dev)
+        _init_group(dev)
     from convdr_amd import _lib
     from convdr_amd.search import FlatIPIndex
     L_ = _lib.lib()
