@@ -293,7 +293,8 @@ class FlatIPIndex:
         return bad
 
     def search(self, q, k):
-        """FAISS ``index.search``: numpy in, numpy (D, I) out; always the exact top-k or an exception."""
+        """FAISS ``index.search``: numpy in, numpy (D, I) out; always the exact top-k (queries no scan can certify take the
+        exhaustive rung, `stats["exhaustive_queries"]`)."""
         D, I = self.search_tensors(q, k)
         return D.cpu().numpy(), I.cpu().numpy()
 
@@ -347,10 +348,63 @@ class FlatIPIndex:
         if self.precision == "auto":
             self._x3_first = self.stats["x3_queries"] > nq // 2
         if len(bad):
-            raise _lib.ConvdrError("convdr_ip_search: %d queries could not be certified (more than 8192 passages inside the "
-                                   "error band of the k-th score even with the split-bf16 scan)" % len(bad))
+            # last rung: more than 8192 passages inside the error band of the k-th score even with the split-bf16 scan
+            # (blocks whose norms spread over orders of magnitude: eps scales with the LARGEST norm).  Every slice of
+            # <= cap rows is searched with all of its rows as candidates -- exact by construction -- and the slices are
+            # merged in row order (earlier rows win ties): slow (one small launch chain per slice) but always an answer
+            idx = torch.as_tensor(np.asarray(bad, dtype=np.int64), device=self.device)
+            Db, Ib = self._search_exhaustive(qt[idx].contiguous(), k)
+            D[idx], I[idx] = Db, Ib
+            self.stats["exhaustive_queries"] = len(bad)
         return D, I
 
+    def _search_exhaustive(self, q, k):
+        import torch
+        L = _lib.lib()
+        nq, n = int(q.shape[0]), self.ntotal
+        kk = min(2 * k, 4096)           # candidates carried through the merges (see the re-ranking below)
+        cap = 4096
+        while cap < 2 * kk:
+            cap *= 2
+        step = cap                      # n <= cap: the plan takes every row as a candidate (no threshold pass, tau = -inf)
+
+        def exact(p32, pbf, m, kq, qq):
+            D = torch.empty((qq.shape[0], kq), dtype=torch.float32, device=self.device)
+            I = torch.empty((qq.shape[0], kq), dtype=torch.int64, device=self.device)
+            status = torch.empty(qq.shape[0], dtype=torch.int32, device=self.device)
+            tau_retry = torch.empty(qq.shape[0], dtype=torch.float32, device=self.device)
+            ws = self._workspace(L.convdr_ip_workspace_bytes(int(qq.shape[0]), m, self.d, kq, cap))
+            _lib.check(L.convdr_ip_search(_lib.ptr(qq), int(qq.shape[0]), _lib.ptr(p32), _lib.ptr(pbf), None, m, self.d, kq,
+                                          _lib.ptr(self._max_norm), None, cap, 0, _lib.ptr(ws), ws.numel(), _lib.ptr(D), _lib.ptr(I),
+                                          _lib.ptr(status), _lib.ptr(tau_retry), _lib.stream_ptr()), "convdr_ip_search")
+            if int((status != 0).sum().item()):
+                raise _lib.ConvdrError("convdr_ip_search: exhaustive slice of %d rows not certified" % m)
+            return D, I
+
+        merged = None
+        with torch.cuda.device(self.device):
+            for s0 in range(0, n, step):
+                e0 = min(n, s0 + step)
+                D, I = exact(self._p32[s0:e0], self._pbf[s0:e0], e0 - s0, kk, q)
+                I = torch.where(I >= 0, I + s0, I)
+                merged = (D, I) if merged is None else tuple(t[:, :kk].contiguous() for t in merge_topk_device(merged, (D, I), kk))
+            # The merges compare the fp32-rounded scores; the result's order is defined on the canonical fp64 scores (two
+            # rows whose scores round to the same fp32 value are NOT a tie).  So each query's <= 2k survivors -- a superset
+            # of its top-k: rounding is monotone -- are gathered in row order and ranked once more, exactly, as one slice.
+            Dout = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+            Iout = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+            for j in range(nq):
+                rows = merged[1][j]
+                rows = torch.sort(rows[rows >= 0]).values
+                m = int(rows.numel())
+                if m == 0:
+                    Dout[j] = -3.4028234663852886e38
+                    Iout[j] = -1
+                    continue
+                Dj, Ij = exact(self._p32[rows].contiguous(), self._pbf[rows].contiguous(), m, k, q[j:j + 1].contiguous())
+                Dout[j] = Dj[0]
+                Iout[j] = torch.where(Ij[0] >= 0, rows[Ij[0].clamp_min(0)], Ij[0])
+        return Dout, Iout
 
 def load_block(path):
     """pickle.load, as run_convdr_inference.py:164-175 does."""
