@@ -167,3 +167,32 @@ def test_use_mean_pooling_matches_reference(golden_dir):
     sd = _sd(np.load(os.path.join(golden_dir, "encoder_rdot_nll.npz")))
     emb = OE.rdot_nll_emb(sd, torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"]), num_layers=2, num_heads=2, use_mean=True)
     np.testing.assert_allclose(emb.numpy(), z["emb"], atol=2e-5, rtol=0)
+
+
+def test_product_eval_dev_query_equals_oracle_on_random_rankings(tmp_path):
+    """The vectorised product writer against the oracle's row-by-row restatement of run_convdr_inference.py:21-113 on
+    random rankings: many offsets mapping to the same pid (first occurrence kept), lists that run out of distinct pids
+    before topN, repeated query ids."""
+    from convdr_amd.search import EvalDevQuery
+    for seed in range(12):
+        rs = np.random.RandomState(seed)
+        nq, topN = int(rs.randint(1, 9)), int(rs.choice([1, 5, 20]))
+        n_off = int(rs.randint(topN, 200))
+        n_pid = int(rs.randint(1, n_off + 1))
+        offset2pid = rs.randint(0, n_pid, size=n_off).tolist()
+        width = int(rs.choice([topN, 2 * topN]))                     # merged lists keep 2 * topN entries after >= 2 blocks
+        merged_I = np.stack([rs.permutation(n_off)[:width] if n_off >= width else rs.randint(0, n_off, size=width)
+                             for _ in range(nq)]).astype(np.int64)
+        merged_D = -np.sort(-rs.rand(nq, width) * 100, axis=1)
+        qids = ["q%d" % (i if rs.rand() < 0.85 else 0) for i in range(nq)]
+        with open(tmp_path / "queries.raw.tsv", "w") as f:
+            for q in sorted(set(qids)):
+                f.write("%s\ttext of %s\n" % (q, q))
+        with open(tmp_path / "collection.tsv", "w") as f:
+            for pid in range(n_pid):
+                f.write("%d\tpassage %d\n" % (pid, pid))
+        out_j, out_t = str(tmp_path / ("o%d.jsonl" % seed)), str(tmp_path / ("o%d.trec" % seed))
+        EvalDevQuery(qids, merged_D, {}, merged_I, topN, out_j, out_t, offset2pid, str(tmp_path), "raw",
+                     raw_sequences=[["h", "c"]] * nq)
+        rows = OS.eval_dev_query_rows(qids, merged_D, merged_I, topN, offset2pid)
+        assert open(out_t).read() == "".join(OS.trec_lines(rows, topN)), seed
