@@ -328,6 +328,10 @@ __device__ __forceinline__ float gelu_grad(float x) {
 // One stage holds TL / PASSES rows, so the tile leaves in PASSES passes of NT / PASSES MFMA column blocks.
 // LDS rows are TR * 2 bytes; the 16-byte chunk index is XOR-swizzled with the row so that both the 8-byte column
 // writes and the row-major 16-byte reads spread over all banks.
+// Two forms share the pass image: the cooperative one above (put / store: the whole workgroup parks a pass, a barrier,
+// every thread stores rows other waves wrote) serves the transposed V^T tiles of the QKV projection; the token-major
+// outputs use the wave-local one (put_w / store_w / store_w_part, round 2): each wave parks and stores its own
+// 32 x (32 MT) part, with no barrier inside the passes.
 #ifndef CONVDR_EPI_HALVES
 #define CONVDR_EPI_HALVES 1   // 256^2 tiles: the two 128-byte halves of a pass row are stored as soon as each is parked (FFN1 -0.8 %)
 #endif
