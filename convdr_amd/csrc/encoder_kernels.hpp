@@ -323,83 +323,26 @@ __device__ __forceinline__ float gelu_grad(float x) {
 // ---- bf16 output tiles leave through LDS ---------------------------------------------------------------------
 // In the accumulator layout a lane owns 4 consecutive R indices of ONE L row, so a direct store instruction touches
 // 32 different output rows with 16 bytes each: 8192 partial-line write transactions per 256 x 256 tile.  Instead the
-// converted tile is parked in an idle operand stage as C[L row][R index] bf16 and written out cooperatively, 16
-// bytes per lane, every wave instruction covering whole 128-byte lines (QKV: 13.9 -> 11.5 ms per 12 layers).
-// One stage holds TL / PASSES rows, so the tile leaves in PASSES passes of NT / PASSES MFMA column blocks.
-// LDS rows are TR * 2 bytes; the 16-byte chunk index is XOR-swizzled with the row so that both the 8-byte column
-// writes and the row-major 16-byte reads spread over all banks.
-// Two forms share the pass image: the cooperative one above (put / store: the whole workgroup parks a pass, a barrier,
-// every thread stores rows other waves wrote) serves the transposed V^T tiles of the QKV projection; the token-major
-// outputs use the wave-local one (put_w / store_w / store_w_part, round 2): each wave parks and stores its own
-// 32 x (32 MT) part, with no barrier inside the passes.
+// converted tile is parked in dead operand slots as C[L row][R index] bf16 and written out 16 bytes per lane, every
+// wave instruction covering whole 128-byte lines (QKV: 13.9 -> 11.5 ms per 12 layers, round 1).  The image holds
+// TL / PASSES rows, so the tile leaves in PASSES passes of NT / PASSES MFMA column blocks.  Round 1 parked a pass
+// cooperatively (a workgroup barrier, then every thread stored rows other waves had written); since round 2 every
+// wave parks and stores ITS OWN 32 NTP x 32 MT part (put_w / store_w / store_w_part) with no barrier inside the
+// passes -- the token-major outputs and the transposed V^T tiles of the QKV projection alike.
 #ifndef CONVDR_EPI_HALVES
 #define CONVDR_EPI_HALVES 1   // 256^2 tiles: the two 128-byte halves of a pass row are stored as soon as each is parked (FFN1 -0.8 %)
 #endif
-#ifndef CONVDR_EPI_WAVE_LOCAL
-#define CONVDR_EPI_WAVE_LOCAL 1   // bf16 tile outputs of the token-major epilogue: 1 = each wave parks and stores its own part (no pass barriers)
-#endif
 template <class T>
 struct CTile {
-  static constexpr int CH = T::TR / 8;                                   // 16-byte chunks per row
   static constexpr int PASSES = (T::TL * T::TR * 2) / T::STAGE_BYTES;    // Tile256: 2, Tile128: 1
   static constexpr int NTP = T::NT / PASSES;                             // MFMA column blocks per pass
   static constexpr int ROWS = T::TL / PASSES;
-  static constexpr int STORES_PER_WAVE = ROWS * CH / T::THREADS;         // global store instructions per pass
   static_assert(PASSES >= 1 && PASSES * NTP == T::NT && ROWS * T::TR * 2 <= T::STAGE_BYTES, "C tile must fit a stage");
   // The parked pass lives in two half regions (rows [0, HALF) and [HALF, ROWS)): one contiguous stage in the
   // two-stage kernels (hi = lo + HALF_BYTES), two separate dead operand slots in the R3 form.
   static constexpr int HALF = ROWS / 2, HALF_BYTES = HALF * T::TR * 2;
   struct Base { uint32_t lo, hi; };
   __device__ static __forceinline__ Base contiguous(const char* sC) { return Base{lds_off(sC), lds_off(sC) + HALF_BYTES}; }
-  __device__ static __forceinline__ int addr(int row, int chunk) {   // row relative to its half; the swizzle term only
-    return row * (T::TR * 2) + ((chunk ^ ((row ^ (row / CH)) & (CH - 1))) << 4);   // needs put and store to agree
-  }
-  // registers 4g..4g+3 of MFMA tile (mt, nt) of this lane, packed to bf16
-  __device__ static __forceinline__ void put(Base sC, const WavePos<T>& w, int mt, int nt, int g, uint2 o) {
-    const int fl = w.r_base(mt, g);
-    const int row = (w.wl * NTP + (nt % NTP)) * 32 + w.li;
-    const bool up = row >= HALF;
-    lds_write_b64_hidden((up ? sC.hi : sC.lo) + addr(up ? row - HALF : row, fl >> 3) + (fl & 4) * 2, (u32x2_t){o.x, o.y});
-  }
-  // dst -> element (L row 0, R index 0) of the tile; row_limit / col_limit = valid L rows / R indices (col_limit % 4 == 0).
-  // Thread t owns 16-byte chunk t % CH of rows t / CH + 16 i: all LDS reads are issued before the first store, the
-  // per-iteration row offsets are compile-time, and a tile that lies fully inside the matrix takes no bound checks
-  // (the store tail was issue-bound: 325 cycles per store with the generic index arithmetic, measured by s_memtime).
-  __device__ static __forceinline__ void store(Base sC, int pass, bf16_t* dst, int64_t ld, int64_t row_limit,
-                                               int64_t col_limit, int tid) {
-    constexpr int RPI = T::THREADS / CH;   // rows covered per iteration
-    constexpr int BATCH = 4;               // LDS reads in flight before their stores (16 VGPRs; the kernel is at the cap)
-    static_assert(RPI * CH == T::THREADS && (32 * NTP) % RPI == 0 && ROWS % RPI == 0 && STORES_PER_WAVE % BATCH == 0 &&
-                      HALF % RPI == 0,
-                  "store geometry");
-    const int r0 = tid / CH, c = tid - r0 * CH;
-    const int64_t nv = col_limit - c * 8;
-    bf16_t* p = dst + c * 8 + (int64_t)r0 * ld;
-    const bool inside = row_limit >= T::TL && col_limit >= T::TR;   // workgroup-uniform
-#pragma unroll
-    for (int i0 = 0; i0 < STORES_PER_WAVE; i0 += BATCH) {
-      u32x4_t v[BATCH];
-      static_assert(BATCH == 4, "lds_read4_b128_hidden reads four chunks");
-      auto at = [&](int i) {   // (i * RPI) is compile-time: so is the choice of the half
-        const int row = i * RPI;
-        return (row >= HALF ? sC.hi : sC.lo) + addr((row >= HALF ? row - HALF : row) + r0, c);
-      };
-      lds_read4_b128_hidden(at(i0 + 0), at(i0 + 1), at(i0 + 2), at(i0 + 3), v[0], v[1], v[2], v[3]);
-#pragma unroll
-      for (int j = 0; j < BATCH; ++j) {
-        constexpr int blk = 32 * NTP;
-        const int i = i0 + j;
-        const int rowc = ((i * RPI) / blk * T::NT + pass * NTP) * 32 + (i * RPI) % blk;   // compile-time part of the row
-        bf16_t* pr = p + (int64_t)rowc * ld;
-        if (inside) {
-          *(u32x4_t*)pr = v[j];
-        } else if (rowc + r0 < row_limit && nv > 0) {
-          if (nv >= 8) *(u32x4_t*)pr = v[j];
-          else *(uint2*)pr = make_uint2(v[j].x, v[j].y);
-        }
-      }
-    }
-  }
   // Wave-local form: a wave parks ITS OWN part of the pass -- 32 NTP token rows x the 32 MT features it computed, 8 KB,
   // rows of MT * 64 bytes, 16-byte chunk index XOR row -- and writes it out itself, 64 / CW whole rows per instruction.
   // No workgroup barrier between a pass's arithmetic and its stores, so the two waves of a SIMD drift apart and one
@@ -669,11 +612,12 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
           for (int r = 0; r < 16; ++r) s += acc.c[mt][nt][r];
       if (s == 12345.678f) a.Cb[0] = f32_to_bf16(s);
     } else if (c.swap) {
-      // ---- V third -> Vt[feature][token]: features on lanes, tokens on registers ----
+      // ---- V third -> Vt[feature][token]: features on lanes, tokens on registers; wave-local park like the
+      // token-major outputs (a wave's part: 32 NTP features x its 32 MT tokens) ----
       lds_barrier();   // every wave is done with the last K step's stage
 #pragma unroll
       for (int pass = 0; pass < CT::PASSES; ++pass) {
-        if (pass) lds_barrier();   // the previous pass has been read out
+        const uint32_t wb = CT::wave_base(sC, we.wave);
 #pragma unroll
         for (int ntl = 0; ntl < CT::NTP; ++ntl) {
           const int nt = pass * CT::NTP + ntl;
@@ -686,15 +630,16 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
               uint2 o;
               o.x = pack_bf16x2(v[4 * g + 0] + bv, v[4 * g + 1] + bv);
               o.y = pack_bf16x2(v[4 * g + 2] + bv, v[4 * g + 3] + bv);
-              CT::put(sC, we, mt, nt, g, o);
+              CT::put_w(wb, we, mt, ntl, g, o);
             }
         }
-        lds_barrier();
         if (pass == CT::PASSES - 1 && has_next) {   // the prefetch has had the whole epilogue to land: retire it
           lds_dma_wait_all();                        // BEFORE the last stores enter the (in-order) queue
           landed = true;
         }
-        CT::store(sC, pass, a.Vt + (int64_t)(n0 + (a.third0 - 2) * a.H) * a.ldt + t0, a.ldt, a.N - n0, a.rows - t0, tid_e);
+        const int row0 = (we.wl * T::NT + pass * CT::NTP) * 32, col0 = we.wr * T::MT * 32;   // feature / token offsets
+        CT::store_w(wb, we.lane, a.Vt + (int64_t)(n0 + (a.third0 - 2) * a.H + row0) * a.ldt + t0 + col0, a.ldt,
+                    a.N - n0 - row0, a.rows - t0 - col0);
       }
     } else {
       // ---- epilogue: the tile's bias slice is parked in LDS behind the stages (no vmcnt round trip per register
@@ -708,11 +653,8 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
       for (int out = 0; out < NOUT; ++out)
 #pragma unroll
         for (int pass = 0; pass < CT::PASSES; ++pass) {
-#if !CONVDR_EPI_WAVE_LOCAL
-          if (BF16_OUT && (pass || out)) lds_barrier();   // the previous pass has been read out
-#endif
           const uint32_t wb = CT::wave_base(sC, we.wave);   // (wave-local park: a wave re-reads only what it wrote)
-          constexpr bool HALVES = CONVDR_EPI_WAVE_LOCAL && CONVDR_EPI_HALVES && BF16_OUT && T::MT >= 4 && CT::NTP == 1;
+          constexpr bool HALVES = CONVDR_EPI_HALVES && BF16_OUT && T::MT >= 4 && CT::NTP == 1;
           bf16_t* wdst = nullptr;
           int64_t wld = 0, wrows = 0, wcols = 0;
           if constexpr (HALVES) {
@@ -785,7 +727,6 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                   uint2 o;
                   o.x = pack_bf16x2(y0, y1);
                   o.y = pack_bf16x2(y2, y3);
-#if CONVDR_EPI_WAVE_LOCAL
                   CT::put_w(wb, we, mt, ntl, g, o);
                   if constexpr (HALVES) {
                     if (mt == T::MT / 2 - 1 && g == 3) {   // the first half of the row is parked: send it off
@@ -793,9 +734,6 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                       CT::template store_w_part<0, CT::CW / 2>(wb, we.lane, wdst, wld, wrows, wcols);
                     }
                   }
-#else
-                  CT::put(sC, we, mt, nt, g, o);
-#endif
                 } else if (t_ok && (full_n || f < a.N)) {
                   if constexpr (EPI == EPI_SLAB_F32) {
                     *(float4*)(a.Cf + ((int64_t)blockIdx.y * a.rows + t) * a.N + f) = make_float4(y0, y1, y2, y3);
@@ -807,9 +745,6 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
           }
           CONVDR_TRACE(3 + 4 * pass)
           if constexpr (BF16_OUT) {
-#if !CONVDR_EPI_WAVE_LOCAL
-            lds_barrier();
-#endif
             CONVDR_TRACE(4 + 4 * pass)
             if (out == NOUT - 1 && pass == CT::PASSES - 1 && has_next) {   // see the V third above
               lds_dma_wait_all();
@@ -827,16 +762,12 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                 dst = a.dbg_skip_epi == 4 ? a.Cb : (out ? a.Cb2 : a.Cb) + t0 * a.N + n0;
                 ldo = a.N; cols = a.N - n0;
               }
-#if CONVDR_EPI_WAVE_LOCAL
               if constexpr (HALVES) {
                 CT::template store_w_part<CT::CW / 2, CT::CW / 2>(wb, we.lane, wdst, wld, wrows, wcols);
               } else {
                 const int row0 = (we.wl * T::NT + pass * CT::NTP) * 32, col0 = we.wr * T::MT * 32;
                 CT::store_w(wb, we.lane, dst + (int64_t)row0 * ldo + col0, ldo, a.rows - t0 - row0, cols - col0);
               }
-#else
-              CT::store(sC, pass, dst, ldo, a.rows - t0, cols, tid_e);
-#endif
             }
             CONVDR_TRACE(6 + 4 * pass)
           }
