@@ -19,6 +19,10 @@ _SIGNATURES = {
     "convdr_ip_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "convdr_ip_search": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_int64, C.c_int, C.c_int, _p, _p, C.c_int, C.c_int,
                                    _p, C.c_size_t, _p, _p, _p, _p, _p]),
+    "convdr_ip_prepare_block_f16": (C.c_int, [_p, C.c_int64, C.c_int, _p, C.c_float, _p, _p, _p, _p]),
+    "convdr_ip_f16_scale": (C.c_float, [C.c_float]),
+    "convdr_ip_search_f16": (C.c_int, [_p, C.c_int, _p, _p, _p, C.c_float, C.c_int64, C.c_int, C.c_int, _p, _p, C.c_int,
+                                       C.c_int, _p, C.c_size_t, _p, _p, _p, _p, _p]),
     "convdr_ip_debug_counts": (_p, [_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "convdr_ip_debug_band": (_p, [_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
 }

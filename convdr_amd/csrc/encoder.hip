@@ -9,6 +9,7 @@
 namespace convdr {
 
 struct EncBufs {
+  int32_t* status;   // workspace offset 0: CONVDR_ENC_STATUS_* flags of the last forward
   int32_t *tok_id, *tok_pos;
   bf16_t *X, *Q, *K, *Vt, *ctx, *Hm, *cls_b, *cls_ctx, *cls_x, *cls_x1;
   float *Y, *cls_y, *cls_f, *head_y;
@@ -23,6 +24,7 @@ static EncBufs enc_plan(const convdr_encoder_config* c, int64_t rows, int B, cha
   const int H = c->hidden, I = c->intermediate;
   const int64_t rs = rows + 128;  // slack: attention K tiles / clamped reads
   p.ldt = align_up((size_t)rows + 64, 8);
+  p.status = (int32_t*)take(256);
   p.tok_id = (int32_t*)take(rs * 4);
   p.tok_pos = (int32_t*)take(rs * 4);
   p.X = (bf16_t*)take(rs * H * 2);
@@ -174,8 +176,9 @@ extern "C" int convdr_encoder_forward(const convdr_encoder_config* cfg, const co
   const int H = cfg->hidden;
   // V^T columns past the last row are read (never used) by the last key tile: keep them finite
   CONVDR_CHECK_HIP(hipMemset2DAsync(p.Vt + rows, p.ldt * 2, 0, (p.ldt - rows) * 2, H, st));
+  CONVDR_CHECK_HIP(hipMemsetAsync(p.status, 0, 256, st));
   hipLaunchKernelGGL(k_seq_pack, dim3((B + 3) / 4), dim3(256), 0, st, input_ids, ids_are_int32, attention_mask, seq_lens, B, L, cu_seqlens,
-                     cfg->kind, cfg->pad_idx, cfg->max_pos, p.tok_id, p.tok_pos);
+                     cfg->kind, cfg->pad_idx, cfg->max_pos, cfg->vocab, p.tok_id, p.tok_pos, p.status);
   CONVDR_CHECK_LAUNCH("k_seq_pack");
   {
     ProfScope prof("embed_ln", st);

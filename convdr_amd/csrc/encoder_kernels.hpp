@@ -17,6 +17,7 @@
 //   ctx  [rows, H]  bf16   attention output
 //   Hm   [rows, I]  bf16   gelu(FFN1)
 #pragma once
+#include "../../include/convdr_hip.h"
 #include "dropout.hpp"
 #include "gemm_nt.hpp"
 
@@ -34,8 +35,8 @@ namespace convdr {
 static __global__ void __launch_bounds__(256) k_seq_pack(const void* __restrict__ ids_v, int ids32,
                                                   const int64_t* __restrict__ mask, const int32_t* __restrict__ lens,
                                                   int B, int L, const int32_t* __restrict__ cu, int kind, int pad_idx,
-                                                  int max_pos, int32_t* __restrict__ tok_id,
-                                                  int32_t* __restrict__ tok_pos) {
+                                                  int max_pos, int vocab, int32_t* __restrict__ tok_id,
+                                                  int32_t* __restrict__ tok_pos, int32_t* __restrict__ status) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -44,15 +45,21 @@ static __global__ void __launch_bounds__(256) k_seq_pack(const void* __restrict_
   const int32_t* ids_i = (const int32_t*)ids_v;
   const int len_b = lens[b];
   int kept = 0, nonpad = 0;
+  int flags = 0;
   for (int l0 = 0; l0 < L; l0 += 64) {
     const int l = l0 + lane;
     const bool valid = l < L;
-    const int64_t id = valid ? (ids32 ? (int64_t)ids_i[(int64_t)b * L + l] : ids[(int64_t)b * L + l]) : (int64_t)pad_idx;
+    int64_t id = valid ? (ids32 ? (int64_t)ids_i[(int64_t)b * L + l] : ids[(int64_t)b * L + l]) : (int64_t)pad_idx;
     const bool m = valid && (mask ? mask[(int64_t)b * L + l] != 0 : l < len_b);
+    if (l == 0 && !m) flags |= CONVDR_ENC_STATUS_BAD_MASK;   // the CLS position must be unmasked
     const bool np = valid && id != pad_idx;
     const unsigned long long bm = __ballot(m), bnp = __ballot(np);
     const unsigned long long lt = (1ull << lane) - 1ull;
     if (m) {
+      // The reference's embedding lookup raises IndexError for an id outside the table (models.py:141-142 -> nn.Embedding).
+      // Here the id is clamped (no out-of-bounds read or atomic in the backward) and the batch is flagged; the host
+      // raises at its next look at the status word.
+      if (id < 0 || id >= (int64_t)vocab) { flags |= CONVDR_ENC_STATUS_BAD_TOKEN; id = 0; }
       const int row = base + kept + __popcll(bm & lt);
       if (row < end) {
         int p = kind == 0 ? (np ? nonpad + __popcll(bnp & (lt | (1ull << lane))) + pad_idx : pad_idx) : l;
@@ -63,6 +70,12 @@ static __global__ void __launch_bounds__(256) k_seq_pack(const void* __restrict_
     }
     kept += __popcll(bm);
     nonpad += __popcll(bnp);
+  }
+  if (kept != len_b) flags |= CONVDR_ENC_STATUS_BAD_LENS;    // seq_lens[b] != mask[b].sum() (or > L)
+  if (__ballot(flags != 0) != 0ull) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) flags |= __shfl_xor(flags, o, 64);
+    if (lane == 0) atomicOr(status, flags);
   }
   for (int r = base + kept + lane; r < end; r += 64) {
     tok_id[r] = -1;

@@ -70,6 +70,18 @@ __device__ __forceinline__ void lds_read4_b128_hidden(uint32_t a0, uint32_t a1, 
       : "memory");
 }
 
+// One MFMA of the engine: 32x32x16, fp32 accumulate; the operands are 16-bit words the staging never interprets --
+// bf16 everywhere except the fp16 rung of the similarity scan (ip_topk.hip), which reads the same LDS image as halfs
+// (v_mfma_f32_32x32x16_f16: same rate and register layout, 11 significand bits instead of 8).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_32x32x16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 template <int WR_, int WL_, int MT_, int NT_>
 struct TileCfg {
   static constexpr int WR = WR_, WL = WL_, MT = MT_, NT = NT_;
@@ -200,7 +212,7 @@ __device__ __forceinline__ void gemm_issue_stage(const TileSrc<T>& src, int kt, 
 // gemm_issue_stage (cross-tile prefetch of a persistent kernel); stage0_landed: ... and waited for it (vmcnt).  Returns the stage NOT read by the last K step: once
 // a wave is back from this call it may issue DMA into that stage (every wave has passed the last barrier, so all
 // reads of it are done); the other stage may be reused only after one more __syncthreads().
-template <class T>
+template <class T, bool F16 = false>
 __device__ __forceinline__ int gemm_nt_mainloop(const TileSrc<T>& src, int K, char* smem, GemmAcc<T>& acc,
                                                 const WavePos<T>& w, int first_buf = 0, bool stage0_in_flight = false,
                                                 bool stage0_landed = false, unsigned long long* step_trace = nullptr) {
@@ -255,7 +267,7 @@ __device__ __forceinline__ int gemm_nt_mainloop(const TileSrc<T>& src, int K, ch
       for (int i = 0; i < T::MT; ++i)
 #pragma unroll
         for (int j = 0; j < T::NT; ++j)
-          acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc.c[i][j], 0, 0, 0);
+          acc.c[i][j] = mfma_32x32x16<F16>(fa[s & 1][i], fb[s & 1][j], acc.c[i][j]);
       __builtin_amdgcn_sched_barrier(0);
     }
 #else
@@ -271,7 +283,7 @@ __device__ __forceinline__ int gemm_nt_mainloop(const TileSrc<T>& src, int K, ch
       for (int i = 0; i < T::MT; ++i)
 #pragma unroll
         for (int j = 0; j < T::NT; ++j)
-          acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc.c[i][j], 0, 0, 0);
+          acc.c[i][j] = mfma_32x32x16<F16>(a[i], b[j], acc.c[i][j]);
     }
 #endif
     CONVDR_STEP_TRACE(4)
@@ -326,7 +338,7 @@ __device__ __forceinline__ void gemm_r3_prologue(const TileSrcAll<T>& src, int K
 // Returns the slot state for the NEXT tile: once a wave is back from this call, the R slots `rs`, rs + 1 and the L slot
 // `ls` of the returned state are free (the last step read the other ones), so the next tile's prologue may be issued
 // at once -- under this tile's epilogue (prologue_in_flight on the next call).
-template <class T>
+template <class T, bool F16 = false>
 __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src, int K, char* smem, GemmAcc<T>& acc,
                                                        const WavePos<T>& w, R3Slots st = R3Slots{0, 0},
                                                        bool prologue_in_flight = false, bool r1_deferred = false,
@@ -386,7 +398,7 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
       for (int i = 0; i < T::MT; ++i) {
 #pragma unroll
         for (int j = 0; j < T::NT; ++j)
-          acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc.c[i][j], 0, 0, 0);
+          acc.c[i][j] = mfma_32x32x16<F16>(fa[s & 1][i], fb[s & 1][j], acc.c[i][j]);
 #if CONVDR_R3_VARIANT == 1
         if (s == CONVDR_R3_LSUB && r1_deferred && kt == 0 && issue_l && i < R_DPW)
           gemm_stage_round<T::WAVES>(src.R, i, 1, sR + (rs == 2 ? 0 : rs + 1) * T::R_BYTES, w.wave);

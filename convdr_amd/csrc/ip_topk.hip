@@ -37,47 +37,112 @@ constexpr int IP_SAMPLE_MAX = 262144;
 //   bf16 scan:        (1 + u)^2 - 1 = 2u + u^2          + d * 2^-23
 //   split-bf16 scan:  hi*hi + hi*lo + lo*hi leaves out lo*lo and the two second-rounding remainders,
 //                     each <= u^2 (1 + u) |q| |p|         + 3 d * 2^-23 (one accumulator chain over the three passes)
-static inline float ip_eps_coef(int d, bool x3) {
-  const double u = 1.0 / 256.0, acc = (double)d / 8388608.0;
+//   fp16 scan:        same forms with u = 2^-11 (8x tighter: 1.07e-3 at d = 768 in one pass, 2.8e-4 split) PLUS an absolute
+//                     term: below 2^-14 a half has no relative precision.  Both operands are scaled by powers of two
+//                     (exact; per block / per query) so that their norms sit near 2^12, and an element is charged
+//                     eta = 2^-14 of absolute error -- which also covers hardware that flushes subnormal MFMA inputs:
+//                     |fl(q) fl(p) - q p| summed over d  <=  rel |q||p| + eta (1 + u) sqrt(d) (|q| + |p|) + d eta^2
+//                     (ip_eps_abs; ~1e-6 of |q||p| at these scales).  The scan then works entirely in scaled units:
+//                     thresholds, candidate scores and eps; the results come from the fp64 re-scoring of the originals.
+constexpr int IP_KIND_BF16 = 0, IP_KIND_F16 = 1;
+static inline float ip_eps_coef(int d, bool x3, int kind = IP_KIND_BF16) {
+  const double u = kind == IP_KIND_F16 ? 1.0 / 2048.0 : 1.0 / 256.0, acc = (double)d / 8388608.0;
   const double c = x3 ? 3.0 * u * u * (1.0 + 2.0 * u) + 3.0 * acc : 2.0 * u + u * u + acc;
   return (float)(c * 1.0001);
 }
+constexpr double IP_F16_ETA = 1.0 / 16384.0;
+static inline float ip_eps_abs(int d, bool x3, int kind) {   // multiplies (|q| + max|p|), scaled units
+  if (kind != IP_KIND_F16) return 0.f;
+  // split scan: hi and lo are both halfs; the remainder x - hi - lo carries at most eta as well
+  return (float)((x3 ? 2.0 : 1.0) * IP_F16_ETA * (1.0 + 1.0 / 2048.0) * sqrt((double)d) * 1.0001);
+}
+constexpr float IP_F16_TARGET_EXP = 12.f;    // scales put the (first) max norm into [2^12, 2^13)
+constexpr float IP_F16_NORM_LIMIT = 60000.f; // scaled norms above this may hold elements that round to inf: CONVDR_IP_RANGE
 
 // ------------------------------------------------------------------------------------------
 // rows fp32 -> bf16 of (x - centre) (+ per-row L2 norm of the centred row, + global max norm).
 // Optional second output: the bf16 of the rounding remainder (x - centre) - hi, for the split-bf16 scan.
 // One wave per row, float4 loads.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_rows_to_bf16(const float* __restrict__ X, int64_t n, int d,
-                                                      const float* __restrict__ centre, bf16_t* __restrict__ Y,
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  const f16x2_t r = {(_Float16)lo, (_Float16)hi};   // v_cvt_pkrtz is NOT used: round to nearest even
+  return *(const uint32_t*)&r;
+}
+template <int KIND>
+__device__ __forceinline__ uint32_t pack_half2(float lo, float hi) {
+  return KIND == IP_KIND_F16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi);
+}
+template <int KIND>
+__device__ __forceinline__ float half_lo_to_f32(uint32_t packed) {
+  if constexpr (KIND == IP_KIND_F16) { const uint16_t h = (uint16_t)packed; return (float)*(const _Float16*)&h; }
+  return bf16_to_f32((bf16_t)packed);
+}
+template <int KIND>
+__device__ __forceinline__ float half_hi_to_f32(uint32_t packed) {
+  if constexpr (KIND == IP_KIND_F16) { const uint16_t h = (uint16_t)(packed >> 16); return (float)*(const _Float16*)&h; }
+  return bf16_to_f32((bf16_t)(packed >> 16));
+}
+
+// PER_ROW_SCALE (queries of the fp16 scan): every row is multiplied by its own power of two 2^(12 - e), |row| = m 2^e
+// with m in [0.5, 1), so its scaled norm lies in [2^11, 2^12); row_norm receives the SCALED norm.  Otherwise `scale`
+// (a power of two; 1 for bf16) multiplies every row and row_norm / max_norm are UNSCALED.
+template <int KIND, bool PER_ROW_SCALE>
+__global__ void __launch_bounds__(256) k_rows_to_half(const float* __restrict__ X, int64_t n, int d,
+                                                      const float* __restrict__ centre, float scale, bf16_t* __restrict__ Y,
                                                       bf16_t* __restrict__ Ylo, float* __restrict__ row_norm,
                                                       float* __restrict__ max_norm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float wmax = 0.f;
+  // Norms are summed in fp64: eps is proportional to them, and in fp32 the squares of elements below ~1e-19 underflow
+  // (a block of tiny-magnitude embeddings would get norm 0 = "no rounding error").  The pass is HBM-bound either way.
+  auto sq4 = [](const float4& v) {
+    return (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+  };
+  auto wave_sum_f64 = [](double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n; row += (int64_t)gridDim.x * 4) {
     const float* x = X + row * d;
-    float ss = 0.f;
+    double ss = 0.0;
+    float sc = scale;
+    if constexpr (PER_ROW_SCALE) {
+      for (int e = lane * 4; e < d; e += 256) ss += sq4(*(const float4*)(x + e));
+      ss = wave_sum_f64(ss);
+      int ex = 0;
+      const float nm0 = (float)sqrt(ss);
+      (void)frexpf(nm0, &ex);
+      int sh = (int)IP_F16_TARGET_EXP - ex;
+      sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+      sc = (nm0 > 0.f && nm0 < INFINITY) ? ldexpf(1.f, sh) : 1.f;
+      ss = 0.0;
+    }
     for (int e = lane * 4; e < d; e += 256) {
       float4 v = *(const float4*)(x + e);
       if (centre) {
         const float4 c = *(const float4*)(centre + e);
         v.x -= c.x; v.y -= c.y; v.z -= c.z; v.w -= c.w;
       }
-      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-      const bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
-      uint2 o;
-      o.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
-      o.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
-      *(uint2*)(Y + row * d + e) = o;
-      if (Ylo) {
-        uint2 l;
-        l.x = pack_bf16x2(v.x - bf16_to_f32(h0), v.y - bf16_to_f32(h1));
-        l.y = pack_bf16x2(v.z - bf16_to_f32(h2), v.w - bf16_to_f32(h3));
-        *(uint2*)(Ylo + row * d + e) = l;
+      if constexpr (PER_ROW_SCALE) { v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+      ss += sq4(v);
+      if (Y) {
+        if constexpr (!PER_ROW_SCALE && KIND == IP_KIND_F16) { v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+        uint2 o;
+        o.x = pack_half2<KIND>(v.x, v.y);
+        o.y = pack_half2<KIND>(v.z, v.w);
+        *(uint2*)(Y + row * d + e) = o;
+        if (Ylo) {
+          uint2 l;
+          l.x = pack_half2<KIND>(v.x - half_lo_to_f32<KIND>(o.x), v.y - half_hi_to_f32<KIND>(o.x));
+          l.y = pack_half2<KIND>(v.z - half_lo_to_f32<KIND>(o.y), v.w - half_hi_to_f32<KIND>(o.y));
+          *(uint2*)(Ylo + row * d + e) = l;
+        }
       }
     }
-    ss = wave_sum(ss);
-    const float nm = sqrtf(ss);
+    ss = wave_sum_f64(ss);
+    const float nm = (float)(sqrt(ss) * (1.0 + 1e-6));   // (rounded up: a bound)
     if (row_norm && lane == 0) row_norm[row] = nm;
     wmax = fmaxf(wmax, nm);
   }
@@ -245,7 +310,7 @@ __device__ __forceinline__ void scan_epilogue(const ScanArgs& a, GemmAcc<T>& acc
 // tile order, query tile fastest); the first K chunk of the next tile streams into the idle operand stage while the
 // epilogue of this one runs, so neither the workgroup dispatch gap nor the cold HBM round trip for a fresh passage
 // tile is exposed (they were ~40 % of a 12-step tile).
-template <int MODE, class T, bool X3>
+template <int MODE, class T, bool X3, bool F16>
 __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan(const ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t ntiles = (uint32_t)a.nPt * (uint32_t)a.nQt;
@@ -287,14 +352,14 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan(const ScanArgs a) {
     float tau_lane[T::NT];
 #pragma unroll
     for (int nt = 0; nt < T::NT; ++nt) tau_lane[nt] = tau_next[nt];
-    int idle = gemm_nt_mainloop<T>(src, a.d, smem, acc, w, buf, true);
+    int idle = gemm_nt_mainloop<T, F16>(src, a.d, smem, acc, w, buf, true);
     if constexpr (X3) {  // S~ = Ph Qh + Ph Ql + Pl Qh: fp32-class scores from three bf16 passes into the same accumulators
       __syncthreads();
       const TileSrc<T> s2(a.P, a.d, a.n, a.Qlo, a.d, a.nq_pad, m0, n0, w);
-      idle = gemm_nt_mainloop<T>(s2, a.d, smem, acc, w, idle);
+      idle = gemm_nt_mainloop<T, F16>(s2, a.d, smem, acc, w, idle);
       __syncthreads();
       const TileSrc<T> s3(a.Plo, a.d, a.n, a.Qb, a.d, a.nq_pad, m0, n0, w);
-      idle = gemm_nt_mainloop<T>(s3, a.d, smem, acc, w, idle);
+      idle = gemm_nt_mainloop<T, F16>(s3, a.d, smem, acc, w, idle);
     }
 #pragma unroll
     for (int nt = 0; nt < T::NT; ++nt) asm volatile("" : "+v"(tau_lane[nt]));   // hipcc: the loads are retired HERE
@@ -430,7 +495,7 @@ __device__ __forceinline__ void scan_emit_flush(const ScanArgs& a, const WavePos
 // The emitting scan of 256 x 256 tiles on the 3 R-slot / 2 L-slot main loop (gemm_nt_mainloop_r3); same persistent walk,
 // next-tile prologue under the epilogue and one-tile-ahead thresholds as k_ip_scan.  (The split-bf16 scan and the
 // sampling modes stay on the two-stage loop.)
-template <class T>
+template <class T, bool F16>
 __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan_r3(const ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t ntiles = (uint32_t)a.nPt * (uint32_t)a.nQt;
@@ -471,7 +536,7 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan_r3(const ScanArgs a) 
     float tau_lane[T::NT];
 #pragma unroll
     for (int nt = 0; nt < T::NT; ++nt) tau_lane[nt] = tau_next[nt];
-    slots = gemm_nt_mainloop_r3<T>(src, a.d, smem, acc, w, slots, true);
+    slots = gemm_nt_mainloop_r3<T, F16>(src, a.d, smem, acc, w, slots, true);
 #pragma unroll
     for (int nt = 0; nt < T::NT; ++nt) asm volatile("" : "+v"(tau_lane[nt]));
     int tid_e = threadIdx.x;
@@ -614,7 +679,8 @@ __global__ void __launch_bounds__(1024) k_ip_cut(int64_t n, int k, int cap, cons
                                                 uint32_t* __restrict__ counts_packed,
                                                 uint32_t* __restrict__ cand_id, float* __restrict__ cand_s,
                                                 const float* __restrict__ tau, const float* __restrict__ qnorm,
-                                                const float* __restrict__ p_max_norm, float eps_coef,
+                                                const float* __restrict__ p_max_norm, float eps_coef, float eps_abs,
+                                                float p_scale, float norm_limit,
                                                 uint32_t* __restrict__ m_out, int32_t* __restrict__ status,
                                                 float* __restrict__ tau_retry) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -634,7 +700,9 @@ __global__ void __launch_bounds__(1024) k_ip_cut(int64_t n, int k, int cap, cons
   __syncthreads();
   const int need = (int64_t)k < n ? k : (int)n;
   const float t = tau[q];
-  const float eps = eps_coef * qnorm[q] * p_max_norm[0] * 1.001f + 1e-30f;
+  // (scaled units for the fp16 scan: qnorm is the scaled query norm, pm the scaled largest passage norm)
+  const float pm = p_max_norm[0] * p_scale;
+  const float eps = (eps_coef * qnorm[q] * pm + eps_abs * (qnorm[q] + pm) + eps_abs * eps_abs) * 1.001f + 1e-30f;
   const bool have_k = need > 0 && c >= need;
   float cut = -INFINITY;
   if (have_k)
@@ -664,6 +732,10 @@ __global__ void __launch_bounds__(1024) k_ip_cut(int64_t n, int k, int cap, cons
     } else if (need > 0 && t > -INFINITY && cut < t) {
       st = CONVDR_IP_UNCERTAIN;  // band reaches below tau: list incomplete in [cut, tau)
       retry = nextafterf(cut, -INFINITY);
+    }
+    if (pm > norm_limit) {   // fp16 scan copy built with a scale too large for this block's norms: elements may be inf
+      st = CONVDR_IP_RANGE;
+      retry = -INFINITY;
     }
     m_out[q] = sh_m;
     status[q] = st;
@@ -822,11 +894,11 @@ static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
   return p;
 }
 
-template <int MODE, class T, bool X3>
+template <int MODE, class T, bool X3, bool F16>
 static int launch_scan_x(const ScanArgs& a, hipStream_t st) {
   static DeviceOnce attr_done;  // > 48 KB dynamic LDS needs the opt-in once per kernel and device
   if (attr_done.first())
-    CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_scan<MODE, T, X3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_scan<MODE, T, X3, F16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          T::SMEM_BYTES));
   const unsigned tiles = (unsigned)a.nPt * (unsigned)a.nQt;
   static const bool r3 = getenv("CONVDR_DBG_SCAN_NO_R3") == nullptr;   // A/B switch: the two-stage loop
@@ -835,13 +907,13 @@ static int launch_scan_x(const ScanArgs& a, hipStream_t st) {
       constexpr int R3_SMEM = 3 * T::R_BYTES + 2 * T::L_BYTES;
       static DeviceOnce attr3;
       if (attr3.first())
-        CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_scan_r3<T>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_SMEM));
+        CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_scan_r3<T, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_SMEM));
       ScanArgs b = a;
 #ifdef CONVDR_ENABLE_TRACE   // timing only (every threshold = +inf: results are garbage): `make TRACE=1` library only
       if (getenv("CONVDR_DBG_SCAN_NOEMIT")) b.nq = 0;
 #endif
       ProfScope prof("ip_scan_emit", st);
-      hipLaunchKernelGGL((k_ip_scan_r3<T>), dim3(std::min(tiles, (unsigned)device_cu_count())), dim3(T::THREADS), R3_SMEM, st, b);
+      hipLaunchKernelGGL((k_ip_scan_r3<T, F16>), dim3(std::min(tiles, (unsigned)device_cu_count())), dim3(T::THREADS), R3_SMEM, st, b);
       CONVDR_CHECK_LAUNCH("k_ip_scan_r3");
       return 0;
     }
@@ -855,19 +927,20 @@ static int launch_scan_x(const ScanArgs& a, hipStream_t st) {
   static const bool no_emit = getenv("CONVDR_DBG_SCAN_NOEMIT") != nullptr;   // timing only: every threshold = +inf
   if (no_emit) b.nq = 0;
 #endif
-  hipLaunchKernelGGL((k_ip_scan<MODE, T, X3>), dim3(grid), dim3(T::THREADS), T::SMEM_BYTES, st, b);
+  hipLaunchKernelGGL((k_ip_scan<MODE, T, X3, F16>), dim3(grid), dim3(T::THREADS), T::SMEM_BYTES, st, b);
   CONVDR_CHECK_LAUNCH("k_ip_scan");
   return 0;
 }
 
-template <int MODE, class T>
+template <int MODE, class T, bool F16>
 static int launch_scan_t(const ScanArgs& a, hipStream_t st) {
-  return a.Plo ? launch_scan_x<MODE, T, true>(a, st) : launch_scan_x<MODE, T, false>(a, st);
+  return a.Plo ? launch_scan_x<MODE, T, true, F16>(a, st) : launch_scan_x<MODE, T, false, F16>(a, st);
 }
 
 template <int MODE>
-static int launch_scan(const ScanArgs& a, bool big, hipStream_t st) {
-  return big ? launch_scan_t<MODE, Tile256>(a, st) : launch_scan_t<MODE, Tile128>(a, st);
+static int launch_scan(const ScanArgs& a, bool big, int kind, hipStream_t st) {
+  if (kind == IP_KIND_F16) return big ? launch_scan_t<MODE, Tile256, true>(a, st) : launch_scan_t<MODE, Tile128, true>(a, st);
+  return big ? launch_scan_t<MODE, Tile256, false>(a, st) : launch_scan_t<MODE, Tile128, false>(a, st);
 }
 
 }  // namespace convdr
@@ -934,17 +1007,46 @@ extern "C" int convdr_ip_column_mean(const float* p_f32, int64_t n, int d, float
   return 0;
 }
 
-extern "C" int convdr_ip_prepare_block(const float* p_f32, int64_t n, int d, const float* centre, void* p_bf16,
-                                       void* p_bf16_lo, float* max_norm, convdr_stream_t stream) {
+static int ip_prepare_block(int kind, const float* p_f32, int64_t n, int d, const float* centre, float scale, void* p_half,
+                            void* p_half_lo, float* max_norm, hipStream_t st) {
   CONVDR_REQUIRE(n >= 0 && d > 0 && d % 64 == 0, "convdr_ip_prepare_block: need d %% 64 == 0 (got n=%lld d=%d)",
                  (long long)n, d);
   if (n == 0) return 0;
   const int64_t blocks = ceil_div64(n, 4);
   const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
-  hipLaunchKernelGGL(k_rows_to_bf16, dim3(grid), dim3(256), 0, (hipStream_t)stream, p_f32, n, d, centre, (bf16_t*)p_bf16,
-                     (bf16_t*)p_bf16_lo, (float*)nullptr, max_norm);
-  CONVDR_CHECK_LAUNCH("k_rows_to_bf16");
+  if (kind == IP_KIND_F16) {
+    int ex = 0;
+    CONVDR_REQUIRE(scale > 0.f && frexpf(scale, &ex) == 0.5f, "convdr_ip_prepare_block_f16: scale must be a power of two (got %g)",
+                   (double)scale);
+    hipLaunchKernelGGL((k_rows_to_half<IP_KIND_F16, false>), dim3(grid), dim3(256), 0, st, p_f32, n, d, centre, scale,
+                       (bf16_t*)p_half, (bf16_t*)p_half_lo, (float*)nullptr, max_norm);
+  } else {
+    hipLaunchKernelGGL((k_rows_to_half<IP_KIND_BF16, false>), dim3(grid), dim3(256), 0, st, p_f32, n, d, centre, 1.f,
+                       (bf16_t*)p_half, (bf16_t*)p_half_lo, (float*)nullptr, max_norm);
+  }
+  CONVDR_CHECK_LAUNCH("k_rows_to_half");
   return 0;
+}
+
+extern "C" int convdr_ip_prepare_block(const float* p_f32, int64_t n, int d, const float* centre, void* p_bf16,
+                                       void* p_bf16_lo, float* max_norm, convdr_stream_t stream) {
+  return ip_prepare_block(IP_KIND_BF16, p_f32, n, d, centre, 1.f, p_bf16, p_bf16_lo, max_norm, (hipStream_t)stream);
+}
+
+extern "C" int convdr_ip_prepare_block_f16(const float* p_f32, int64_t n, int d, const float* centre, float scale, void* p_f16,
+                                           void* p_f16_lo, float* max_norm, convdr_stream_t stream) {
+  return ip_prepare_block(IP_KIND_F16, p_f32, n, d, centre, scale, p_f16, p_f16_lo, max_norm, (hipStream_t)stream);
+}
+
+extern "C" float convdr_ip_f16_scale(float max_norm) {
+  // power of two that puts max_norm into [2^12, 2^13): elements stay below 2^13 (fp16 max 65504 leaves a factor 7 for
+  // blocks added later), typical elements (norm / sqrt(d)) far above the 2^-14 end of the normal range
+  if (!(max_norm > 0.f) || max_norm == INFINITY) return 1.f;
+  int ex = 0;
+  (void)frexpf(max_norm, &ex);
+  int sh = (int)IP_F16_TARGET_EXP + 1 - ex;
+  sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+  return ldexpf(1.f, sh);
 }
 
 extern "C" size_t convdr_ip_workspace_bytes(int nq, int64_t n, int d, int k, int cap) {
@@ -960,12 +1062,10 @@ extern "C" const uint32_t* convdr_ip_debug_band(const void* workspace, int nq, i
   return (const uint32_t*)((const char*)workspace + ip_plan(nq, n, d, k, cap).o_m);
 }
 
-extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, const void* p_bf16, const void* p_bf16_lo,
-                                int64_t n, int d,
-                                int k, const float* p_max_norm, const float* tau_in, int cap, int rank_target,
-                                void* workspace, size_t workspace_bytes, float* D, int64_t* I, int32_t* status,
-                                float* tau_retry, convdr_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
+static int ip_search(int kind, float p_scale, const float* q_f32, int nq, const float* p_f32, const void* p_bf16,
+                     const void* p_bf16_lo, int64_t n, int d, int k, const float* p_max_norm, const float* tau_in, int cap,
+                     int rank_target, void* workspace, size_t workspace_bytes, float* D, int64_t* I, int32_t* status,
+                     float* tau_retry, hipStream_t st) {
   CONVDR_REQUIRE(nq > 0 && k > 0 && n >= 0, "convdr_ip_search: bad sizes nq=%d k=%d n=%lld", nq, k, (long long)n);
   CONVDR_REQUIRE(d > 0 && d % 64 == 0 && d <= 4096, "convdr_ip_search: need d %% 64 == 0 and d <= 4096 (got %d)", d);
   CONVDR_REQUIRE(n < ((int64_t)1 << 31), "convdr_ip_search: block too large (n=%lld >= 2^31)", (long long)n);
@@ -991,9 +1091,13 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
   CONVDR_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)p.nq_pad * IP_COUNT_STRIDE * 4, st));
   bf16_t* qlo = p_bf16_lo ? (bf16_t*)(ws + p.o_qlo) : nullptr;
   if (qlo) CONVDR_CHECK_HIP(hipMemsetAsync(qlo, 0, (size_t)p.nq_pad * d * 2, st));
-  hipLaunchKernelGGL(k_rows_to_bf16, dim3((nq + 3) / 4), dim3(256), 0, st, q_f32, (int64_t)nq, d, (const float*)nullptr, qb,
-                     qlo, qnorm, (float*)nullptr);
-  CONVDR_CHECK_LAUNCH("k_rows_to_bf16(Q)");
+  if (kind == IP_KIND_F16)
+    hipLaunchKernelGGL((k_rows_to_half<IP_KIND_F16, true>), dim3((nq + 3) / 4), dim3(256), 0, st, q_f32, (int64_t)nq, d,
+                       (const float*)nullptr, 1.f, qb, qlo, qnorm, (float*)nullptr);
+  else
+    hipLaunchKernelGGL((k_rows_to_half<IP_KIND_BF16, false>), dim3((nq + 3) / 4), dim3(256), 0, st, q_f32, (int64_t)nq, d,
+                       (const float*)nullptr, 1.f, qb, qlo, qnorm, (float*)nullptr);
+  CONVDR_CHECK_LAUNCH("k_rows_to_half(Q)");
 
   if (n == 0) {
     hipLaunchKernelGGL(k_fill_f32, dim3((p.nq_pad + 255) / 256), dim3(256), 0, st, tau, p.nq_pad, -INFINITY);
@@ -1014,7 +1118,7 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
       a.nPt = p.nSt; a.pt_stride = p.stride;
       if (p.mode == IP_MODE_FULL) {
         r = (int64_t)R < n ? R : (int)n;
-        if (int e = launch_scan<IP_MODE_FULL>(a, p.big, st)) return e;
+        if (int e = launch_scan<IP_MODE_FULL>(a, p.big, kind, st)) return e;
       } else {
         // The sample keeps the two best scores of every 64 sampled passages, so it can only represent a rank whose expected
         // hits per 64 passages stay well below 2: R <= n / 128 (half a hit per 64).  Blocks of 32 k .. 200 k passages
@@ -1026,7 +1130,7 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
         r = (int)lrint(R * frac);
         if (r < 8) r = 8;
         if (r > p.nvals / 4) r = (int)(p.nvals / 4);
-        if (int e = launch_scan<IP_MODE_TOP2>(a, p.big, st)) return e;
+        if (int e = launch_scan<IP_MODE_TOP2>(a, p.big, kind, st)) return e;
       }
       static DeviceOnce attr_done;
       if (attr_done.first())
@@ -1036,7 +1140,7 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
       CONVDR_CHECK_LAUNCH("k_tau_select");
     }
     a.nPt = p.nPt; a.pt_stride = 1;
-    if (int e = launch_scan<IP_MODE_EMIT>(a, p.big, st)) return e;
+    if (int e = launch_scan<IP_MODE_EMIT>(a, p.big, kind, st)) return e;
   }
   static DeviceOnce attr_done2;
   if (attr_done2.first()) {
@@ -1048,7 +1152,9 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
   ProfScope prof("ip_cut", st);
   hipLaunchKernelGGL(k_ip_cut, dim3(nq), dim3(1024), (size_t)cap * 8, st, n, k, cap, counts,
                      (uint32_t*)(ws + p.o_counts_packed), cand_id, cand_s, tau, qnorm,
-                     p_max_norm, ip_eps_coef(d, p_bf16_lo != nullptr), band, status, tau_retry);
+                     p_max_norm, ip_eps_coef(d, p_bf16_lo != nullptr, kind), ip_eps_abs(d, p_bf16_lo != nullptr, kind),
+                     kind == IP_KIND_F16 ? p_scale : 1.f, kind == IP_KIND_F16 ? IP_F16_NORM_LIMIT : INFINITY, band, status,
+                     tau_retry);
   CONVDR_CHECK_LAUNCH("k_ip_cut");
   }
   if (n > 0) {
@@ -1060,4 +1166,23 @@ extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, 
   hipLaunchKernelGGL(k_ip_select, dim3(nq), dim3(IP_SELECT_THREADS), (size_t)cap * 12, st, k, cap, band, cand_id, cand_x, D, I);
   CONVDR_CHECK_LAUNCH("k_ip_select");
   return 0;
+}
+
+extern "C" int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, const void* p_bf16, const void* p_bf16_lo,
+                                int64_t n, int d, int k, const float* p_max_norm, const float* tau_in, int cap,
+                                int rank_target, void* workspace, size_t workspace_bytes, float* D, int64_t* I,
+                                int32_t* status, float* tau_retry, convdr_stream_t stream) {
+  return ip_search(IP_KIND_BF16, 1.f, q_f32, nq, p_f32, p_bf16, p_bf16_lo, n, d, k, p_max_norm, tau_in, cap, rank_target,
+                   workspace, workspace_bytes, D, I, status, tau_retry, (hipStream_t)stream);
+}
+
+extern "C" int convdr_ip_search_f16(const float* q_f32, int nq, const float* p_f32, const void* p_f16, const void* p_f16_lo,
+                                    float p_scale, int64_t n, int d, int k, const float* p_max_norm, const float* tau_in,
+                                    int cap, int rank_target, void* workspace, size_t workspace_bytes, float* D,
+                                    int64_t* I, int32_t* status, float* tau_retry, convdr_stream_t stream) {
+  int ex = 0;
+  CONVDR_REQUIRE(p_scale > 0.f && frexpf(p_scale, &ex) == 0.5f, "convdr_ip_search_f16: p_scale must be a power of two (got %g)",
+                 (double)p_scale);
+  return ip_search(IP_KIND_F16, p_scale, q_f32, nq, p_f32, p_f16, p_f16_lo, n, d, k, p_max_norm, tau_in, cap, rank_target,
+                   workspace, workspace_bytes, D, I, status, tau_retry, (hipStream_t)stream);
 }

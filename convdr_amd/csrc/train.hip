@@ -26,6 +26,7 @@ struct LayerBwd {
 };
 
 struct TrainBufs {
+  int32_t* status;
   int32_t *tok_id, *tok_pos;
   LayerSave* L;  // host array (inside the plan object)
   LayerBwd* G;   // host array
@@ -61,6 +62,7 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
   const int64_t rs = rows + 128;
   p.Tp = (int64_t)align_up((size_t)rows, 64);
   p.ldt = p.Tp + 64;
+  p.status = (int32_t*)take(256);   // workspace offset 0, as in the inference plan
   p.tok_id = (int32_t*)take(rs * 4);
   p.tok_pos = (int32_t*)take(rs * 4);
   for (int l = 0; l < c->layers; ++l) {
@@ -345,8 +347,9 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
   CONVDR_REQUIRE(workspace_bytes >= p.total, "convdr_encoder_train_forward: workspace too small (%zu < %zu)",
                  workspace_bytes, p.total);
   const int H = cfg->hidden, I = cfg->intermediate;
+  CONVDR_CHECK_HIP(hipMemsetAsync(p.status, 0, 256, st));
   hipLaunchKernelGGL(k_seq_pack, dim3((B + 3) / 4), dim3(256), 0, st, input_ids, ids_are_int32, attention_mask, seq_lens, B, L,
-                     cu_seqlens, cfg->kind, cfg->pad_idx, cfg->max_pos, p.tok_id, p.tok_pos);
+                     cu_seqlens, cfg->kind, cfg->pad_idx, cfg->max_pos, cfg->vocab, p.tok_id, p.tok_pos, p.status);
   CONVDR_CHECK_LAUNCH("k_seq_pack");
   hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.tok_id, p.tok_pos, rows, H,
                      w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, cfg->ln_eps, P.layers[0].Xin,

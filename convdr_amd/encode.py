@@ -87,6 +87,8 @@ def encode_shard(model, cache, rank=0, world=1, batch_size=1024, is_query_infere
             progress(n)
     if on_gpu:
         torch.cuda.synchronize(dev)
+        from .train import check_status
+        check_status(model)  # token ids outside the embedding table: IndexError like the reference's lookup (models.py:141)
     if out is None:
         return np.zeros((0, 768), np.float32), idx
     return out.numpy(), idx

@@ -38,20 +38,22 @@ def evaluate(args, eval_dataset, model, logger=None):
     set_seed(args)  # the reference re-seeds here (:132-133)
     embedding, embedding2id, raw_sequences = [], [], []
     model.eval()
+    import inspect
+    fwd = (model.module if hasattr(model, "module") else model).forward
+    takes_lens = "seq_lens" in inspect.signature(fwd).parameters      # (BiEncoder.forward has no such extension)
     for batch in eval_dataloader:
         qids = batch["qid"]
         ids, id_mask = (ele.to(args.device, non_blocking=True) for ele in [batch["concat_ids"], batch["concat_id_mask"]])
         with torch.no_grad():
             # the collate function right-pads (utils/util.py:163-185): the host knows the lengths, no device round trip
             lens = batch["concat_id_mask"].sum(1).numpy().astype(np.int32)
-            try:
-                embs = model(ids, id_mask, seq_lens=lens)
-            except TypeError:          # a model class without the seq_lens extension (BiEncoder)
-                embs = model(ids, id_mask)
+            embs = model(ids, id_mask, seq_lens=lens) if takes_lens else model(ids, id_mask)
         embedding.append(embs.detach())
         embedding2id.extend(qids)
         raw_sequences.extend(batch["history_utterances"])
     if not embedding:
         return np.zeros((0, 768), np.float32), embedding2id, raw_sequences
     embedding = torch.cat(embedding, 0).cpu().numpy()
+    from .train import check_status
+    check_status(model)      # token ids outside the embedding table: IndexError like the reference's lookup (models.py:141)
     return embedding, embedding2id, raw_sequences

@@ -164,11 +164,25 @@ class EncoderTower(nn.Module):
 
     # ---- packed weights ---------------------------------------------------------------------
     def _version_key(self, extra):
-        # (walking the module tree costs 0.2 ms per call at 200 parameters; the list is rebuilt only when a parameter
-        # object has been replaced, e.g. by resize_token_embeddings)
-        ps = self.__dict__.get("_plist")
-        if ps is None or self.embeddings.word_embeddings.weight is not ps[0]:
-            ps = self.__dict__["_plist"] = list(self.parameters())
+        # (walking the module tree costs 0.2 ms per call at 200 parameters; the flat list is kept and re-validated against
+        # the modules' own `_parameters` dicts -- an identity check per entry, no generator machinery -- so replacing ANY
+        # Parameter object (resize_token_embeddings, `layer.dense.weight = nn.Parameter(...)`, pruning / LoRA-style
+        # re-parametrisation) rebuilds it: ADVICE r2)
+        cache = self.__dict__.get("_plist")
+        if cache is not None:
+            ps, owners = cache
+            if not all(d.get(k) is p for p, (d, k) in zip(ps, owners)) or sum(len(m._parameters) for m in self.__dict__["_pmods"]) != len(ps):
+                cache = None
+        if cache is None:
+            ps, owners, mods = [], [], []
+            for mod in self.modules():
+                mods.append(mod)
+                for k, p in mod._parameters.items():
+                    if p is not None:
+                        ps.append(p)
+                        owners.append((mod._parameters, k))
+            self.__dict__["_plist"] = (ps, owners)
+            self.__dict__["_pmods"] = mods
         return tuple((p.data_ptr(), p._version) for p in ps) + tuple((p.data_ptr(), p._version) for p in extra)
 
     def invalidate_packed(self):
@@ -332,7 +346,8 @@ class EncoderTower(nn.Module):
             raise ValueError("attention_mask=None needs seq_lens")
         B, L = ids.shape
         dev = ids.device
-        from ..train import _lens_and_check, _pinned_upload
+        from ..train import _lens_and_check, _pinned_upload, _status_poll, _status_post
+        _status_poll(self)          # (a batch flagged by an earlier forward raises here at the latest)
         # one small D2H round trip per batch unless the caller knows the lengths; it also validates the token ids
         seq_lens, lens_host = _lens_and_check(ids, mask, self.embeddings.word_embeddings.num_embeddings, seq_lens)
         if lens_host.min() < 1:
@@ -353,6 +368,7 @@ class EncoderTower(nn.Module):
                                                  _lib.ptr(cu), _lib.ptr(seq_lens), rows, max_len, _lib.ptr(self._ws),
                                                  self._ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
                        "convdr_encoder_forward")
+            _status_post(self, self._ws)
         return out
 
 

@@ -78,12 +78,22 @@ def search_sharded(index, queries, k, embid, group=None):
     return Dm.cpu().numpy(), Im.cpu().numpy()
 
 
-def search_sharded_device(index, queries, k, embid, group=None, force=False):
-    """search_sharded without the host round trip: `queries` and `embid` are tensors on the index's device, the
-    per-rank (scores, record offsets) are exchanged with two all-gathers ([W, nq, k] fp32 + int64: 9.6 MB at W = 8,
+def search_sharded_device(index, queries, k, embid, group=None, force=False, certify=True):
+    """search_sharded without the host round trip of the results: `queries` and `embid` are tensors on the index's device,
+    the per-rank (scores, record offsets) are exchanged with ONE all-gather ([W, nq, k] fp32 + int64: 9.6 MB at W = 8,
     k = 100, nq = 1000) and merged on the device.  Returns device tensors (D [nq, k] fp32, offsets [nq, k] int64,
-    status [nq] int32 of the LOCAL search -- non-zero entries are the queries FlatIPIndex.search would re-run)."""
-    D, I, status = index.search_device(queries, k)[:3]
+    status [nq] int32).
+
+    The reference's sharded search is exact on every shard (faiss IndexFlatIP per GPU, run_convdr_inference.py:180-182,
+    356-367), so the LOCAL lists that enter the exchange are the certified ones: `index.search_tensors` runs the whole
+    precision ladder (retries, split scan, exhaustive rung) for the queries the first pass cannot certify -- each rank
+    for its own block, before any collective, so ranks may take different numbers of rounds -- and `status` is all zero.
+    certify=False (instrumentation only) exchanges the first pass as it is and returns its status."""
+    if certify and hasattr(index, "search_tensors"):
+        D, I = index.search_tensors(queries, k)
+        status = torch.zeros(D.shape[0], dtype=torch.int32, device=D.device)
+    else:
+        D, I, status = index.search_device(queries, k)[:3]
     ids = torch.where(I >= 0, embid[I.clamp(min=0)], torch.full_like(I, -1))
     W = _world()
     if W == 1 and not (force and dist.is_initialized()):
@@ -104,6 +114,46 @@ def search_sharded_device(index, queries, k, embid, group=None, force=False):
     I_all = out[..., 1:].contiguous().view(torch.int64).view(W, nq, k)
     Dm, Im = merge_rank_topk(D_all, I_all, k)
     return Dm, Im, status
+
+
+def train_sampler(dataset, shuffle=True, seed=0, drop_last=False, rank=None, world=None):
+    """The sampler of a one-process-per-GPU training run.  The reference draws ONE RandomSampler batch per step and lets
+    nn.DataParallel scatter it over the visible GPUs (run_convdr_train.py:51-57,77-78); with a process per GPU each rank
+    draws its own disjoint 1 / W of every epoch's permutation instead (torch's DistributedSampler: rank r takes
+    indices r, r + W, ... of the permutation seeded with seed + epoch -- call ``sampler.set_epoch(epoch)`` at the top of
+    every epoch, where the reference's RandomSampler simply reshuffles).  World size 1: the reference's samplers.
+    The per-rank batch size is ``args.per_gpu_train_batch_size``; global batch = W x that (configs[4]: 8 x 64)."""
+    from torch.utils.data import RandomSampler, SequentialSampler
+    from torch.utils.data.distributed import DistributedSampler
+    W = _world() if world is None else int(world)
+    if W == 1:
+        return RandomSampler(dataset) if shuffle else SequentialSampler(dataset)
+    r = dist.get_rank() if rank is None else int(rank)
+    return DistributedSampler(dataset, num_replicas=W, rank=r, shuffle=shuffle, seed=seed, drop_last=drop_last)
+
+
+def shard_batch(batch, rank=None, world=None):
+    """This rank's contiguous slice of a GLOBAL batch (a tuple / list / dict of tensors or arrays whose first dimension is
+    the batch): what nn.DataParallel's scatter hands replica `rank` (run_convdr_train.py:77-78).  For drivers that keep
+    the reference's single global batch (e.g. to replay one of its runs); a DistributedSampler run never needs it.
+    The batch size must be divisible by the world size (DataParallel gives the last replica a short chunk; the step's
+    mean-over-ranks loss is only the global mean for equal chunks)."""
+    W = _world() if world is None else int(world)
+    r = (dist.get_rank() if W > 1 else 0) if rank is None else int(rank)
+    if W == 1:
+        return batch
+
+    def cut(x):
+        import numpy as np
+        if not isinstance(x, (torch.Tensor, np.ndarray, list, tuple)):      # scalars, None, strings, nested dicts: replicated
+            return x
+        n = len(x)
+        if n % W:
+            raise ValueError("shard_batch: batch of %d does not divide over %d ranks" % (n, W))
+        return x[r * (n // W):(r + 1) * (n // W)]
+    if isinstance(batch, dict):
+        return {k: cut(v) for k, v in batch.items()}
+    return type(batch)(cut(x) for x in batch)
 
 
 class DataParallelStudent:

@@ -22,25 +22,32 @@ def _torch():
     return torch
 
 
-STATUS_OK, STATUS_OVERFLOW, STATUS_TOO_FEW, STATUS_UNCERTAIN = 0, 1, 2, 3
+STATUS_OK, STATUS_OVERFLOW, STATUS_TOO_FEW, STATUS_UNCERTAIN, STATUS_RANGE = 0, 1, 2, 3, 4
+
+_KINDS = {"auto": "f16", "fp16": "f16", "fp16x3": "f16", "bf16": "bf16", "bf16x3": "bf16"}
 
 
 class FlatIPIndex:
-    """Exact inner-product index resident in HBM.  ``add`` keeps the fp32 block and builds its bf16 scan copy;
+    """Exact inner-product index resident in HBM.  ``add`` keeps the fp32 block and builds its 16-bit scan copy;
     ``search`` returns FAISS-shaped ``(D float32 [nq,k], I int64 [nq,k])`` and is certified exact
     (see include/convdr_hip.h).
 
-    precision: "auto" (default) scans in bf16 and re-runs the queries that cannot be certified with the
-    split-bf16 scan (three MFMA passes, ~10x tighter error band); "bf16" / "bf16x3" pin one rung.
-    center: subtract the column mean of the first added block from every passage before rounding to bf16
-    (ranking-neutral, shrinks the error band by |p| / |p - mean|; essential for real encoder outputs,
-    which share a large common component)."""
+    precision: "auto" (default) scans in fp16 (v_mfma_f32_32x32x16_f16: the bf16 rate, 8x tighter error band) and
+    re-runs the queries that cannot be certified with the split-fp16 scan (three MFMA passes, another 4x); "fp16" /
+    "fp16x3" / "bf16" / "bf16x3" pin one rung (the bf16 pair is the round-1/2 ladder: same engine, u = 2^-8).  Whatever
+    the rung, a query it cannot certify ends on the exhaustive rung, so the result never depends on the choice.
+    center: subtract the column mean of the first added block from every passage before rounding (ranking-neutral,
+    shrinks the error band by |p| / |p - mean|; essential for real encoder outputs, which share a large common
+    component).
+    reserve(n): allocate the resident block for n passages up front; add() then fills it in place.  Without it every
+    add() after the first re-allocates (FAISS semantics need one contiguous block): fine for the reference's one add per
+    reset, not for building a 117 GB corpus from slices."""
 
     def __init__(self, d, device=None, cap=4096, rank_target=0, precision="auto", center=True):
         import torch
         if not torch.cuda.is_available():
             raise _lib.ConvdrError("FlatIPIndex needs a GPU (no CPU fallback)")
-        assert precision in ("auto", "bf16", "bf16x3")
+        assert precision in _KINDS, precision
         _lib.lib()
         # the scan contracts in 64-wide K steps: other widths get zero columns, which add exact zeros to every score
         self.d_in = int(d)
@@ -48,45 +55,123 @@ class FlatIPIndex:
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.cap, self.rank_target = int(cap), int(rank_target)
         self.precision, self.center = precision, bool(center)
+        self.kind = _KINDS[precision]
+        self._half_dtype = torch.float16 if self.kind == "f16" else torch.bfloat16
         self.host_chunk_bytes = 64 << 20       # staging-buffer size of the streamed host -> HBM path (add); 64 MB x 16
                                                # threads measured best on the bench host (tools/dbg/block_load_sweep.py)
         self.host_copy_threads = 16            # file reads / memcpy slices in flight while filling a staging buffer
+        self.host_stage_buffers = 3            # pinned staging buffers in flight (copy stream never waits for the host)
         self.stats = {}
+        self._s32 = self._s16 = self._slo = None
         self.reset()
 
     # -- faiss-like surface ---------------------------------------------------
     @property
     def ntotal(self):
-        return 0 if self._p32 is None else int(self._p32.shape[0])
+        return self._n
+
+    # the resident block (views of the used rows of the backing storage)
+    @property
+    def _p32(self):
+        return None if self._s32 is None else self._s32[:self._n]
+
+    @property
+    def _pbf(self):
+        return None if self._s16 is None else self._s16[:self._n]
+
+    @property
+    def _plo(self):
+        return None if self._slo is None else self._slo[:self._n]
 
     def reset(self):
+        """faiss ``index.reset()``: forget the passages.  A reservation made with reserve() survives (its memory is reused
+        by the next block); ``release()`` drops it."""
         import torch
-        self._p32 = None
-        self._pbf = None
-        self._plo = None
+        self._n = 0
+        if not getattr(self, "_reserved", False):
+            self._s32 = self._s16 = self._slo = None
         self._centre = None
+        self._scale = 1.0                       # power of two applied to the fp16 scan copy (1 for bf16)
         self._max_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._ws = None
         self._x3_first = False
         if not hasattr(self, "_copy_stream"):
             self._copy_stream, self._stage = None, None
 
-    def _prepare(self, t, want_lo):
+    def release(self):
+        self._reserved = False
+        self.reset()
+
+    def reserve(self, n, lo=None):
+        """Backing storage for n passages (fp32 block + 16-bit scan copy, + the remainder copy of the split scan when
+        `lo`, default: only if the precision pins it).  Existing rows are kept."""
         import torch
+        n = int(n)
+        want_lo = (self.precision in ("bf16x3", "fp16x3")) if lo is None else bool(lo)
+        if self._s32 is not None and self._s32.shape[0] >= n and (self._slo is not None or not want_lo):
+            self._reserved = True
+            return
+        with torch.cuda.device(self.device):
+            def grow(old, dtype):
+                t = torch.empty((n, self.d), dtype=dtype, device=self.device)
+                if old is not None and self._n:
+                    t[:self._n].copy_(old[:self._n])
+                return t
+            self._s32 = grow(self._s32, torch.float32)
+            self._s16 = grow(self._s16, self._half_dtype)
+            if want_lo or self._slo is not None:
+                self._slo = grow(self._slo, self._half_dtype)
+        self._reserved = True
+
+    def _prepare_into(self, src32, dst16, dstlo):
+        """scan copy (and remainder copy) of the fp32 rows `src32`; folds their norms into the block's max norm"""
         L = _lib.lib()
-        pbf = torch.empty(t.shape, dtype=torch.bfloat16, device=self.device)
-        plo = torch.empty(t.shape, dtype=torch.bfloat16, device=self.device) if want_lo else None
-        _lib.check(L.convdr_ip_prepare_block(_lib.ptr(t), t.shape[0], self.d, _lib.ptr(self._centre), _lib.ptr(pbf),
-                                             _lib.ptr(plo), _lib.ptr(self._max_norm), _lib.stream_ptr()),
-                   "convdr_ip_prepare_block")
-        return pbf, plo
+        if self.kind == "f16":
+            _lib.check(L.convdr_ip_prepare_block_f16(_lib.ptr(src32), src32.shape[0], self.d, _lib.ptr(self._centre),
+                                                     float(self._scale), _lib.ptr(dst16), _lib.ptr(dstlo),
+                                                     _lib.ptr(self._max_norm), _lib.stream_ptr()), "convdr_ip_prepare_block_f16")
+        else:
+            _lib.check(L.convdr_ip_prepare_block(_lib.ptr(src32), src32.shape[0], self.d, _lib.ptr(self._centre), _lib.ptr(dst16),
+                                                 _lib.ptr(dstlo), _lib.ptr(self._max_norm), _lib.stream_ptr()),
+                       "convdr_ip_prepare_block")
+
+    def _first_rows(self, t):
+        """The first rows an empty index sees fix its centring vector and, for the fp16 scan, the power-of-two scale of the
+        scan copy (from these rows' largest centred norm: one extra pass over them and one host read per index
+        lifetime; later rows may be up to 7x longer before the copy has to be rebuilt, see _rebuild_scaled)."""
+        if self.center:
+            self._set_centre(t)
+        if self.kind == "f16":
+            L = _lib.lib()
+            _lib.check(L.convdr_ip_prepare_block_f16(_lib.ptr(t), t.shape[0], self.d, _lib.ptr(self._centre), 1.0, None, None,
+                                                     _lib.ptr(self._max_norm), _lib.stream_ptr()), "convdr_ip_prepare_block_f16")
+            self._scale = float(L.convdr_ip_f16_scale(float(self._max_norm.item())))
+
+    def _rebuild_scaled(self):
+        """CONVDR_IP_RANGE: rows added after the scale was fixed are more than 7x longer than the first block's longest.
+        Re-derive the scale from the block's max norm and rebuild the fp16 copies from the resident fp32 rows."""
+        import torch
+        with torch.cuda.device(self.device):
+            self._scale = float(_lib.lib().convdr_ip_f16_scale(float(self._max_norm.item())))
+            if self._n:
+                self._prepare_into(self._p32, self._pbf, self._plo)
+
+    def _grow_for(self, m, want_lo):
+        """rows [n, n + m) of the backing storage, growing it when needed (exact fit unless reserved larger)"""
+        need = self._n + m
+        if self._s32 is None or self._s32.shape[0] < need or (want_lo and self._slo is None):
+            keep = getattr(self, "_reserved", False)
+            self.reserve(need, lo=want_lo or self._slo is not None)
+            self._reserved = keep
+        a, b = self._n, need
+        return self._s32[a:b], self._s16[a:b], (self._slo[a:b] if self._slo is not None else None)
 
     def add(self, x, chunk_bytes=None):
         """x: numpy / torch [n, d] float32 (host or device).  Appends to the index.
         A HOST array -- typically the memory-mapped payload of a block file (blocks.BlockView) -- is streamed: chunks of
-        ~chunk_bytes (default 64 MB) go through two pinned staging buffers, the H2D copy of chunk i + 1 (copy stream) runs under the
-        centring / bf16 rounding / norm pass of chunk i (convdr_ip_prepare_block), and the host fills one staging buffer
-        (page faults on the mmap = the disk read) while the other is in flight.  The reference does pickle.load (a full
+        ~chunk_bytes (default 64 MB) go through pinned staging buffers, the H2D copy of chunk i + 1 (copy stream) runs under the
+        centring / rounding / norm pass of chunk i (convdr_ip_prepare_block*), and the host fills one staging buffer
+        (page faults on the mmap = the disk read) while the others are in flight.  The reference does pickle.load (a full
         host copy of the 14.6 GB block) and a pageable copy (run_convdr_inference.py:164-180)."""
         import torch
         chunk_bytes = int(chunk_bytes or self.host_chunk_bytes)
@@ -106,13 +191,23 @@ class FlatIPIndex:
             t = t.float()
         t = t.to(self.device, non_blocking=True).contiguous()
         assert t.dim() == 2 and t.shape[1] == self.d, "expected [n, %d], got %s" % (self.d, tuple(t.shape))
-        if t.shape[0] == 0:
+        m = int(t.shape[0])
+        if m == 0:
             return
+        want_lo = self.precision in ("bf16x3", "fp16x3") or self._slo is not None
         with torch.cuda.device(self.device):
-            if self._p32 is None and self.center:
-                self._set_centre(t)
-            pbf, plo = self._prepare(t, self.precision == "bf16x3" or self._plo is not None)
-        self._append(t, pbf, plo)
+            if self._n == 0:
+                self._first_rows(t)
+            if self._s32 is None and not want_lo:
+                # first block of an unreserved index: adopt the caller's device tensor instead of copying it
+                self._s32 = t
+                self._s16 = torch.empty((m, self.d), dtype=self._half_dtype, device=self.device)
+                dst32, dst16, dstlo = self._s32, self._s16, None
+            else:
+                dst32, dst16, dstlo = self._grow_for(m, want_lo)
+                dst32.copy_(t)
+            self._prepare_into(dst32, dst16, dstlo)
+        self._n += m
 
     def _pad_columns(self, x):
         import torch
@@ -128,38 +223,26 @@ class FlatIPIndex:
         _lib.check(_lib.lib().convdr_ip_column_mean(_lib.ptr(t), t.shape[0], self.d, _lib.ptr(scratch),
                                                    _lib.ptr(self._centre), _lib.stream_ptr()), "convdr_ip_column_mean")
 
-    def _append(self, t, pbf, plo):
-        import torch
-        if self._p32 is None:
-            self._p32, self._pbf, self._plo = t, pbf, plo
-        else:  # FAISS semantics: add() appends (the centring vector stays the first block's mean)
-            self._p32 = torch.cat([self._p32, t], 0)
-            self._pbf = torch.cat([self._pbf, pbf], 0)
-            if plo is not None:
-                self._plo = torch.cat([self._plo, plo], 0)
-
     def _add_host_streamed(self, arr, chunk_bytes, reader=None):
         import time
         import torch
         n, d = arr.shape
         assert d == self.d, "expected [n, %d], got %s" % (self.d, arr.shape)
-        L = _lib.lib()
         rows_per = max(1, int(chunk_bytes) // (4 * d))
-        want_lo = self.precision == "bf16x3" or self._plo is not None
+        want_lo = self.precision in ("bf16x3", "fp16x3") or self._slo is not None
+        nbuf = max(2, int(self.host_stage_buffers))
         t0 = time.perf_counter()
         with torch.cuda.device(self.device):
             main = torch.cuda.current_stream()
             if getattr(self, "_copy_stream", None) is None:
                 self._copy_stream = torch.cuda.Stream(device=self.device)
                 self._stage = None
-            if self._stage is None or self._stage[0].shape[0] < min(rows_per, n):
-                self._stage = [torch.empty((min(rows_per, n), d), dtype=torch.float32).pin_memory() for _ in range(2)]
-                self._stage_ev = [None, None]
+            if self._stage is None or len(self._stage) != nbuf or self._stage[0].shape[0] < min(rows_per, n):
+                self._stage = [torch.empty((min(rows_per, n), d), dtype=torch.float32).pin_memory() for _ in range(nbuf)]
+                self._stage_ev = [None] * nbuf
             cs = self._copy_stream
-            p32 = torch.empty((n, d), dtype=torch.float32, device=self.device)
-            pbf = torch.empty((n, d), dtype=torch.bfloat16, device=self.device)
-            plo = torch.empty((n, d), dtype=torch.bfloat16, device=self.device) if want_lo else None
-            cs.wait_stream(main)                    # (p32 / pbf allocation order)
+            p32, p16, plo = self._grow_for(n, want_lo)
+            cs.wait_stream(main)                    # (allocation order / the copy of the old rows in _grow_for)
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             threads = max(1, min(int(self.host_copy_threads), avail))
             if getattr(self, "_pool", None) is None or self._pool_threads != threads:
@@ -171,12 +254,13 @@ class FlatIPIndex:
             # tests/test_ip_search_gpu.py::test_randomised_cases_match_the_oracle: 1 run in ~500 put rows of the second
             # block into the first)
             freed = self._stage_ev
-            first = self._p32 is None
+            first = self._n == 0
             for ci, s in enumerate(range(0, n, rows_per)):
                 e = min(n, s + rows_per)
-                buf = self._stage[ci & 1]
-                if freed[ci & 1] is not None:
-                    freed[ci & 1].synchronize()
+                bi = ci % nbuf
+                buf = self._stage[bi]
+                if freed[bi] is not None:
+                    freed[bi].synchronize()
                 dst = buf.numpy()[:e - s]
                 if reader is not None:
                     reader(dst, s, e, pool=pool, parts=threads)          # positioned file reads, `threads` slices in flight
@@ -189,47 +273,57 @@ class FlatIPIndex:
                     p32[s:e].copy_(buf[:e - s], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(cs)
-                freed[ci & 1] = ev
+                freed[bi] = ev
                 main.wait_event(ev)
-                if first and self.center and ci == 0:
+                if first and ci == 0:
                     # centre = column mean of the first chunk (>= 40 k passages): any centre keeps the search exact -- it
                     # shifts every score of a query by the same constant -- it only has to be close to the mean to shrink
-                    # the bf16 error band
-                    self._set_centre(p32[s:e])
-                _lib.check(L.convdr_ip_prepare_block(_lib.ptr(p32[s:e]), e - s, d, _lib.ptr(self._centre), _lib.ptr(pbf[s:e]),
-                                                     _lib.ptr(plo[s:e]) if plo is not None else None, _lib.ptr(self._max_norm),
-                                                     _lib.stream_ptr()), "convdr_ip_prepare_block")
-            self._append(p32, pbf, plo)
+                    # the rounding-error band; likewise the fp16 scale comes from the first chunk's norms
+                    self._first_rows(p32[s:e])
+                self._prepare_into(p32[s:e], p16[s:e], plo[s:e] if plo is not None else None)
+            self._n += n
         self.stats["add_host_s"] = time.perf_counter() - t0     # host time to enqueue (the last chunks are still in flight)
         self.stats["add_host_bytes"] = n * d * 4
 
     def _ensure_lo(self):
-        """Remainder copy for the split-bf16 scan, built on first use."""
+        """Remainder copy for the split scan, built on first use."""
         import torch
-        if self._plo is None and self._p32 is not None:
+        if self._slo is None and self._s32 is not None:
             with torch.cuda.device(self.device):
-                self._max_norm_saved = self._max_norm.clone()
-                _, self._plo = self._prepare(self._p32, True)
+                self._slo = torch.empty((self._s32.shape[0], self.d), dtype=self._half_dtype, device=self.device)
+                if self._n:
+                    self._prepare_into(self._p32, self._pbf, self._plo)
 
     def update_rows(self, row0, emb):
         """Overwrite rows [row0, row0 + len(emb)) of the resident block with freshly encoded embeddings
-        (device fp32 [m, d]) and refresh their bf16 scan copy / the block's max norm.  No sync."""
+        (device fp32 [m, d]) and refresh their scan copy / the block's max norm.  No sync."""
         import torch
         m = int(emb.shape[0])
         assert emb.dtype == torch.float32 and emb.is_contiguous() and row0 + m <= self.ntotal
         dst32, dstbf = self._p32[row0:row0 + m], self._pbf[row0:row0 + m]
-        dstlo = None if self._plo is None else self._plo[row0:row0 + m]
+        dstlo = None if self._slo is None else self._plo[row0:row0 + m]
         dst32[:, :self.d_in].copy_(emb)      # (zero columns of a padded width stay zero)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().convdr_ip_prepare_block(_lib.ptr(dst32), m, self.d, _lib.ptr(self._centre), _lib.ptr(dstbf),
-                                                         _lib.ptr(dstlo), _lib.ptr(self._max_norm), _lib.stream_ptr()),
-                       "convdr_ip_prepare_block")
+            self._prepare_into(dst32, dstbf, dstlo)
 
     def _workspace(self, nbytes):
         import torch
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def _search_call(self, q, nq, p32, p16, plo, n, k, tau_in, cap, rank_target, ws, D, I, status, tau_retry):
+        L = _lib.lib()
+        if self.kind == "f16":
+            _lib.check(L.convdr_ip_search_f16(_lib.ptr(q), nq, _lib.ptr(p32), _lib.ptr(p16), _lib.ptr(plo), float(self._scale), n,
+                                              self.d, k, _lib.ptr(self._max_norm), _lib.ptr(tau_in), cap, rank_target,
+                                              _lib.ptr(ws), ws.numel(), _lib.ptr(D), _lib.ptr(I), _lib.ptr(status),
+                                              _lib.ptr(tau_retry), _lib.stream_ptr()), "convdr_ip_search_f16")
+        else:
+            _lib.check(L.convdr_ip_search(_lib.ptr(q), nq, _lib.ptr(p32), _lib.ptr(p16), _lib.ptr(plo), n, self.d, k,
+                                          _lib.ptr(self._max_norm), _lib.ptr(tau_in), cap, rank_target,
+                                          _lib.ptr(ws), ws.numel(), _lib.ptr(D), _lib.ptr(I), _lib.ptr(status),
+                                          _lib.ptr(tau_retry), _lib.stream_ptr()), "convdr_ip_search")
 
     def search_device(self, q, k, tau_in=None, cap=None, x3=None):
         """One enqueue of the kernel pipeline; q is a device fp32 [nq, d] tensor.
@@ -238,7 +332,7 @@ class FlatIPIndex:
         L = _lib.lib()
         cap = cap or self.cap
         if x3 is None:
-            x3 = self.precision == "bf16x3"
+            x3 = self.precision in ("bf16x3", "fp16x3")
         if x3:
             self._ensure_lo()
         nq, n = int(q.shape[0]), self.ntotal
@@ -252,10 +346,7 @@ class FlatIPIndex:
         pbf = self._pbf if n else q
         plo = self._plo if (x3 and n) else None
         with torch.cuda.device(self.device):
-            _lib.check(L.convdr_ip_search(_lib.ptr(q), nq, _lib.ptr(p32), _lib.ptr(pbf), _lib.ptr(plo), n, self.d, k,
-                                          _lib.ptr(self._max_norm), _lib.ptr(tau_in), cap, self.rank_target,
-                                          _lib.ptr(ws), ws.numel(), _lib.ptr(D), _lib.ptr(I), _lib.ptr(status),
-                                          _lib.ptr(tau_retry), _lib.stream_ptr()), "convdr_ip_search")
+            self._search_call(q, nq, p32, pbf, plo, n, k, tau_in, cap, self.rank_target, ws, D, I, status, tau_retry)
         return D, I, status, tau_retry
 
     def last_counts(self, nq, k, cap=None):
@@ -301,10 +392,10 @@ class FlatIPIndex:
     def search_tensors(self, q, k):
         """``search`` with the certified result left on the device (torch fp32 [nq, k], int64 [nq, k]).
 
-        precision="auto": the bf16 scan first; queries it cannot certify are re-run -- with a lower threshold while their
-        error band still fits the candidate list, with the split-bf16 scan (10x tighter band) once the band has swallowed
-        the whole list (encoder outputs: after centring, |p - mean| ~ 1.5 against score spreads of ~0.5).  The index
-        remembers when most queries of a block ended on the split scan and starts there next time (`x3_first`)."""
+        precision="auto": the fp16 scan first; queries it cannot certify are re-run -- with a lower threshold while their
+        error band still fits the candidate list, with the split scan (4x tighter band) once the band has swallowed
+        the whole list.  The index remembers when most queries of a block ended on the split scan and starts there next
+        time (`x3_first`)."""
         import torch
         qt = torch.as_tensor(q)
         if qt.dtype != torch.float32:
@@ -313,14 +404,20 @@ class FlatIPIndex:
         assert qt.dim() == 2 and qt.shape[1] == self.d
         k = int(k)
         nq = int(qt.shape[0])
-        x3 = self.precision == "bf16x3" or (self.precision == "auto" and getattr(self, "_x3_first", False) and self.ntotal > 0)
+        x3 = self.precision in ("bf16x3", "fp16x3") or (self.precision == "auto" and getattr(self, "_x3_first", False) and self.ntotal > 0)
         D, I, status, tau_retry = self.search_device(qt, k, x3=x3)
-        self.stats = {"retried": int((status != 0).sum().item()), "rounds": 1, "x3_queries": nq if x3 else 0, "x3_first": bool(x3)}
+        rescaled = 0
+        if self.kind == "f16" and int((status == STATUS_RANGE).sum().item()):
+            self._rebuild_scaled()
+            rescaled = 1
+            D, I, status, tau_retry = self.search_device(qt, k, x3=x3)
+        self.stats = {"retried": int((status != 0).sum().item()), "rounds": 1, "x3_queries": nq if x3 else 0, "x3_first": bool(x3),
+                      "rescaled": rescaled}
         bad = []
         if self.stats["retried"]:
             if self.precision == "auto" and not x3:
                 # a band that already covers every emitted candidate only grows with a lower threshold: those queries go
-                # straight to the split scan, the others get their bf16 retries
+                # straight to the split scan, the others get their single-pass retries
                 emitted, band = self.last_counts(nq, k)
                 st = status.cpu().numpy()
                 sat = ((band >= emitted) & (emitted > 0)).cpu().numpy() & (st == STATUS_UNCERTAIN)
@@ -336,7 +433,7 @@ class FlatIPIndex:
             else:
                 bad = self._certify(qt, k, D, I, status, tau_retry, x3)
         if len(bad) and self.precision == "auto" and not x3:
-            # second rung: split-bf16 scan for the queries the bf16 error band cannot separate
+            # second rung: split scan for the queries the single-pass error band cannot separate
             idx = torch.as_tensor(bad, device=self.device)
             qs = qt[idx].contiguous()
             self.stats["x3_queries"] = len(bad)
@@ -348,7 +445,7 @@ class FlatIPIndex:
         if self.precision == "auto":
             self._x3_first = self.stats["x3_queries"] > nq // 2
         if len(bad):
-            # last rung: more than 8192 passages inside the error band of the k-th score even with the split-bf16 scan
+            # last rung: more than 8192 passages inside the error band of the k-th score even with the split scan
             # (blocks whose norms spread over orders of magnitude: eps scales with the LARGEST norm).  Every slice of
             # <= cap rows is searched with all of its rows as candidates -- exact by construction -- and the slices are
             # merged in row order (earlier rows win ties): slow (one small launch chain per slice) but always an answer
@@ -374,9 +471,7 @@ class FlatIPIndex:
             status = torch.empty(qq.shape[0], dtype=torch.int32, device=self.device)
             tau_retry = torch.empty(qq.shape[0], dtype=torch.float32, device=self.device)
             ws = self._workspace(L.convdr_ip_workspace_bytes(int(qq.shape[0]), m, self.d, kq, cap))
-            _lib.check(L.convdr_ip_search(_lib.ptr(qq), int(qq.shape[0]), _lib.ptr(p32), _lib.ptr(pbf), None, m, self.d, kq,
-                                          _lib.ptr(self._max_norm), None, cap, 0, _lib.ptr(ws), ws.numel(), _lib.ptr(D), _lib.ptr(I),
-                                          _lib.ptr(status), _lib.ptr(tau_retry), _lib.stream_ptr()), "convdr_ip_search")
+            self._search_call(qq, int(qq.shape[0]), p32, pbf, None, m, kq, None, cap, 0, ws, D, I, status, tau_retry)
             if int((status != 0).sum().item()):
                 raise _lib.ConvdrError("convdr_ip_search: exhaustive slice of %d rows not certified" % m)
             return D, I
@@ -405,6 +500,7 @@ class FlatIPIndex:
                 Dout[j] = Dj[0]
                 Iout[j] = torch.where(Ij[0] >= 0, rows[Ij[0].clamp_min(0)], Ij[0])
         return Dout, Iout
+
 
 def load_block(path):
     """pickle.load, as run_convdr_inference.py:164-175 does."""

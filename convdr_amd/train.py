@@ -175,6 +175,60 @@ def _pinned_upload(arr, dev):
     return t.to(dev, non_blocking=True)
 
 
+# ---- status word of the encoder forward (include/convdr_hip.h: CONVDR_ENC_STATUS_*) -------------------------------
+# With caller-provided host lengths a forward has no device -> host round trip, so nothing on the host can look at the
+# token ids.  The packing kernel does (clamps + flags); the flag word is copied to a pinned slot behind every forward
+# and looked at without waiting: at the start of the tower's next forward, and by `check_status(model)` which the
+# loops call at their own sync points (encode.py / inference.py after the embeddings came back).  So a bad batch raises
+# the reference's IndexError at the latest one call later, never reads out of bounds, and costs no sync.
+_STATUS_RING = 64
+
+
+def _status_post(tower, ws):
+    st = tower.__dict__.get("_status")
+    if st is None:
+        st = tower.__dict__["_status"] = {"ring": torch.zeros(_STATUS_RING, dtype=torch.int32).pin_memory(), "pending": [], "next": 0}
+    if len(st["pending"]) >= _STATUS_RING - 1:
+        _status_poll(tower, sync=True)
+    slot = st["next"]
+    st["next"] = (slot + 1) % _STATUS_RING
+    st["ring"][slot:slot + 1].copy_(ws[:4].view(torch.int32), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    st["pending"].append((slot, ev))
+
+
+def _status_poll(tower, sync=False):
+    st = tower.__dict__.get("_status")
+    if not st or not st["pending"]:
+        return
+    flags, left = 0, []
+    for slot, ev in st["pending"]:
+        if sync:
+            ev.synchronize()
+        if sync or ev.query():
+            flags |= int(st["ring"][slot])
+        else:
+            left.append((slot, ev))
+    st["pending"] = left
+    if flags & 1:
+        raise IndexError("token id out of range for the %d-row word-embedding table (flagged by the packing kernel; the "
+                         "embeddings of that batch are meaningless)" % tower.embeddings.word_embeddings.num_embeddings)
+    if flags & 2:
+        raise ValueError("seq_lens does not match the number of unmasked tokens of a sequence (or exceeds the padded length)")
+    if flags & 4:
+        raise ValueError("every sequence needs attention_mask[:, 0] == 1")
+
+
+def check_status(model, sync=True):
+    """Raise what the reference's embedding lookup would have raised (IndexError) for any forward of `model`'s towers
+    enqueued so far whose packing kernel flagged its inputs.  sync=True waits for those forwards."""
+    m = model.module if hasattr(model, "module") else model
+    for mod in m.modules():
+        if "_status" in mod.__dict__:
+            _status_poll(mod, sync=sync)
+
+
 def _lens_and_check(ids, mask, vocab, seq_lens=None):
     """(device int32 lens, host int32 lens).  Without caller-provided host lengths this is the one device -> host
     round trip of a forward; the largest / smallest token id ride along and are validated like the reference's
@@ -204,6 +258,7 @@ class _EncoderFn(torch.autograd.Function):
             raise _lib.ConvdrError("encoder inputs must be CUDA tensors (no CPU fallback)")
         B, L = ids.shape
         dev = ids.device
+        _status_poll(tower)
         seq_lens_dev, lens_host = _lens_and_check(ids, mask, tower.embeddings.word_embeddings.num_embeddings, seq_lens)
         if lens_host.min() < 1:
             raise ValueError("every sequence needs at least one unmasked token")
@@ -223,6 +278,7 @@ class _EncoderFn(torch.autograd.Function):
                                                        _lib.ptr(cu), _lib.ptr(seq_lens_dev), rows, max_len, _lib.ptr(ws),
                                                        ws.numel(), _lib.ptr(out), drop, _lib.stream_ptr()),
                        "convdr_encoder_train_forward")
+            _status_post(tower, ws)
             # the transposed weight copies are needed by the backward only: pack them on the side stream, under this
             # forward (0.6 ms of small transposes per step that would otherwise sit in front of the backward)
             main = torch.cuda.current_stream()
@@ -560,18 +616,27 @@ class AdamW(torch.optim.Optimizer):
 
     def _try_flat_step(self):
         ops = self.__dict__.pop("_flat_ops_cache", None) or self._flat_operands()
+        ok = ops is not None
+        if ok and ops[0]:
+            ps, P, G = ops
+            st = self._adopt_flat_state(ps, P)
+            steps = {int(self.state[p]["step"]) for p in ps}
+            ok = len(steps) == 1              # parameters at different step counts: per-parameter update
         scale = self.__dict__.pop("_pending_grad_scale", None)
-        if ops is None:
-            assert scale is None, "a deferred clip coefficient needs the flat update path"
+        if not ok:
+            if scale is not None:
+                # clip_grad_norm_ deferred the clip coefficient (and a folded 1 / world) to this step: it must not be lost
+                # on the per-parameter fallback -- apply it to the gradients now
+                for g in self.param_groups:
+                    for p in g["params"]:
+                        if p.grad is not None:
+                            with torch.cuda.device(p.grad.device):
+                                _lib.check(_lib.lib().convdr_scale_f32(_lib.ptr(p.grad), p.grad.numel(), _lib.ptr(scale),
+                                                                       _lib.stream_ptr()), "convdr_scale_f32")
             return False
-        ps, P, G = ops
-        if not ps:
+        if not ops[0]:
             return True
         g0 = self.param_groups[0]
-        st = self._adopt_flat_state(ps, P)
-        steps = {int(self.state[p]["step"]) for p in (ps[0], ps[-1])}
-        if len(steps) != 1:
-            return False                      # parameters at different step counts: per-parameter update
         step = steps.pop() + 1
         b1, b2 = g0["betas"]
         with torch.cuda.device(P.device):

@@ -51,6 +51,15 @@ int convdr_ip_column_mean(const float* p_f32, int64_t n, int d, float* scratch, 
 int convdr_ip_prepare_block(const float* p_f32, int64_t n, int d, const float* centre, void* p_bf16, void* p_bf16_lo,
                             float* max_norm, convdr_stream_t stream);
 
+/* The same for the fp16 scan (the default first rung: v_mfma_f32_32x32x16_f16 runs at the bf16 rate with 11 significand
+ * bits instead of 8, i.e. an 8x tighter error band per pass):  p_f16 = half(scale * (p - centre)),  p_f16_lo (nullable)
+ * = half of the remainder.  `scale` is a power of two (exact) that moves the block's norms to ~2^12, away from both
+ * ends of the half range; convdr_ip_f16_scale(max norm seen so far) proposes it.  *max_norm stays UNSCALED.
+ * p_f16 == NULL: only fold the norms into *max_norm (the pass that finds the scale of a first block). */
+int convdr_ip_prepare_block_f16(const float* p_f32, int64_t n, int d, const float* centre, float scale, void* p_f16,
+                                void* p_f16_lo, float* max_norm, convdr_stream_t stream);
+float convdr_ip_f16_scale(float max_norm);
+
 /* Bytes of device workspace convdr_ip_search needs for these sizes. */
 size_t convdr_ip_workspace_bytes(int nq, int64_t n, int d, int k, int cap);
 
@@ -60,6 +69,8 @@ size_t convdr_ip_workspace_bytes(int nq, int64_t n, int d, int k, int cap);
                                  when tau_retry does not exceed the tau that was used)                    */
 #define CONVDR_IP_TOO_FEW 2   /* fewer than min(k, n) candidates passed tau: retry with tau_retry         */
 #define CONVDR_IP_UNCERTAIN 3 /* the re-score band reaches below tau: retry with tau_retry               */
+#define CONVDR_IP_RANGE 4     /* fp16 scan only: scale * max norm > 60000, elements of the half copy may be
+                                 inf -- rebuild the copy with convdr_ip_f16_scale(current max norm), search again */
 
 /* .search(Q, k): exact inner-product top-k of nq fp32 queries against one resident block.
  *   scan     bf16 MFMA GEMM  S~ = P_bf16 * Q_bf16^T  with a fused per-query threshold test: passages with
@@ -84,6 +95,19 @@ int convdr_ip_search(const float* q_f32, int nq, const float* p_f32, const void*
                      int k, const float* p_max_norm, const float* tau_in, int cap, int rank_target,
                      void* workspace, size_t workspace_bytes, float* D, int64_t* I, int32_t* status,
                      float* tau_retry, convdr_stream_t stream);
+
+/* convdr_ip_search over the fp16 scan copy built by convdr_ip_prepare_block_f16 with the same p_scale.  Queries are
+ * scaled per row by a power of two inside (norm -> [2^11, 2^12)); thresholds (tau_in / tau_retry) are in those scaled
+ * units and are only meaningful for a retry of the same query against the same copy.
+ *   eps = (2u + u^2 + d 2^-23) |q| max|p'| + eta (1 + u) sqrt(d) (|q| + max|p'|) + d eta^2,  u = 2^-11, eta = 2^-14
+ *   (1.07e-3 |q| max|p'| at d = 768; the absolute term ~1e-6 of it);  p_f16_lo non-NULL: the split scan
+ *   S~ = Ph Qh + Ph Ql + Pl Qh with 3 u^2 + 3 d 2^-23 = 2.8e-4.
+ * status may also be CONVDR_IP_RANGE (see above).  D / I are defined exactly as for convdr_ip_search -- the rung only
+ * decides which candidates are re-scored, never the result. */
+int convdr_ip_search_f16(const float* q_f32, int nq, const float* p_f32, const void* p_f16, const void* p_f16_lo, float p_scale,
+                         int64_t n, int d, int k, const float* p_max_norm, const float* tau_in, int cap, int rank_target,
+                         void* workspace, size_t workspace_bytes, float* D, int64_t* I, int32_t* status,
+                         float* tau_retry, convdr_stream_t stream);
 
 /* Instrumentation of the last convdr_ip_search on this workspace (device uint32 [nq] each):
  * candidates emitted by the scan / size of the exactly re-scored band. */
@@ -150,6 +174,15 @@ int convdr_cast_f32_bf16(const float* x, void* y, int64_t n, convdr_stream_t str
 int convdr_pack_kslice(const void* w_bf16, int n, int k, void* out, convdr_stream_t stream);
 
 size_t convdr_encoder_workspace_bytes(const convdr_encoder_config* cfg, int64_t rows, int B);
+
+/* Status word of an encoder forward: the first int32 of `workspace` (inference and training forward alike), zeroed at
+ * the start of the call and OR-ed by the packing kernel.  The reference raises IndexError from nn.Embedding for a token
+ * id outside the table (model/models.py:141-142); a kernel cannot raise, so the id is clamped to 0 (no out-of-bounds
+ * read, no out-of-bounds atomic in the backward), the flag is set, and the host raises when it next reads the word
+ * (the outputs of a flagged batch are meaningless). */
+#define CONVDR_ENC_STATUS_BAD_TOKEN 1  /* a token id < 0 or >= cfg->vocab under the mask                       */
+#define CONVDR_ENC_STATUS_BAD_LENS 2   /* seq_lens[b] != number of unmasked tokens of row b (or > L)          */
+#define CONVDR_ENC_STATUS_BAD_MASK 4   /* attention_mask[b, 0] == 0: the CLS position must be a real token    */
 
 /* out[b, :] = embedding of sequence b.  input_ids / attention_mask: device int64 [B, L] exactly as the reference
  * drivers pass them (gen_passage_embeddings.py:105-112); with ids_are_int32 != 0 input_ids is int32 [B, L] (token-cache

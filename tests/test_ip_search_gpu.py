@@ -45,6 +45,83 @@ def test_search_matches_oracle_bit_exact(torch_cuda, n, nq, k, d):
     assert D.dtype == np.float32 and I.dtype == np.int64
 
 
+@pytest.mark.parametrize("precision", ["fp16", "fp16x3", "bf16", "bf16x3"])
+@pytest.mark.parametrize("n,nq,k,d", [(700, 16, 100, 768), (40000, 140, 100, 768), (33000, 130, 7, 128)])
+def test_every_pinned_rung_returns_the_same_exact_result(torch_cuda, precision, n, nq, k, d):
+    """The rung (fp16 / split fp16 / bf16 / split bf16 MFMA scan) only decides which candidates are re-scored: D and I
+    are defined on the canonical fp64 scores and must not depend on it."""
+    P, Q = synth_corpus(200 + n % 89, n, d), synth_corpus(8, nq, d)
+    idx = _index(d, precision=precision)
+    idx.add(P)
+    D, I = idx.search(Q, k)
+    Dr, Ir = OS.flat_ip_search(Q, P, k)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D, Dr)
+
+
+@pytest.mark.parametrize("scale_p,scale_q", [(1e-6, 1.0), (3e4, 1e-5), (1.0, 1e6), (1e-20, 1e-12), (1e12, 1e10)])
+def test_fp16_rung_is_scale_free(torch_cuda, scale_p, scale_q):
+    """Halfs span 6e-8 .. 65504: the scan copy and every query are moved to norms ~2^12 by exact powers of two, so blocks
+    and queries of any magnitude certify on the first pass like unit-scale ones."""
+    P = (synth_corpus(71, 20000, 768) * np.float32(scale_p)).astype(np.float32)
+    Q = (synth_corpus(72, 12, 768) * np.float32(scale_q)).astype(np.float32)
+    idx = _index(768, precision="fp16")
+    idx.add(P)
+    D, I = idx.search(Q, 100)
+    assert idx.stats["retried"] <= 1 and not idx.stats.get("exhaustive_queries"), idx.stats
+    Dr, Ir = OS.flat_ip_search(Q, P, 100)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D, Dr)
+
+
+def test_fp16_scan_copy_is_rebuilt_when_later_rows_outgrow_its_scale(torch_cuda):
+    """The power-of-two scale of the fp16 copy is fixed by the first rows an index sees.  Rows added later that are > 7x
+    longer could round to inf: the cut kernel reports CONVDR_IP_RANGE instead of a result, the index re-derives the scale
+    from the block's max norm, rebuilds the copy and searches again."""
+    torch = torch_cuda
+    P0, P1 = synth_corpus(81, 6000, 768), synth_corpus(82, 5000, 768) * np.float32(300.0)
+    Q = synth_corpus(83, 9, 768)
+    idx = _index(768)
+    idx.add(P0)
+    s0 = idx._scale
+    idx.add(P1)
+    st = idx.search_device(torch.from_numpy(Q).cuda(), 20)[2]
+    assert (st.cpu().numpy() == 4).all()
+    D, I = idx.search(Q, 20)
+    assert idx.stats["rescaled"] == 1 and idx._scale < s0
+    P = np.concatenate([P0, P1])
+    Dr, Ir = OS.flat_ip_search(Q, P, 20)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D, Dr)
+    D, I = idx.search(Q, 20)
+    assert idx.stats["rescaled"] == 0
+    np.testing.assert_array_equal(I, Ir)
+
+
+def test_reserved_index_fills_in_place(torch_cuda):
+    """reserve(n): the resident block is allocated once and add() fills it slice by slice -- no re-allocation (the
+    unreserved FAISS-style append copies the whole block on every add: impossible for a 117 GB corpus)."""
+    torch = torch_cuda
+    P, Q = synth_corpus(91, 9000, 768), synth_corpus(92, 7, 768)
+    idx = _index(768)
+    idx.reserve(9000)
+    base = (idx._s32.data_ptr(), idx._s16.data_ptr())
+    for a in range(0, 9000, 2500):
+        idx.add(torch.from_numpy(P[a:a + 2500]).cuda())
+        assert (idx._s32.data_ptr(), idx._s16.data_ptr()) == base
+    assert idx.ntotal == 9000 and torch.equal(idx._p32.cpu(), torch.from_numpy(P))
+    D, I = idx.search(Q, 100)
+    Dr, Ir = OS.flat_ip_search(Q, P, 100)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D, Dr)
+    idx.reset()                                  # faiss reset keeps the reservation: next block, same memory
+    assert idx.ntotal == 0
+    idx.add(P[:3000])
+    assert idx._s32.data_ptr() == base[0]
+    D, I = idx.search(Q, 10)
+    np.testing.assert_array_equal(I, OS.flat_ip_search(Q, P[:3000], 10)[1])
+
+
 def test_exact_ties_lower_index_first(torch_cuda):
     base = synth_corpus(21, 300, 768)
     P = np.concatenate([base[:200], base[50:60], base[50:60]])
@@ -214,7 +291,7 @@ def test_full_size_properties_1m_x_1k(torch_cuda, n):
     assert (above <= k - 1).all(), above.max().item()
 
 
-@pytest.mark.parametrize("precision", ["auto", "bf16x3"])
+@pytest.mark.parametrize("precision", ["auto", "fp16", "bf16x3"])
 def test_clustered_embeddings_are_searched_exactly(torch_cuda, precision):
     """Encoder outputs share a large common component (cosine ~0.9 between passages), which puts thousands of scores
     inside the bf16 error band of the k-th one: centring + the split-bf16 rung must still return the exact top-k."""

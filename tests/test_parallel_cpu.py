@@ -229,3 +229,36 @@ def test_two_ranks_write_two_blocks_equal_to_one_rank(tmp_path):
         assert all(_run(_stream_doc_job, 2, 29631))
     finally:
         os.environ.pop("CONVDR_TEST_DIR", None)
+
+
+def _sampler_job(rank, world):
+    """Per-rank batch sharding of a training run (north_star: "DistributedSampler training batches shard"): the ranks'
+    samplers partition every epoch's permutation, re-seeded per epoch; shard_batch cuts a global batch the way
+    nn.DataParallel's scatter does (run_convdr_train.py:77-78)."""
+    from convdr_amd import parallel
+    data = list(range(103))
+    smp = parallel.train_sampler(data, shuffle=True, seed=5)
+    epochs = []
+    for ep in range(2):
+        smp.set_epoch(ep)
+        epochs.append(list(iter(smp)))
+    batch = (torch.arange(16).view(8, 2), np.arange(8), None, {"k": 1})
+    mine = parallel.shard_batch(batch)
+    return epochs, mine[0].tolist(), mine[1].tolist(), mine[2], mine[3]
+
+
+def test_distributed_sampler_and_batch_sharding():
+    out = _run(_sampler_job, 2, 29617)
+    for ep in range(2):
+        a, b = out[0][0][ep], out[1][0][ep]
+        assert len(a) == len(b) == 52                        # ceil(103 / 2): one index is repeated to pad, as torch does
+        assert set(a) | set(b) == set(range(103)) and len(set(a) & set(b)) <= 1
+    assert out[0][0][0] != out[0][0][1]                      # set_epoch reshuffles
+    assert out[0][1] + out[1][1] == torch.arange(16).view(8, 2).tolist()
+    assert out[0][2] + out[1][2] == list(range(8))
+    assert out[0][3] is None and out[0][4] == {"k": 1}
+    from convdr_amd import parallel
+    from torch.utils.data import RandomSampler
+    assert isinstance(parallel.train_sampler(list(range(5))), RandomSampler)      # world size 1: the reference's sampler
+    with pytest.raises(ValueError):
+        parallel.shard_batch((torch.zeros(7, 2),), rank=0, world=2)

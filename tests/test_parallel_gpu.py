@@ -62,6 +62,48 @@ def test_two_ranks_sharded_search_on_device_equals_search_one_by_one():
     assert all(_run(_search_job, 2, 29641))
 
 
+def _clustered_search_job(rank, world):
+    """Encoder-like shards: a dominant common component (cos ~ 0.98 between passages), with and without norms spread over
+    e^+-2.  A first scan pass over the raw rows cannot certify such queries; the lists that enter the exchange must
+    nevertheless be exact, like the reference's per-GPU IndexFlatIP (run_convdr_inference.py:180-182, 356-367)."""
+    from convdr_amd import blocks, parallel
+    from convdr_amd.search import FlatIPIndex
+    from oracle import search as OS
+    rs = np.random.RandomState(0)
+    N, d, k, nq = 24013, 768, 50, 21
+    c = rs.randn(d).astype(np.float32)
+    P0 = (0.9 * c[None, :] + 0.12 * rs.randn(N, d)).astype(np.float32)
+    P1 = P0 * np.exp(rs.uniform(-2, 2, size=(N, 1))).astype(np.float32)
+    Q = (0.9 * c[None, :] + 0.12 * rs.randn(nq, d)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    mine = blocks.shard_indices(N, world, rank)
+    out = {}
+    # ("bf16", un-centred) on the equal-norm block: the loosest rung on raw clustered rows cannot certify anything -- the
+    # ladder certainly has work (with the norm spread the scores separate by norm and even that rung certifies)
+    for name, P, precision, center in (("spread/auto", P1, "auto", True), ("plain/auto", P0, "auto", True),
+                                       ("plain/bf16-raw", P0, "bf16", False)):
+        blocks_all = [(P[blocks.shard_indices(N, world, r)], blocks.shard_indices(N, world, r)) for r in range(world)]
+        mD, mI = OS.search_one_by_one(blocks_all, Q, k)
+        index = FlatIPIndex(d, device=dev, precision=precision, center=center)
+        index.add(P[mine])
+        Qall = torch.from_numpy(Q).to(dev)
+        first = index.search_device(Qall, k)[2]
+        D, I, status = parallel.search_sharded_device(index, Qall, k, torch.from_numpy(mine).to(dev))
+        out[name] = (int((first != 0).sum()), int((status != 0).sum()), dict(index.stats),
+                     bool(np.array_equal(I.cpu().numpy(), mI[:, :k])),
+                     bool(np.array_equal(D.cpu().numpy(), mD[:, :k].astype(np.float32))))
+    return out
+
+
+def test_two_ranks_sharded_search_is_certified_on_clustered_shards():
+    res = _run(_clustered_search_job, 2, 29645)
+    for out in res:
+        for name, (first_bad, bad, stats, ids_ok, scores_ok) in out.items():
+            assert bad == 0 and ids_ok and scores_ok, (name, first_bad, bad, stats, ids_ok, scores_ok)
+        # the raw bf16 rung really needed the ladder (otherwise this test shows nothing)
+        assert out["plain/bf16-raw"][0] > 0 and out["plain/bf16-raw"][2]["retried"] > 0, out["plain/bf16-raw"][:3]
+
+
 def _train_job(rank, world):
     from types import SimpleNamespace
     from convdr_amd import parallel

@@ -635,6 +635,54 @@ def test_out_of_range_token_id_raises_like_the_reference():
             model.eval()(long_ids.cuda(), long_mask.cuda())
 
 
+def test_out_of_range_token_id_on_the_host_lengths_path_is_flagged_by_the_kernel():
+    """With caller-provided host lengths (corpus loop, `evaluate`, 6-tuple training batches) no forward looks at the ids on
+    the host.  The packing kernel clamps an out-of-table id (no out-of-bounds read of the embedding table, no
+    out-of-bounds atomic in the embedding backward) and flags the batch; the host raises the reference's IndexError
+    (models.py:141-142 -> nn.Embedding) at `check_status`, or at the tower's next forward at the latest."""
+    from convdr_amd import train as TR
+    model = _tiny().cuda().eval()
+    ids, mask = _batch(np.random.RandomState(15), 2, 16, [16, 9])
+    lens = np.array([16, 9], np.int32)
+    good = ids.clone()
+    ids[1, 3] = 200                                   # vocab = 200
+    ids[0, 5] = -7
+    with torch.no_grad():
+        ok = model(good.cuda(), mask.cuda(), seq_lens=lens)
+        TR.check_status(model)                        # clean batch: nothing raised
+        model(ids.cuda(), mask.cuda(), seq_lens=lens)                 # enqueued; nothing on the host has seen the ids
+        with pytest.raises(IndexError):
+            TR.check_status(model)
+        TR.check_status(model)                        # reported once
+        again = model(good.cuda(), mask.cuda(), seq_lens=lens)
+    assert torch.equal(ok, again)                     # the clamped batch corrupted nothing
+    # the differentiable forward + backward: the word-embedding gradient is scattered with atomics
+    model.train()
+    out = model(ids.cuda(), mask.cuda(), seq_lens=lens)
+    out.sum().backward()
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        model(good.cuda(), mask.cuda(), seq_lens=lens)                # ... the next forward at the latest
+    # lengths that contradict the mask, and a masked CLS position
+    model.eval()
+    with torch.no_grad():
+        model(good.cuda(), mask.cuda(), seq_lens=np.array([16, 12], np.int32))
+        with pytest.raises(ValueError):
+            TR.check_status(model)
+        m2 = mask.clone()
+        m2[1, 0] = 0
+        model(good.cuda(), m2.cuda(), seq_lens=np.array([16, 8], np.int32))
+        with pytest.raises(ValueError):
+            TR.check_status(model)
+    # the corpus loop (int32 ids, mask = None): encode.encode_shard raises after its final sync
+    bad = good.to(torch.int32).clone()
+    bad[0, 2] = 4096
+    with torch.no_grad():
+        model.roberta.embed(bad.cuda(), None, head=(model.embeddingHead, model.norm), seq_lens=lens)
+    with pytest.raises(IndexError):
+        TR.check_status(model)
+
+
 def test_kd_step_at_configs2_size_matches_autograd():
     """BASELINE configs[2] at its stated size: roberta-base shape (12 layers x 768, vocab 50265), batch 64, student
     turns of <= 256 tokens, teacher targets of <= 64 tokens (ragged, OR-QuAC-shaped) -- the KD loss (MSE, :114-115), the
