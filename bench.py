@@ -210,6 +210,59 @@ def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=
     return out
 
 
+def train_rank_measure(dev, Bt=64, K=10, Ld=512, steps=4, warmup=2):
+    """configs[4]'s per-GPU step (run_convdr_train.py:101-193 with --ranking_task): B = 64 student turns of <= 256 tokens,
+    teacher targets of <= 64, K = 10 documents x 512 tokens per sample.  Timed three ways: the reference's flow (the frozen
+    teacher RE-ENCODES the 640 documents every step, :118-159), the lookup of the same embeddings from corpus blocks
+    (`doc_embs=`), and the lookup with the all-gathered in-batch negatives of configs[4] (one rank here:
+    the gather is the identity, the loss runs over B x K = 640 documents per query instead of 10)."""
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    from convdr_amd import train as TR
+    student = random_rdot_model(0).to(dev)
+    teacher = random_rdot_model(1).to(dev).eval()
+    student.config.hidden_dropout_prob = student.config.attention_probs_dropout_prob = 0.1
+    TR.flatten_parameters(student)
+    g = torch.Generator(device=dev).manual_seed(3)
+
+    def turns(B, L, lo):
+        ids = torch.randint(3, 50000, (B, L), generator=g, device=dev)
+        ids[:, 0] = 0
+        lens = torch.randint(lo, L + 1, (B,), generator=g, device=dev)
+        mask = (torch.arange(L, device=dev)[None, :] < lens[:, None]).long()
+        return ids * mask, mask, lens.cpu().numpy().astype(np.int32)
+    (ci, cm, cl), (ti, tm, tl) = turns(Bt, 256, 32), turns(Bt, 64, 8)
+    di, dm, _ = turns(Bt * K, Ld, Ld)                    # full 512-token documents
+    batch = (ci, cm, ti, tm, cl, tl)
+    with torch.no_grad():
+        doc_embs = torch.cat([teacher(di[i:i + 128], dm[i:i + 128], is_query=False) for i in range(0, Bt * K, 128)], 0)
+    out = {}
+    for name, kw, inb in (("reencode_docs", {"doc_ids": di, "doc_mask": dm}, False), ("lookup_doc_embs", {"doc_embs": doc_embs}, False),
+                          ("lookup_doc_embs_inbatch_negatives", {"doc_embs": doc_embs}, True)):
+        targs = SimpleNamespace(learning_rate=1e-5, adam_epsilon=1e-8, max_grad_norm=1.0, ranking_task=True, no_mse=False,
+                                num_negatives=K - 1, gradient_accumulation_steps=1, in_batch_negatives=inb)
+        opt = TR.get_optimizer(targs, student, weight_decay=0.0)
+        sched = TR.get_linear_schedule_with_warmup(opt, 0, 10_000)
+        for i in range(warmup):
+            TR.train_step(targs, student, teacher, opt, sched, batch, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss, l1, l2 = TR.train_step(targs, student, teacher, opt, sched, batch, **kw)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out[name] = {"ms_per_step": ms, "samples_per_s": Bt / (ms / 1e3), "loss1_kd": float(l1.detach()), "loss2_rank": float(l2.detach())}
+        del opt
+    flop_docs = Bt * K * flop_per_passage(Ld)
+    out["config"] = {"workload": "configs[4] per-GPU step: KD + ranking, batch %d, %d docs x %d tokens per sample" % (Bt, K, Ld),
+                     "teacher_doc_TFLOP_per_step": flop_docs / 1e12, "student_dropout": 0.1}
+    out["reencode_docs"]["teacher_doc_TFLOPs"] = flop_docs / 1e12 / ((out["reencode_docs"]["ms_per_step"] - out["lookup_doc_embs"]["ms_per_step"]) / 1e3)
+    del student, teacher, doc_embs, di, dm
+    torch.cuda.empty_cache()
+    return out
+
+
 def main_train(args):
     import torch
     import torch.distributed as dist
@@ -307,11 +360,129 @@ def extras_search(dev, index, tower, head, building, filled_rows, nq, k, d):
     with torch.no_grad():
         qtok = synthetic_tokens(min(nq, 1024), 32, 999, dev)
         Qe = tower.embed(qtok, None, head=head, seq_lens=np.full(qtok.shape[0], 32, np.int32))
-    enc_idx = FlatIPIndex(d, device=dev)
-    enc_idx.add(building._p32[:filled_rows])     # (rows of the ring no step has written yet are zeros)
-    out["search_encoded_block"] = dict(timed_search(enc_idx, Qe), corpus="the %d passages this run encoded (bench ring), %d encoded queries"
-                                       % (enc_idx.ntotal, Qe.shape[0]))
-    del enc_idx
+    torch.cuda.empty_cache()
+    # ---- (3) the same at the headline's size: 1M passages ENCODED by the model (489 batches of 2048 x 128 distinct
+    # token sequences, ~25 s), 1k encoded queries: which rung certifies, and at what rate
+    n_big = int(os.environ.get("CONVDR_BENCH_ENCODED_N", "1000000"))
+    if n_big > 0:
+        EB = 2048
+        Pe = torch.empty((n_big, d), dtype=torch.float32, device=dev)
+        lens = np.full(EB, 128, np.int32)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for s0 in range(0, n_big, EB):
+                m = min(EB, n_big - s0)
+                tok = synthetic_tokens(EB, 128, 5000 + s0 // EB, dev)
+                Pe[s0:s0 + m] = tower.embed(tok, None, head=head, seq_lens=lens)[:m]
+        torch.cuda.synchronize()
+        enc_s = time.perf_counter() - t0
+        big = FlatIPIndex(d, device=dev)
+        big.add(Pe)
+        res = timed_search(big, Qe)
+        cnt = big.last_counts(Qe.shape[0], k)
+        res.update(corpus="%d passages encoded by the random-init model (distinct 128-token sequences), %d encoded queries" % (n_big, Qe.shape[0]),
+                   encode_s=enc_s, encode_passages_per_s=n_big / enc_s,
+                   candidates_per_query={"emitted": cnt[0].float().mean().item(), "rescored_band": cnt[1].float().mean().item()})
+        pw = torch.nn.functional.normalize(Pe[:4096] - Pe[:4096].mean(0, keepdim=True), dim=1)
+        res["mean_pairwise_cosine_raw"] = float((torch.nn.functional.normalize(Pe[:2048], dim=1) @ torch.nn.functional.normalize(Pe[2048:4096], dim=1).T).mean())
+        res["mean_abs_pairwise_cosine_centred"] = float((pw[:2048] @ pw[2048:].T).abs().mean())
+        out["search_encoded_1m"] = res
+        # a mid-size block of the same distribution (the two-best-of-64 threshold sample can only aim at rank n / 128 here:
+        # expect one retry round)
+        mid = FlatIPIndex(d, device=dev)
+        mid.add(Pe[:47104].clone())
+        out["search_encoded_47k"] = dict(timed_search(mid, Qe), corpus="the first 47,104 of those passages")
+        del big, mid, Pe
+        torch.cuda.empty_cache()
+    return out
+
+
+def extras_encode_loop(dev, model, n_pass=200_000, L=128):
+    """a-8 end to end (gen_passage_embeddings.py:73-127): token cache ON DISK -> mmap reader -> token-budget batcher ->
+    pinned staging -> encoder -> pinned fp32 block -> the two block files, ragged passages of 24..128 tokens."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import torch
+    from convdr_amd import blocks, encode
+    rs = np.random.RandomState(0)
+    lens = rs.randint(24, L + 1, size=n_pass)
+    rec = np.zeros((n_pass, 4 + 4 * L), np.uint8)
+    rec[:, :4] = np.stack([(lens >> s) & 255 for s in (24, 16, 8, 0)], 1).astype(np.uint8)
+    ids = rs.randint(3, 50000, size=(n_pass, L)).astype(np.int32)
+    ids[:, 0] = 0
+    ids[np.arange(L)[None, :] >= lens[:, None]] = 0
+    rec[:, 4:] = ids.view(np.uint8).reshape(n_pass, 4 * L)
+    td = tempfile.mkdtemp(prefix="convdr_bench_enc_")
+    try:
+        base = os.path.join(td, "passages")
+        rec.tofile(base)
+        json.dump({"type": "int32", "total_number": n_pass, "embedding_size": L}, open(base + "_meta", "w"))
+        del rec, ids
+        with blocks.TokenCache(base) as cache:
+            encode.encode_shard(model, cache, batch_size=8192, token_budget=262144, max_seq_length=L)    # warm-up pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            emb, embid = encode.encode_shard(model, cache, batch_size=8192, token_budget=262144, max_seq_length=L)
+            t1 = time.perf_counter()
+            blocks.dump_block(os.path.join(td, "passage__emb_p__data_obj_0.pb"), emb)
+            blocks.dump_block(os.path.join(td, "passage__embid_p__data_obj_0.pb"), embid)
+            t2 = time.perf_counter()
+        return {"passages": n_pass, "real_tokens": int(lens.sum()), "lengths": "uniform 24..%d" % L,
+                "passages_per_s": n_pass / (t1 - t0), "real_tokens_per_s": float(lens.sum()) / (t1 - t0),
+                "passages_per_s_incl_block_write": n_pass / (t2 - t0), "block_write_s": t2 - t1,
+                "path": "token cache file (page cache warm) -> blocks.TokenCache mmap -> encode.plan_batches (262,144 packed rows "
+                        "per launch) -> pinned int32 staging -> encoder -> pinned fp32 block -> blocks.dump_block x 2"}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
+def extras_search_38m(dev, nq, k, d):
+    """BASELINE's target corpus on ONE MI355X: 38M x 768 resident (117 GB fp32 + 58 GB fp16 scan copy of 288 GB), built from
+    8 slices of 4.75M generated on the device into reserved storage; 1k queries, top-100; and the HBM-bound regime at
+    100 queries."""
+    import torch
+    from convdr_amd.search import FlatIPIndex
+    free, total = torch.cuda.mem_get_info()
+    n_slice, slices = 4_750_000, 8
+    n = n_slice * slices
+    if free < n * d * 6 + (20 << 30):
+        return {"skipped": "only %.0f GB of HBM free" % (free / 1e9)}
+    idx = FlatIPIndex(d, device=dev)
+    idx.reserve(n)
+    Q = torch.randn(nq, d, device=dev, generator=torch.Generator(device=dev).manual_seed(1234))
+    needles = torch.arange(nq, device=dev) * (n // nq) + 17
+    t0 = time.perf_counter()
+    for s in range(slices):
+        P = torch.randn(n_slice, d, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + s))
+        sel = (needles >= s * n_slice) & (needles < (s + 1) * n_slice)
+        P[needles[sel] - s * n_slice] = Q[sel]
+        idx.add(P)
+        del P
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+
+    def timed(Qx, reps):
+        D, I = idx.search_tensors(Qx, k)
+        torch.cuda.synchronize()
+        st = dict(idx.stats)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            D, I = idx.search_tensors(Qx, k)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, st, D, I
+    ms, st, D, I = timed(Q, 3)
+    ok = bool((I[:, 0] == needles).all().item() and (D[:, :-1] >= D[:, 1:]).all().item())
+    out = {"passages": n, "queries": nq, "topk": k, "build_s_8_slices_generated_on_device": build_s,
+           "ms_per_search_incl_certify": ms, "pairs_per_s": nq * n / (ms / 1e3),
+           "scan_TFLOPs_if_all_time_were_scan": 2.0 * nq * n * d / (ms / 1e3) / 1e12,
+           "queries_retried": st.get("retried"), "rounds": st.get("rounds"), "planted_needles_rank_first_and_sorted": ok,
+           "resident_GB": n * d * 6 / 1e9}
+    ms100, st100, _, _ = timed(Q[:100].contiguous(), 3)
+    out["nq100"] = {"ms_per_search": ms100, "pairs_per_s": 100 * n / (ms100 / 1e3),
+                    "scan_copy_GB_per_s": n * d * 2 / (ms100 / 1e3) / 1e9, "frac_of_hbm_peak": n * d * 2 / (ms100 / 1e3) / 1e9 / HBM_PEAK_GBS,
+                    "queries_retried": st100.get("retried")}
+    del idx
     torch.cuda.empty_cache()
     return out
 
@@ -380,6 +551,8 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
 
+    retried = [0]
+
     def step(i, timers=None):
         with torch.no_grad():
             if timers:
@@ -394,7 +567,11 @@ def main():
                 Qall = parallel.all_gather_rows(Q_local, force=world == 1)[:nq]
                 out = parallel.search_sharded_device(index, Qall, k, embid, force=world == 1)
             else:
-                out = index.search_device(Q, k)
+                # the product path: FlatIPIndex.search_tensors = first pass + certification ladder for whatever the first
+                # pass could not certify (nothing on this corpus: stats["retried"] is reported below)
+                D_, I_ = index.search_tensors(Q, k)
+                out = (D_, I_, None)
+                retried[0] += index.stats.get("retried", 0)
             if timers:
                 timers[2].record()
         return out
@@ -413,7 +590,8 @@ def main():
         out = step(i, ev[i])
     sync_all()
     el = time.perf_counter() - t0
-    status_bad = int((out[2] != 0).sum().item())
+    status_bad = int((out[2] != 0).sum().item()) if out[2] is not None else 0    # (after certification: always 0)
+    first_pass_retries = retried[0]
     emitted, band = (t.float().mean().item() for t in index.last_counts(nq, k))
     enc_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / args.steps
     ip_ms = sum(b.elapsed_time(c) for _, b, c in ev) / args.steps
@@ -457,7 +635,8 @@ def main():
                    "TFLOPs_dense_count": enc_rate * flop_per_passage(SL) / 1e12,
                    "frac_of_bf16_mfma_peak": enc_rate * flop_per_passage(SL) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
         "ip_search": {"pairs_per_s_per_gpu": nq * n / (ip_ms / 1e3), "ms_per_search_incl_fold": ip_ms,
-                      "uncertified_queries": status_bad,
+                      "uncertified_queries": status_bad, "queries_retried_after_first_pass_all_steps": first_pass_retries,
+                      "scan": "fp16 MFMA (v_mfma_f32_32x32x16_f16), eps = 1.07e-3 |q| max|p - centre|; certified by the fp64 re-score",
                       "candidates_per_query": {"emitted": emitted, "rescored_band": band}},
         "kernels": kern,
         "roofline": {"kernel": "k_gemm<EPI_GELU_BF16> (FFN1 [%d x 768] x [768 x 3072])" % rows, "bound": "mfma",
@@ -486,6 +665,7 @@ def main():
             for kn, v in pmc.items():
                 if kname in kn:
                     roof["traffic"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+                    roof["traffic_source"] = "committed PMC run of this command (profiles/r02_pmc_hbm_traffic.json), NOT measured in this run"
                     roof["traffic_note"] = ("bytes per launch at the L2<->fabric boundary (Infinity-Cache hits included), "
                                             "profiles/r02_pmc_hbm_traffic.json; algorithmic bytes = %d"
                                             % (rows * H * 2 + rows * I * 2 + H * I * 2))
@@ -502,6 +682,10 @@ def main():
             line["train_kd"] = {kk: kd[kk] for kk in keys}
             kd0 = train_kd_measure(dev, 0, 1, False, 10, 3, 64, with_kernels=False, dropout=0.0)
             line["train_kd_no_dropout"] = {kk: kd0[kk] for kk in ("value", "unit", "ms_per_step", "config", "final_loss")}
+            line["train_rank"] = train_rank_measure(dev)
+            line["encode_loop"] = extras_encode_loop(dev, random_rdot_model().to(dev).eval())
+            torch.cuda.empty_cache()
+            line["search_38m_1gpu"] = extras_search_38m(dev, nq, k, d)
         except Exception as e:      # the extras must never cost the headline line
             line["extras_error"] = "%s: %s" % (type(e).__name__, e)
     if not args.no_cpu_baseline:

@@ -200,14 +200,14 @@ class BlockView:
         self.offset = end
         self.array = np.frombuffer(self._mm, dtype, count, end).reshape(shape)
 
-    def read_rows_into(self, out, row0, row1, pool=None, parts=8):
+    def read_rows_into(self, out, row0, row1, pool=None, parts=8, wait=True):
         """Copy rows [row0, row1) of the payload into `out` (a C-contiguous ndarray of that shape, e.g. a pinned staging
         buffer) with positioned reads straight from the file -- no page faults on the mapping, and `parts` slices in
         flight on `pool` (a concurrent.futures executor; os.preadv releases the GIL), so the copy runs at several memcpy
         streams instead of one fault-bound one (measured 4.4 GB/s through the mmap on the bench host)."""
         if self._mm is None:                        # small in-frame array: already in memory
             np.copyto(out, self.array[row0:row1])
-            return
+            return []
         row_bytes = int(self.array.strides[0])
         mv = memoryview(out).cast("B")
         total = (row1 - row0) * row_bytes
@@ -223,11 +223,14 @@ class BlockView:
                 pos += got
         if pool is None or parts <= 1 or total < (8 << 20):
             rd(0, total)
-            return
+            return []
         step = (total // parts + 4095) // 4096 * 4096
         futs = [pool.submit(rd, a, min(total, a + step)) for a in range(0, total, step)]
+        if not wait:
+            return futs          # (the caller joins them: several chunks' reads in flight, FlatIPIndex._add_host_streamed)
         for f in futs:
             f.result()
+        return []
 
     def close(self):
         self.array = None

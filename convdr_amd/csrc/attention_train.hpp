@@ -261,7 +261,10 @@ struct AttnBwdArgs {
   int64_t rows;
   const float* LSE;    // [heads, ldt], base-2 (see AttnTrainArgs::lse)
   int heads;
-  const float* Dr;     // [heads, ldt]  D[h, t] = sum_d dO[t, d] O[t, d]
+  const float* Dr;     // [heads, ldt]  D[h, t] = sum_d dO[t, d] O[t, d]  (read by the dK / dV kernel)
+  const bf16_t* O;     // [rows, H] forward output (ctx).  Non-null: the dQ kernel computes D for its own queries from its dO
+  float* Dw;           //   fragment + the matching O fragment and WRITES it to Dw (= Dr) for the dK / dV kernel that follows on
+                       //   the stream -- the separate row-dot pass (12 launches per step) is gone
   int64_t ldt;
   const int32_t *cu, *lens;
   int H;
@@ -298,7 +301,26 @@ static __global__ void __launch_bounds__(256, 3) k_attention_bwd_dq(const AttnBw
   }
   const float c = a.scale * 1.44269504088896341f;
   const float lse2 = a.LSE[(int64_t)h * a.ldt + base + qc];
-  const float Di = a.Dr[(int64_t)h * a.ldt + base + qc];
+  float Di;
+  if (a.O) {   // D of this lane's query: its half of the 64 head dimensions here, the other half in lane ^ 32
+    const bf16_t* op = a.O + (base + qc) * H + h * 64 + 8 * hi;
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      union { bf16x8 v; uint32_t u[4]; } x, y;
+      x.v = dof[s];
+      y.v = *(const bf16x8*)(op + 16 * s);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc += __uint_as_float(x.u[j] << 16) * __uint_as_float(y.u[j] << 16) +
+               __uint_as_float(x.u[j] & 0xffff0000u) * __uint_as_float(y.u[j] & 0xffff0000u);
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    Di = acc;
+    if (hi == 0 && q < len) a.Dw[(int64_t)h * a.ldt + base + q] = Di;
+  } else {
+    Di = a.Dr[(int64_t)h * a.ldt + base + qc];
+  }
   f32x16 dq[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }

@@ -191,6 +191,14 @@ struct GemmTnArgs {
   int64_t rows;        // contraction length (common to the batch)
   int steps_per_split; // K steps (of 64 rows) per blockIdx.y
   int nsplit;
+  // Ordered in-place accumulation (nsplit > 1 and flags != nullptr): slice y of a tile adds its partial product into dW
+  // itself, AFTER slice y - 1 has (flags[tile] counts the slices that are done; zeroed before the launch).  The sum is
+  // evaluated in slice order whatever the timing -- deterministic like the slab form -- without the slab round trip
+  // (write + re-read of nsplit x the gradient) and its reduction launches.  It is what lets a contraction of ~140 K steps
+  // (configs[2]: 9 k token rows) be cut in two: 108 tiles of 256^2 fill 42 % of the CUs, 216 fill 84 %.  No deadlock:
+  // workgroups are dispatched in (y, x) order, so a waiting slice-y workgroup implies every slice-(y - 1) workgroup is
+  // already resident or done, and those never wait for anything younger.
+  int* flags;
 };
 
 template <class T>
@@ -218,8 +226,18 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm_tn(const GemmTnAr
     const TnStageSrc<T::TL, T::WAVES> srcL(q.Lm, q.ldl, q.NL, l0, t_begin, a.rows, w.wave, w.lane);
     gemm_tn_mainloop<T>(srcR, srcL, nk, smem, acc, w);
   }
-  const bool slab = a.nsplit > 1;
+  const bool ordered = a.nsplit > 1 && a.flags != nullptr;
+  const bool slab = a.nsplit > 1 && !ordered;
   float* out = q.out + (slab ? (size_t)blockIdx.y * q.NL * q.NR : (size_t)0);
+  if (ordered && blockIdx.y > 0) {
+    // wait for the previous slice of this tile (cdna guide, Guideline 16: poll relaxed, fence once, then plain loads)
+    if (threadIdx.x == 0) {
+      while (__hip_atomic_load(&a.flags[tile_g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)blockIdx.y)
+        __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int nt = 0; nt < T::NT; ++nt) {
     const int n = l0 + w.l_index(nt);
@@ -240,6 +258,15 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm_tn(const GemmTnAr
           *dst = o;
         }
       }
+  }
+  if (ordered && blockIdx.y + 1 < gridDim.y) {   // publish: this slice's sums are in dW
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&a.flags[tile_g], (int)blockIdx.y + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

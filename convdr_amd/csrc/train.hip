@@ -133,7 +133,15 @@ struct WgradFork {
   int init(hipStream_t st) {
     main = st;
     if (!ok) {
-      CONVDR_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      // The weight-gradient branch has no consumer before the optimizer: its stream gets the LOWEST priority, so that its
+      // workgroups take the compute units the activation-gradient chain (the step's critical path: ~230 dependent kernels
+      // that rarely fill the chip) leaves idle instead of competing with it.  (CONVDR_WGRAD_PRIO=0: default priority, A/B.)
+      int least = 0, greatest = 0;
+      static const bool low_prio = !(getenv("CONVDR_WGRAD_PRIO") && atoi(getenv("CONVDR_WGRAD_PRIO")) == 0);
+      if (low_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+        CONVDR_CHECK_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least));
+      else
+        CONVDR_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
       CONVDR_CHECK_HIP(hipEventCreateWithFlags(&prod, hipEventDisableTiming));
       CONVDR_CHECK_HIP(hipEventCreateWithFlags(&fin, hipEventDisableTiming));
       for (int i = 0; i < TRAIN_MAX_LAYERS; ++i) {
@@ -214,17 +222,39 @@ static int wgrad_launch(const WgradItem* it, int count, int64_t rows, float* sla
   }
   const int steps = (int)ceil_div64(rows, 64);
   int nsplit = 1;
+  bool ordered = false;
+  static const bool no_ordered = getenv("CONVDR_DBG_WGRAD_NO_SPLIT") != nullptr;   // A/B switch
   if (steps >= 512 && slab) {   // long contraction, few tiles: slices of >= 256 K steps until the chip is full
     nsplit = (int)ceil_div64(device_cu_count(), tiles);
     if (nsplit > steps / 256) nsplit = steps / 256;
     if ((size_t)nsplit * elems > slab_elems) nsplit = (int)(slab_elems / elems);
     if (nsplit < 1) nsplit = 1;
+  } else if (slab && !no_ordered && steps >= 64 && 2 * tiles <= device_cu_count() * (TnCfg<T>::SMEM_BYTES > 80 * 1024 ? 1 : 2) &&
+             (size_t)tiles * sizeof(int) <= slab_elems * sizeof(float)) {
+    // short contraction, the tiles fill at most half of the chip (configs[2]: 141 K steps, 108 tiles on 256 CUs):
+    // ordered in-place slices of >= 32 K steps, all workgroups resident at once (see GemmTnArgs::flags)
+    const int slots = device_cu_count() * (TnCfg<T>::SMEM_BYTES > 80 * 1024 ? 1 : 2);
+    nsplit = slots / tiles;
+    if (nsplit > steps / 32) nsplit = steps / 32;
+    if (nsplit > 4) nsplit = 4;
+    ordered = nsplit > 1;
+    if (!ordered) nsplit = 1;
   }
   g.steps_per_split = (steps + nsplit - 1) / nsplit;
   if (g.steps_per_split < 1) g.steps_per_split = 1;
   nsplit = steps > 0 ? (steps + g.steps_per_split - 1) / g.steps_per_split : 1;
   g.nsplit = nsplit;
-  if (nsplit > 1) {
+  // the operand windows are addressed with 32-bit byte offsets (buffer descriptors): a slice must stay below 2 GiB
+  int64_t max_ld = 0;
+  for (int i = 0; i < count; ++i) max_ld = std::max(max_ld, std::max(it[i].ld_x, it[i].ld_dy));
+  CONVDR_REQUIRE((int64_t)g.steps_per_split * 64 * max_ld * 2 < ((int64_t)1 << 31),
+                 "wgrad: a contraction slice of %d x 64 rows x %lld columns exceeds the 2 GiB operand window (pass a slab so "
+                 "that it can be split)", g.steps_per_split, (long long)max_ld);
+  g.flags = nullptr;
+  if (ordered && nsplit > 1) {
+    g.flags = (int*)slab;
+    CONVDR_CHECK_HIP(hipMemsetAsync(g.flags, 0, (size_t)tiles * sizeof(int), st));
+  } else if (nsplit > 1) {
     size_t o = 0;
     for (int i = 0; i < count; ++i) {
       g.p[i].out = slab + o;
@@ -236,7 +266,7 @@ static int wgrad_launch(const WgradItem* it, int count, int64_t rows, float* sla
     hipLaunchKernelGGL((k_gemm_tn<T>), dim3((unsigned)tiles, (unsigned)nsplit), dim3(T::THREADS), TnCfg<T>::SMEM_BYTES, st, g);
     CONVDR_CHECK_LAUNCH("k_gemm_tn");
   }
-  if (nsplit > 1)
+  if (nsplit > 1 && !g.flags)
     for (int i = 0; i < count; ++i) {
       const int64_t n = (int64_t)g.p[i].NL * g.p[i].NR;
       hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)(ceil_div64(n / 4, 256) < 2048 ? ceil_div64(n / 4, 256) : 2048)),
@@ -521,11 +551,10 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     g.rows = rows; g.W = (const bf16_t*)lt->wo_t; g.X = d.dYb2; g.N = H; g.K = H; g.Cb = p.dctx;
     if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
     // ---- attention ----
-    hipLaunchKernelGGL(k_attn_rowdot, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.dctx, s.ctx, rows, H, p.Drow,
-                       p.ldt);
-    CONVDR_CHECK_LAUNCH("k_attn_rowdot");
     {
-      AttnBwdArgs a{s.QKV, p.dctx, rows, s.LSE, cfg->heads, p.Drow, p.ldt, cu_seqlens, seq_lens, H, d.dQKV, 0.125f,
+      // (D[h, t] = dO . O per head is computed by the dQ kernel for its own queries and handed to the dK / dV kernel
+      //  through p.Drow: no separate row-dot pass)
+      AttnBwdArgs a{s.QKV, p.dctx, rows, s.LSE, cfg->heads, p.Drow, s.ctx, p.Drow, p.ldt, cu_seqlens, seq_lens, H, d.dQKV, 0.125f,
                     drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att)};
       ProfScope prof("attention_bwd", st);
       const dim3 grid((max_len + 127) / 128, cfg->heads, B);
@@ -677,10 +706,21 @@ extern "C" int convdr_scale_f32(float* x, int64_t n, const float* scale, convdr_
 // -> bf16 [k[i], n[i]] at out + dst_off[i] (elements).  Host arrays; one launch per matrix, no Python round trips.
 extern "C" int convdr_pack_transposed(const float* base, int count, const int64_t* src_off, const int32_t* n, const int32_t* k,
                                       const int64_t* dst_off, void* out, convdr_stream_t stream) {
-  for (int i = 0; i < count; ++i) {
-    hipLaunchKernelGGL(k_transpose_f32_bf16, dim3((k[i] + 63) / 64, (n[i] + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                       base + src_off[i], n[i], k[i], (bf16_t*)out + dst_off[i]);
+  for (int i0 = 0; i0 < count; i0 += TR_MAX_JOBS) {
+    TransposeJobs a{};
+    int tiles = 0;
+    for (int i = i0; i < count && i < i0 + TR_MAX_JOBS; ++i) {
+      TransposeJob& q = a.j[a.count++];
+      q.in = base + src_off[i];
+      q.out = (bf16_t*)out + dst_off[i];
+      q.n = n[i]; q.k = k[i];
+      q.tiles_k = (k[i] + 63) / 64;
+      tiles += q.tiles_k * ((n[i] + 63) / 64);
+      q.tile_end = tiles;
+    }
+    if (tiles == 0) continue;
+    hipLaunchKernelGGL(k_transpose_f32_bf16_batch, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
   }
-  CONVDR_CHECK_LAUNCH("k_transpose_f32_bf16(batch)");
+  CONVDR_CHECK_LAUNCH("k_transpose_f32_bf16_batch");
   return 0;
 }

@@ -26,6 +26,33 @@ __global__ void __launch_bounds__(256) k_transpose_f32_bf16(const float* __restr
   }
 }
 
+// The same for up to TR_MAX_JOBS matrices in ONE launch (the 49 transposed weight copies of a roberta-base student were 49
+// launches of ~11 us on the side stream of every training step): blockIdx.x walks the concatenated 64 x 64 tile lists.
+constexpr int TR_MAX_JOBS = 64;
+struct TransposeJob { const float* in; bf16_t* out; int n, k, tiles_k, tile_end; };
+struct TransposeJobs { TransposeJob j[TR_MAX_JOBS]; int count; };
+__global__ void __launch_bounds__(256) k_transpose_f32_bf16_batch(const TransposeJobs a) {
+  __shared__ float tile[64][65];
+  int ji = 0;
+  for (int i = 0; i + 1 < a.count; ++i)
+    if ((int)blockIdx.x >= a.j[i].tile_end) ji = i + 1;
+  const TransposeJob& q = a.j[ji];
+  const int t = (int)blockIdx.x - (ji ? a.j[ji - 1].tile_end : 0);
+  const int n = q.n, k = q.k;
+  const int k0 = (t % q.tiles_k) * 64, n0 = (t / q.tiles_k) * 64;
+  const float* __restrict__ in = q.in;
+  bf16_t* __restrict__ out = q.out;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (n0 + r < n && k0 + c < k) ? in[(int64_t)(n0 + r) * k + k0 + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;  // out row = k0 + r, col = n0 + c
+    if (k0 + r < k && n0 + c < n) out[(int64_t)(k0 + r) * n + n0 + c] = f32_to_bf16(tile[c][r]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm backward, one wave per row (grid-stride), H <= 1024.
 //   xhat = (y - mean) * rstd;  gdy = g * dy;  dx = rstd * (gdy - mean(gdy) - xhat * mean(gdy * xhat))

@@ -236,45 +236,46 @@ class FlatIPIndex:
             main = torch.cuda.current_stream()
             if getattr(self, "_copy_stream", None) is None:
                 self._copy_stream = torch.cuda.Stream(device=self.device)
-                self._stage = None
-            if self._stage is None or len(self._stage) != nbuf or self._stage[0].shape[0] < min(rows_per, n):
-                self._stage = [torch.empty((min(rows_per, n), d), dtype=torch.float32).pin_memory() for _ in range(nbuf)]
-                self._stage_ev = [None] * nbuf
+            stage, freed = _staging(self.device, min(rows_per, n), d, nbuf)
             cs = self._copy_stream
             p32, p16, plo = self._grow_for(n, want_lo)
             cs.wait_stream(main)                    # (allocation order / the copy of the old rows in _grow_for)
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             threads = max(1, min(int(self.host_copy_threads), avail))
-            if getattr(self, "_pool", None) is None or self._pool_threads != threads:
-                from concurrent.futures import ThreadPoolExecutor
-                self._pool, self._pool_threads = ThreadPoolExecutor(max_workers=threads), threads
-            pool = self._pool
-            # staging buffer i may be refilled once its H2D copy has completed.  The events outlive the call: the buffers do
-            # too, and the last copies of one add() are still in flight when the next add() starts filling them (found by
-            # tests/test_ip_search_gpu.py::test_randomised_cases_match_the_oracle: 1 run in ~500 put rows of the second
-            # block into the first)
-            freed = self._stage_ev
-            first = self._n == 0
-            for ci, s in enumerate(range(0, n, rows_per)):
-                e = min(n, s + rows_per)
+            pool = _copy_pool(threads * (nbuf - 1))
+            chunks = [(s, min(n, s + rows_per)) for s in range(0, n, rows_per)]
+
+            def fill(ci):
+                """start filling staging buffer ci % nbuf with chunk ci: `threads` positioned reads / memcpy slices"""
+                s, e = chunks[ci]
                 bi = ci % nbuf
-                buf = self._stage[bi]
+                # staging buffer bi may be refilled once its previous H2D copy has completed.  The events live with the
+                # buffers (module-level, shared by every index of the process): the last copies of one add() are still in
+                # flight when the next add() starts filling (1 run in ~500 put rows of a second block into the first
+                # before they did, tests/test_ip_search_gpu.py::test_back_to_back_streamed_adds_keep_their_rows)
                 if freed[bi] is not None:
                     freed[bi].synchronize()
-                dst = buf.numpy()[:e - s]
+                dst = stage[bi].numpy()[:e - s]
                 if reader is not None:
-                    reader(dst, s, e, pool=pool, parts=threads)          # positioned file reads, `threads` slices in flight
-                else:                                                    # an array in host memory: parallel memcpy
-                    step = (e - s + threads - 1) // threads
-                    futs = [pool.submit(np.copyto, dst[a:a + step], arr[s + a:min(e, s + a + step)]) for a in range(0, e - s, step)]
-                    for f in futs:
-                        f.result()
+                    return reader(dst, s, e, pool=pool, parts=threads, wait=False)
+                step = (e - s + threads - 1) // threads
+                return [pool.submit(np.copyto, dst[a:a + step], arr[s + a:min(e, s + a + step)]) for a in range(0, e - s, step)]
+            first = self._n == 0
+            inflight = {ci: fill(ci) for ci in range(min(nbuf - 1, len(chunks)))}
+            for ci, (s, e) in enumerate(chunks):
+                for f in inflight.pop(ci):
+                    f.result()
+                bi = ci % nbuf
                 with torch.cuda.stream(cs):
-                    p32[s:e].copy_(buf[:e - s], non_blocking=True)
+                    p32[s:e].copy_(stage[bi][:e - s], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(cs)
                 freed[bi] = ev
                 main.wait_event(ev)
+                if ci + nbuf - 1 < len(chunks):
+                    # nbuf - 1 chunks are being read while this one crosses PCIe (the copy stream never waits for the host;
+                    # with two buffers -- round 2 -- the reads of chunk i + 1 only started after chunk i had been enqueued)
+                    inflight[ci + nbuf - 1] = fill(ci + nbuf - 1)
                 if first and ci == 0:
                     # centre = column mean of the first chunk (>= 40 k passages): any centre keeps the search exact -- it
                     # shifts every score of a query by the same constant -- it only has to be close to the mean to shrink
@@ -500,6 +501,29 @@ class FlatIPIndex:
                 Dout[j] = Dj[0]
                 Iout[j] = torch.where(Ij[0] >= 0, rows[Ij[0].clamp_min(0)], Ij[0])
         return Dout, Iout
+
+
+# Pinned staging buffers and the copy thread pool are process-wide: pinning 64 MB costs ~20 ms (hipHostMalloc), i.e. a
+# fresh set per index would cost as much as loading a 3 GB block through them.
+_STAGING = {}
+_POOLS = {}
+
+
+def _staging(device, rows, d, nbuf):
+    import torch
+    key = (str(device), int(d), int(nbuf))
+    ent = _STAGING.get(key)
+    if ent is None or ent[0][0].shape[0] < rows:
+        ent = _STAGING[key] = ([torch.empty((rows, d), dtype=torch.float32).pin_memory() for _ in range(nbuf)], [None] * nbuf)
+    return ent
+
+
+def _copy_pool(threads):
+    pool = _POOLS.get(threads)
+    if pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = _POOLS[threads] = ThreadPoolExecutor(max_workers=threads)
+    return pool
 
 
 def load_block(path):

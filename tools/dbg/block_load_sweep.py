@@ -9,18 +9,18 @@ td = tempfile.mkdtemp()
 try:
     path = os.path.join(td, "b.pb")
     blocks.dump_block(path, torch.randn(n, d).numpy())
-    for chunk in (64, 128, 256):
-        for th in (8, 16, 32, 64):
+    for chunk, th, nb in ((64, 16, 2), (64, 16, 3), (64, 16, 4), (64, 32, 3), (32, 16, 4), (32, 32, 4), (128, 16, 3), (128, 32, 3), (64, 8, 4)):
+        if True:
             rates = []
             for rep in range(3):
                 with blocks.BlockView(path) as bv:
                     idx = FlatIPIndex(d)
-                    idx.host_chunk_bytes, idx.host_copy_threads = chunk << 20, th
+                    idx.host_chunk_bytes, idx.host_copy_threads, idx.host_stage_buffers = chunk << 20, th, nb
                     torch.cuda.synchronize(); t0 = time.perf_counter()
                     idx.add(bv); torch.cuda.synchronize()
                     rates.append(bv.array.nbytes / (time.perf_counter() - t0) / 1e9)
                     del idx
-            print("chunk %3d MB threads %2d: %.1f GB/s (best of 3: %.1f)" % (chunk, th, rates[-1], max(rates)), flush=True)
+            print("chunk %3d MB threads/chunk %2d buffers %d: %.1f GB/s (best of 3: %.1f)" % (chunk, th, nb, rates[-1], max(rates)), flush=True)
     # pure H2D ceiling from pinned memory
     pin = torch.empty((n // 4, d)).pin_memory(); dev = torch.empty((n // 4, d), device="cuda")
     torch.cuda.synchronize(); t0 = time.perf_counter()
