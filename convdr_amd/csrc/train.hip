@@ -133,15 +133,9 @@ struct WgradFork {
   int init(hipStream_t st) {
     main = st;
     if (!ok) {
-      // The weight-gradient branch has no consumer before the optimizer: its stream gets the LOWEST priority, so that its
-      // workgroups take the compute units the activation-gradient chain (the step's critical path: ~230 dependent kernels
-      // that rarely fill the chip) leaves idle instead of competing with it.  (CONVDR_WGRAD_PRIO=0: default priority, A/B.)
-      int least = 0, greatest = 0;
-      static const bool low_prio = !(getenv("CONVDR_WGRAD_PRIO") && atoi(getenv("CONVDR_WGRAD_PRIO")) == 0);
-      if (low_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
-        CONVDR_CHECK_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least));
-      else
-        CONVDR_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      // (a lowest-priority side stream -- so that this branch would only take the compute units the critical chain leaves
+      //  idle -- measured no different on MI355X, round 3: 11.63 vs 11.66 ms per configs[2] step)
+      CONVDR_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
       CONVDR_CHECK_HIP(hipEventCreateWithFlags(&prod, hipEventDisableTiming));
       CONVDR_CHECK_HIP(hipEventCreateWithFlags(&fin, hipEventDisableTiming));
       for (int i = 0; i < TRAIN_MAX_LAYERS; ++i) {
@@ -223,7 +217,11 @@ static int wgrad_launch(const WgradItem* it, int count, int64_t rows, float* sla
   const int steps = (int)ceil_div64(rows, 64);
   int nsplit = 1;
   bool ordered = false;
-  static const bool no_ordered = getenv("CONVDR_DBG_WGRAD_NO_SPLIT") != nullptr;   // A/B switch
+  // Ordered in-place slices are OFF by default: at the configs[2] size they cut the launch from 3.5 to 2.2 ms of kernel
+  // time per step (216 instead of 108 workgroups) and make the STEP 2 % slower (12.09 vs 11.85 ms, A/B on one box, round
+  // 3) -- the branch runs beside the activation-gradient chain, which is the critical path and loses the compute units
+  // the wider launch takes.  CONVDR_WGRAD_SPLIT=1 turns them on (convdr_wgrad callers with nothing running beside).
+  static const bool no_ordered = !(getenv("CONVDR_WGRAD_SPLIT") && atoi(getenv("CONVDR_WGRAD_SPLIT")));
   if (steps >= 512 && slab) {   // long contraction, few tiles: slices of >= 256 K steps until the chip is full
     nsplit = (int)ceil_div64(device_cu_count(), tiles);
     if (nsplit > steps / 256) nsplit = steps / 256;

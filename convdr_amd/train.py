@@ -185,6 +185,8 @@ _STATUS_RING = 64
 
 
 def _status_post(tower, ws):
+    if torch.cuda.is_current_stream_capturing():       # (hipGraph capture of a step: no host-visible side effects)
+        return
     st = tower.__dict__.get("_status")
     if st is None:
         st = tower.__dict__["_status"] = {"ring": torch.zeros(_STATUS_RING, dtype=torch.int32).pin_memory(), "pending": [], "next": 0}
@@ -200,7 +202,7 @@ def _status_post(tower, ws):
 
 def _status_poll(tower, sync=False):
     st = tower.__dict__.get("_status")
-    if not st or not st["pending"]:
+    if not st or not st["pending"] or torch.cuda.is_current_stream_capturing():
         return
     flags, left = 0, []
     for slot, ev in st["pending"]:
