@@ -109,7 +109,16 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
     if (int e = launch_gemm<EPI_QKV>(g, st, "gemm_qkv")) return e;
     AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, (int64_t)H, p.ctx, lse, 0.125f, (unsigned long long*)g_attn_trace};
     ProfScope prof("attention", st);
-    hipLaunchKernelGGL(k_attention_fwd<false>, dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
+    static const bool qlds = getenv("CONVDR_ATT_QLDS") && atoi(getenv("CONVDR_ATT_QLDS"));   // A/B switch (see k_attention_fwd)
+    if (qlds) {
+      static DeviceOnce attr_q;
+      if (attr_q.first())
+        CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_attention_fwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             ATT_SMEM_BYTES_QLDS));
+      hipLaunchKernelGGL((k_attention_fwd<false, true>), dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES_QLDS, st, a);
+    } else {
+      hipLaunchKernelGGL(k_attention_fwd<false>, dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
+    }
     CONVDR_CHECK_LAUNCH("k_attention_fwd");
   } else {
     // K and V of every token, Q of the B CLS rows only (a third of the projection and the Q / ctx traffic of the

@@ -861,8 +861,13 @@ __device__ __forceinline__ void attn_park_store(char* so, const f32x16 (&o)[2], 
 // CLS_Q (last layer of an inference pass): only the CLS row of every sequence is needed downstream.  Q is then a
 // [B, H] matrix of CLS queries (row b), the workgroup still streams the sequence's K / V^T tiles, wave 0 alone does the
 // arithmetic (all of its 32 query columns carry the same query) and one lane pair stores ctx[b] ([B, H]).
-template <bool CLS_Q>
-static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs a) {
+// QLDS: the workgroup's 128 x 64 Q tile (16 KB behind the K / V^T buffers) arrives by LDS-DMA in whole 128-byte lines
+// like the K / V^T tiles and the fragments are ds_read_b128s, instead of four 16-byte global loads per lane that touch
+// 32 rows x 32 bytes per instruction (128 of a wave's 224 line operations).  Costs a workgroup of occupancy (48 KB: three
+// per CU instead of four).
+constexpr int ATT_SMEM_BYTES_QLDS = ATT_SMEM_BYTES + 128 * 128;
+template <bool CLS_Q, bool QLDS = false>
+static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.z, h = blockIdx.y;
   const int len = a.lens[b];
@@ -881,7 +886,17 @@ static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs 
   CONVDR_ATT_TRACE(1)
 
   bf16x8 qf[4];
-  {
+  if constexpr (QLDS && !CLS_Q) {
+    // 128 rows x 128 B = 4 LDS-DMA rounds of 256 lanes x 16 B (rows past the sequence are other rows of the buffer or its
+    // slack: their scores are never stored)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r0 = (i * 4 + wave) * 8;
+      const int row = r0 + (lane >> 3);
+      const int gch = (lane & 7) ^ ((row >> 1) & 7);
+      glds16((const char*)(a.Q + (base + q0 + row) * a.ldq + h * 64) + gch * 16, smem + ATT_SMEM_BYTES + r0 * 128);
+    }
+  } else {
     const bf16_t* qp = CLS_Q ? a.Q + (int64_t)b * a.ldq + h * 64 + 8 * hi : a.Q + (base + qc) * a.ldq + h * 64 + 8 * hi;
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
@@ -918,6 +933,15 @@ static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs 
     lds_dma_wait_all();  // explicit: hipcc's automatic vmcnt wait for LDS-DMA is not reliable (gemm_nt.hpp)
     __syncthreads();     // tile `it` landed for everyone; everyone finished reading tile it-1 (the other buffer)
     if (it >= 1 && kv0 + 64 < len) stage_tile(kv0 + 64, buf ^ 1);
+    if constexpr (QLDS && !CLS_Q) {
+      if (it == 0) {   // (the Q tile was issued before the K / V^T tiles: it has landed with them)
+        const int qrow = wave * 32 + li;
+        const char* qs = smem + ATT_SMEM_BYTES + qrow * 128;
+        const int qsw = (qrow >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qs + (((2 * s + hi) ^ qsw) * 16));
+      }
+    }
     if (it == 0) { CONVDR_ATT_TRACE(2) }
     if (it == 1) { CONVDR_ATT_TRACE(3) }
     if (CLS_Q && wave != 0) continue;   // (has staged its share and passed the barrier)

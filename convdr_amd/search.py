@@ -60,7 +60,8 @@ class FlatIPIndex:
         self.host_chunk_bytes = 64 << 20       # staging-buffer size of the streamed host -> HBM path (add); 64 MB x 16
                                                # threads measured best on the bench host (tools/dbg/block_load_sweep.py)
         self.host_copy_threads = 16            # file reads / memcpy slices in flight while filling a staging buffer
-        self.host_stage_buffers = 3            # pinned staging buffers in flight (copy stream never waits for the host)
+        self.host_stage_buffers = 4            # pinned staging buffers (3 chunks being read while one crosses PCIe; 37-41 GB/s of a
+                                               # 44 GB/s pinned-H2D ceiling on the r03 box, tools/dbg/block_load_sweep.py)
         self.stats = {}
         self._s32 = self._s16 = self._slo = None
         self.reset()

@@ -169,10 +169,35 @@ def _take_workspace(tower, need, dev):
     return ent, token
 
 
+_PIN_RINGS = {}
+_PIN_SLOTS = 32
+
+
 def _pinned_upload(arr, dev):
-    """Small host array -> device tensor without blocking the host on the stream (pageable copies do)."""
-    t = torch.from_numpy(arr).pin_memory()
-    return t.to(dev, non_blocking=True)
+    """Small host array -> device tensor without blocking the host on the stream (pageable copies do).
+    The pinned staging comes from a ring of reusable slots per size class (``tensor.pin_memory()`` per call costs a host
+    allocator round trip -- and, inside a hipGraph capture, its event queries are illegal); a slot is rewritten only
+    after the copy that last read it has completed (an event per slot, 32 uploads later: never a real wait)."""
+    nbytes = max(int(arr.nbytes), 1)
+    cls = 1 << max(10, (nbytes - 1).bit_length())
+    ring = _PIN_RINGS.get(cls)
+    if ring is None:
+        ring = _PIN_RINGS[cls] = {"buf": torch.empty((_PIN_SLOTS, cls), dtype=torch.uint8).pin_memory(), "ev": [None] * _PIN_SLOTS, "next": 0}
+    i = ring["next"]
+    ring["next"] = (i + 1) % _PIN_SLOTS
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ring["ev"][i] is not None and not capturing:
+        ring["ev"][i].synchronize()
+    host = ring["buf"][i, :nbytes].view(torch.from_numpy(arr).dtype).view(arr.shape)
+    host.copy_(torch.from_numpy(arr))
+    out = host.to(dev, non_blocking=True)
+    if not capturing:
+        ev = torch.cuda.Event()
+        ev.record()
+        ring["ev"][i] = ev
+    else:
+        ring["ev"][i] = None
+    return out
 
 
 # ---- status word of the encoder forward (include/convdr_hip.h: CONVDR_ENC_STATUS_*) -------------------------------

@@ -69,5 +69,7 @@ try:
     out["host_or_launch_bound_share"] = 1.0 - out["graph_replay_ms_per_step"] / out["eager_ms_per_step"]
     out["loss_after_replays"] = float(loss)
 except Exception as e:      # capture is a measurement aid; say why it failed
+    import traceback
+    traceback.print_exc()
     out["graph_error"] = "%s: %s" % (type(e).__name__, str(e)[:400])
 print(json.dumps(out))
