@@ -383,9 +383,12 @@ def gen_encode_loop():
     print("encode-loop fixture written", e.shape, i[:5])
 
 
-def gen_train():
+def gen_train(independent_teacher=False):
     """Drive the reference's own `train()` (run_convdr_train.py:41-252) for 4 optimizer steps on a synthetic dataset:
-    KD (MSE) + ranking task, dropout 0, and record what it computed."""
+    KD (MSE) + ranking task, dropout 0, and record what it computed.
+    independent_teacher: the drivers load teacher and student from ONE checkpoint (loss1 starts at ~3e-4: a poorly
+    conditioned KD fixture); the `train_step_b.npz` variant gives the teacher its own random initialisation, so the MSE
+    term is O(1) and carries gradient from the first step."""
     import random
     import torch
     sys.argv = sys.argv[:1]
@@ -404,6 +407,16 @@ def gen_train():
     init_sd = {k: v.detach().clone() for k, v in student.state_dict().items()}
     teacher = M.MSMarcoConfigDict["rdot_nll"].model_class(cfg)
     teacher.load_state_dict(init_sd)            # the reference loads teacher and student from the same checkpoint
+    if independent_teacher:
+        torch.manual_seed(1007)
+        teacher = M.MSMarcoConfigDict["rdot_nll"].model_class(cfg)
+        with torch.no_grad():
+            for n, p in teacher.named_parameters():
+                if n.endswith("bias"):
+                    p.normal_(0, 0.05)
+                elif "LayerNorm.weight" in n or n == "norm.weight":
+                    p.add_(torch.randn_like(p) * 0.1)
+    teacher_sd = {k: v.detach().clone() for k, v in teacher.state_dict().items()}
 
     rng = np.random.RandomState(7)
     N, Lc, Lt, K = 16, 40, 12, 3
@@ -481,7 +494,10 @@ def gen_train():
         out["w0/" + k] = v.numpy()
     for k, v in student.state_dict().items():
         out["w1/" + k] = v.detach().numpy()
-    np.savez_compressed(os.path.join(HERE, "train_step.npz"), **out)
+    if independent_teacher:
+        for k, v in teacher_sd.items():
+            out["wt/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "train_step_b.npz" if independent_teacher else "train_step.npz"), **out)
     print("train fixture written: steps", gs, "loss1", log["loss1"], "loss2", log["loss2"], "norms", log["norms"])
 
 
@@ -556,6 +572,7 @@ def gen_use_mean():
 
 
 GROUPS = {"encoder": gen_encoder, "search": gen_search, "encode_loop": gen_encode_loop, "train": gen_train,
+          "train_b": lambda: gen_train(independent_teacher=True),
           "evaluate": gen_evaluate, "use_mean": gen_use_mean}
 
 if __name__ == "__main__":

@@ -196,3 +196,61 @@ def test_product_eval_dev_query_equals_oracle_on_random_rankings(tmp_path):
                      raw_sequences=[["h", "c"]] * nq)
         rows = OS.eval_dev_query_rows(qids, merged_D, merged_I, topN, offset2pid)
         assert open(out_t).read() == "".join(OS.trec_lines(rows, topN)), seed
+
+
+import pytest
+
+
+@pytest.mark.parametrize("fixture", ["train_step.npz", "train_step_b.npz"])
+def test_oracle_training_step_replays_the_reference_run(golden_dir, fixture):
+    """oracle/train.py (step body run_convdr_train.py:101-193, clip :188-189, HF AdamW utils/dpr_utils.py:80-87, linear
+    schedule :69-74) against the four optimizer steps the reference's own train() ran: same batches and sampled
+    documents -> the same losses, the same gradient norms, the same parameters after the last step."""
+    from oracle import train as OT
+    z = np.load(os.path.join(golden_dir, fixture))
+    cfg, hp = json.loads(str(z["config"])), json.loads(str(z["hyper"]))
+    NL, NH = cfg["num_hidden_layers"], cfg["num_attention_heads"]
+    sd = {k[3:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith("w0/")}
+    sdt = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("wt/")} or {k: v.clone() for k, v in sd.items()}
+    w1 = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w1/")}
+    # the parameters the reference model trains: everything the hot path reaches (pooler / classifier get no gradient)
+    names = [k for k, v in sd.items() if v.dtype.is_floating_point]
+    no_decay = ["bias", "LayerNorm.weight"]                     # utils/dpr_utils.py:81-86 (name-based groups)
+    m = {k: torch.zeros_like(sd[k]) for k in names}
+    v = {k: torch.zeros_like(sd[k]) for k in names}
+    K1 = hp["num_negatives"] + 1
+    dptr = 0
+    for step, idxs in enumerate(z["batches"]):
+        g = lambda key: torch.from_numpy(np.stack([z["ex/%d/%s" % (i, key)] for i in idxs]))
+        n_docs = len(idxs) * K1
+        rows = z["docs"][dptr:dptr + n_docs]
+        dptr += n_docs
+        Ld = int((rows >= 0).sum(1).max())
+        doc_ids = np.zeros((n_docs, Ld), np.int64)
+        doc_mask = np.zeros((n_docs, Ld), np.int64)
+        for r, row in enumerate(rows):
+            n = int((row >= 0).sum())
+            doc_ids[r, :n] = row[:n]
+            doc_mask[r, :n] = 1
+        leaf = {k: (t.clone().requires_grad_(True) if k in names else t) for k, t in sd.items()}
+        _, l1, l2 = OT.kd_losses(leaf, sdt, (g("concat_ids"), g("concat_id_mask"), g("target_ids"), g("target_id_mask")),
+                                 num_layers=NL, num_heads=NH, docs=(torch.from_numpy(doc_ids), torch.from_numpy(doc_mask)),
+                                 num_negatives=hp["num_negatives"])
+        (l1 + l2).backward()
+        assert abs(l1.item() - z["loss1"][step]) < 2e-5 * max(1.0, z["loss1"][step]), (step, l1.item(), z["loss1"][step])
+        assert abs(l2.item() - z["loss2"][step]) < 2e-5 * max(1.0, z["loss2"][step]), (step, l2.item(), z["loss2"][step])
+        grads = {k: leaf[k].grad for k in names if leaf[k].grad is not None}
+        norm = float(torch.sqrt(sum((gg.double() ** 2).sum() for gg in grads.values())))
+        assert abs(norm / z["grad_norm"][step] - 1) < 1e-4, (step, norm, z["grad_norm"][step])
+        coef = OT.clip_coef(norm, hp["max_grad_norm"])
+        lr = hp["lr"] * OT.linear_schedule(step, hp["warmup"], hp["t_total"])
+        with torch.no_grad():
+            for k, gg in grads.items():
+                wd = 0.0 if any(nd in k for nd in no_decay) else hp["weight_decay"]
+                OT.hf_adamw_step(sd[k], gg * coef, m[k], v[k], step + 1, lr, eps=hp["eps"], weight_decay=wd)
+    for k in names:
+        if k in w1:
+            # (Adam turns an element whose true gradient is rounding noise into a +-lr = 2e-4 step of arbitrary sign; the
+            #  two summation orders agree to <= 5e-6 on every element here: 2.5 % of one step)
+            np.testing.assert_allclose(sd[k].numpy(), w1[k].numpy(), rtol=0, atol=2e-5, err_msg=k)
+            assert (np.abs(sd[k].numpy() - w1[k].numpy()) > 3e-6).mean() < 1e-3, k

@@ -164,25 +164,30 @@ def test_clip_and_adamw_match_oracle():
             assert torch.allclose(p.detach().cpu(), r, rtol=2e-5, atol=1e-7)
 
 
-def test_train_steps_match_reference_run(golden_dir):
+@pytest.mark.parametrize("fixture", ["train_step.npz", "train_step_b.npz"])
+def test_train_steps_match_reference_run(golden_dir, fixture):
     """Replay the 4 optimizer steps the reference's own train() ran (tests/golden/make_golden.py::gen_train):
     same batches, same sampled documents, KD + ranking loss, clip 1.0, HF AdamW (two param groups, wd 0.01),
-    linear schedule with 1 warm-up step -- and compare losses, gradient norms and the final parameters."""
+    linear schedule with 1 warm-up step -- and compare losses, gradient norms and the final parameters.
+    train_step.npz: teacher and student from one checkpoint, as the drivers load them (loss1 starts at 2.8e-4);
+    train_step_b.npz: an independently initialised teacher (loss1 ~ 2.2: the KD term carries gradient from step 0)."""
     from types import SimpleNamespace
     from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
     from convdr_amd import train as TR
-    z = np.load(os.path.join(golden_dir, "train_step.npz"))
+    z = np.load(os.path.join(golden_dir, fixture))
+    tag = "replay" if fixture == "train_step.npz" else "replay_b"
     cfg = json.loads(str(z["config"]))
     hp = json.loads(str(z["hyper"]))
     sd0 = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w0/")}
     sd1 = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w1/")}
+    sdt = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("wt/")} or sd0
 
-    def build():
+    def build(sd):
         m = MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **cfg))
-        missing, unexpected = m.load_state_dict(sd0, strict=False)
+        missing, unexpected = m.load_state_dict(sd, strict=False)
         assert not unexpected
         return m.cuda()
-    student, teacher = build(), build()
+    student, teacher = build(sd0), build(sdt)
     args = SimpleNamespace(learning_rate=hp["lr"], adam_epsilon=hp["eps"], max_grad_norm=hp["max_grad_norm"],
                            ranking_task=True, no_mse=False, num_negatives=hp["num_negatives"], gradient_accumulation_steps=1)
     opt = TR.get_optimizer(args, student, weight_decay=hp["weight_decay"])
@@ -215,13 +220,13 @@ def test_train_steps_match_reference_run(golden_dir):
                                          torch.from_numpy(doc_ids).cuda(), torch.from_numpy(doc_mask).cuda())
             # (the reference's loss1 starts at 2.8e-4 -- student == teacher weights -- so the error is taken relative to
             #  loss1 + 1e-3: bf16 noise of two different forward paths is an absolute ~1e-5 on it)
-            margin("replay/step%d_loss1_rel" % step, abs(l1.item() - z["loss1"][step]) / (z["loss1"][step] + 1e-3), 4e-2)       # measured <= 1.9e-2
+            margin(tag + "/step%d_loss1_rel" % step, abs(l1.item() - z["loss1"][step]) / (z["loss1"][step] + 1e-3), 4e-2)       # measured <= 1.9e-2
             # logits are 768-d dots of ~27-norm vectors (|logit| ~ 10^2): bf16-level embedding error moves the CE by ~1e-2
-            margin("replay/step%d_loss2_abs" % step, abs(l2.item() - z["loss2"][step]), 4e-2)   # measured <= 1.8e-2
+            margin(tag + "/step%d_loss2_abs" % step, abs(l2.item() - z["loss2"][step]), 4e-2)   # measured <= 1.8e-2
     finally:
         TR.clip_grad_norm_ = orig
     # the ranking-loss gradient (softmax - onehot) . docs inherits the CE sensitivity above: direction cos ~0.97, norm +5 %
-    margin("replay/grad_norm_rel", float(np.max(np.abs(np.asarray(norms) / z["grad_norm"] - 1))), 0.12)   # measured 0.060
+    margin(tag + "/grad_norm_rel", float(np.max(np.abs(np.asarray(norms) / z["grad_norm"] - 1))), 0.12)   # measured 0.060
     # parameters: compare the UPDATE (w1 - w0).  Adam normalises every element's step to ~lr, so elements whose
     # gradient is rounding noise (exactly-zero true gradients such as key.bias, tiny LayerNorm terms) move by a
     # full-size pseudo-random step in BOTH implementations; the optimizer arithmetic itself is pinned bit-tight by
@@ -237,8 +242,8 @@ def test_train_steps_match_reference_run(golden_dir):
         if dr.abs().max() == 0:
             assert du.abs().max() < 1e-7, k          # untouched parameters (pooler / classifier) stay untouched
     assert nr > 0
-    margin("replay/update_1-cos", 1 - dot / (nu * nr) ** 0.5, 0.12)          # measured 0.051
-    margin("replay/update_norm_dev", abs((nu / nr) ** 0.5 - 1), 8e-3)         # measured 1.9e-3
+    margin(tag + "/update_1-cos", 1 - dot / (nu * nr) ** 0.5, 0.12)          # measured 0.051
+    margin(tag + "/update_norm_dev", abs((nu / nr) ** 0.5 - 1), 8e-3)         # measured 1.9e-3
 
 
 def test_flat_arena_training_matches_per_parameter_path():
