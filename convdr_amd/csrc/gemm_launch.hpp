@@ -61,7 +61,8 @@ inline int launch_gemm(GemmArgs a, hipStream_t st, const char* prof_name) {
   int64_t tiles256 = (int64_t)(a.N / 256) * ceil_div64(a.rows, 256);
   if (EPI == EPI_SLAB_F32 && a.k_split_len) tiles256 *= a.K / a.k_split_len;
   static const int force128 = getenv("CONVDR_DBG_TILE128") ? atoi(getenv("CONVDR_DBG_TILE128")) : 0;
-  if (fits && tiles256 >= 192 && !force128) return launch_gemm_t<EPI, Tile256>(a, st, prof_name);
+  static const int min256 = getenv("CONVDR_TILE256_MIN_TILES") ? atoi(getenv("CONVDR_TILE256_MIN_TILES")) : 192;   // A/B knob
+  if (fits && tiles256 >= min256 && !force128) return launch_gemm_t<EPI, Tile256>(a, st, prof_name);
   return launch_gemm_t<EPI, Tile128>(a, st, prof_name);
 }
 

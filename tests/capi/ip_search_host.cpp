@@ -21,7 +21,14 @@
     if ((x) != 0) { std::printf("convdr error: %s (%s:%d)\n", convdr_last_error(), __FILE__, __LINE__); return 3; } \
   } while (0)
 
+static int run(bool f16);
 int main() {
+  const int a = run(false);
+  if (a) return a;
+  return run(true);
+}
+
+static int run(bool f16) {
   const int64_t n = 20000;
   const int d = 128, nq = 37, k = 50, cap = 4096;
   std::vector<float> P((size_t)n * d), Q((size_t)nq * d);
@@ -44,10 +51,20 @@ int main() {
   hipStream_t st;
   CK(hipStreamCreate(&st));
   CV(convdr_ip_column_mean(dP, n, d, dScratch, dCentre, st));
-  CV(convdr_ip_prepare_block(dP, n, d, dCentre, dPb, nullptr, dMax, st));
   const size_t ws_bytes = convdr_ip_workspace_bytes(nq, n, d, k, cap);
   CK(hipMalloc(&dWs, ws_bytes));
-  CV(convdr_ip_search(dQ, nq, dP, dPb, nullptr, n, d, k, dMax, nullptr, cap, 0, dWs, ws_bytes, dD, dI, dStatus, dTau, st));
+  if (!f16) {   // the bf16 rung
+    CV(convdr_ip_prepare_block(dP, n, d, dCentre, dPb, nullptr, dMax, st));
+    CV(convdr_ip_search(dQ, nq, dP, dPb, nullptr, n, d, k, dMax, nullptr, cap, 0, dWs, ws_bytes, dD, dI, dStatus, dTau, st));
+  } else {      // the fp16 rung: a norm-only pass finds the power-of-two scale of the scan copy
+    CV(convdr_ip_prepare_block_f16(dP, n, d, dCentre, 1.f, nullptr, nullptr, dMax, st));
+    float mx = 0.f;
+    CK(hipMemcpyAsync(&mx, dMax, 4, hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+    const float scale = convdr_ip_f16_scale(mx);
+    CV(convdr_ip_prepare_block_f16(dP, n, d, dCentre, scale, dPb, nullptr, dMax, st));
+    CV(convdr_ip_search_f16(dQ, nq, dP, dPb, nullptr, scale, n, d, k, dMax, nullptr, cap, 0, dWs, ws_bytes, dD, dI, dStatus, dTau, st));
+  }
   CK(hipStreamSynchronize(st));
   std::vector<float> D((size_t)nq * k);
   std::vector<int64_t> I((size_t)nq * k);
@@ -83,7 +100,7 @@ int main() {
       }
     }
   }
-  std::printf(bad ? "MISMATCH %d\n" : "capi host ok: %d queries x %lld passages, top-%d exact (ABI version %d)\n", bad ? bad : nq,
-              (long long)n, k, convdr_version());
+  std::printf(bad ? "MISMATCH %d\n" : "capi host ok (%s scan): %d queries x %lld passages, top-%d exact (ABI version %d)\n",
+              bad ? (const char*)"" : (f16 ? "fp16" : "bf16"), bad ? bad : nq, (long long)n, k, convdr_version());
   return bad ? 1 : 0;
 }

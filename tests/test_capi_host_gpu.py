@@ -20,4 +20,4 @@ def test_cpp_host_calls_the_c_abi_without_torch(tmp_path):
                            "-o", exe, "-L" + lib_dir, "-lconvdr_hip", "-Wl,-rpath," + lib_dir])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "capi host ok" in out.stdout, out.stdout
+    assert "capi host ok (bf16 scan)" in out.stdout and "capi host ok (fp16 scan)" in out.stdout, out.stdout

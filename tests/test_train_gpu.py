@@ -176,6 +176,11 @@ def test_train_steps_match_reference_run(golden_dir, fixture):
     from convdr_amd import train as TR
     z = np.load(os.path.join(golden_dir, fixture))
     tag = "replay" if fixture == "train_step.npz" else "replay_b"
+    # bars at ~3x the values measured on an MI355X (round 3): (loss1 rel, loss2 abs, grad-norm rel, update 1 - cos).  With the
+    # independent teacher the MSE term is O(1) and agrees to 7e-4 (north_star: 1e-3); the CrossEntropy term keeps its
+    # sensitivity to the bf16 embedding error (|logit| ~ 1e2 on these random tiny models; 1.3e-4 relative at the
+    # configs[4] size, test_rank_step_at_configs4_per_gpu_size_matches_autograd)
+    bar1, bar2, barg, baru = (4e-2, 4e-2, 0.12, 0.12) if tag == "replay" else (2e-3, 0.12, 0.075, 0.14)
     cfg = json.loads(str(z["config"]))
     hp = json.loads(str(z["hyper"]))
     sd0 = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w0/")}
@@ -220,13 +225,13 @@ def test_train_steps_match_reference_run(golden_dir, fixture):
                                          torch.from_numpy(doc_ids).cuda(), torch.from_numpy(doc_mask).cuda())
             # (the reference's loss1 starts at 2.8e-4 -- student == teacher weights -- so the error is taken relative to
             #  loss1 + 1e-3: bf16 noise of two different forward paths is an absolute ~1e-5 on it)
-            margin(tag + "/step%d_loss1_rel" % step, abs(l1.item() - z["loss1"][step]) / (z["loss1"][step] + 1e-3), 4e-2)       # measured <= 1.9e-2
+            margin(tag + "/step%d_loss1_rel" % step, abs(l1.item() - z["loss1"][step]) / (z["loss1"][step] + 1e-3), bar1)       # measured <= 1.9e-2 / 7.2e-4
             # logits are 768-d dots of ~27-norm vectors (|logit| ~ 10^2): bf16-level embedding error moves the CE by ~1e-2
-            margin(tag + "/step%d_loss2_abs" % step, abs(l2.item() - z["loss2"][step]), 4e-2)   # measured <= 1.8e-2
+            margin(tag + "/step%d_loss2_abs" % step, abs(l2.item() - z["loss2"][step]), bar2)   # measured <= 1.8e-2 / 3.9e-2
     finally:
         TR.clip_grad_norm_ = orig
     # the ranking-loss gradient (softmax - onehot) . docs inherits the CE sensitivity above: direction cos ~0.97, norm +5 %
-    margin(tag + "/grad_norm_rel", float(np.max(np.abs(np.asarray(norms) / z["grad_norm"] - 1))), 0.12)   # measured 0.060
+    margin(tag + "/grad_norm_rel", float(np.max(np.abs(np.asarray(norms) / z["grad_norm"] - 1))), barg)   # measured 0.060 / 0.025
     # parameters: compare the UPDATE (w1 - w0).  Adam normalises every element's step to ~lr, so elements whose
     # gradient is rounding noise (exactly-zero true gradients such as key.bias, tiny LayerNorm terms) move by a
     # full-size pseudo-random step in BOTH implementations; the optimizer arithmetic itself is pinned bit-tight by
@@ -242,7 +247,7 @@ def test_train_steps_match_reference_run(golden_dir, fixture):
         if dr.abs().max() == 0:
             assert du.abs().max() < 1e-7, k          # untouched parameters (pooler / classifier) stay untouched
     assert nr > 0
-    margin(tag + "/update_1-cos", 1 - dot / (nu * nr) ** 0.5, 0.12)          # measured 0.051
+    margin(tag + "/update_1-cos", 1 - dot / (nu * nr) ** 0.5, baru)          # measured 0.051 / 0.047
     margin(tag + "/update_norm_dev", abs((nu / nr) ** 0.5 - 1), 8e-3)         # measured 1.9e-3
 
 
