@@ -664,23 +664,24 @@ def main():
     roof["achieved_hipevent"] = dom_tf
     try:
         kname = "k_gemm<1, convdr::TileCfg<2, 4, 4, 2>"
+        rnd = "r03" if os.path.exists(os.path.join(ROOT, "profiles", "r03_bench_default.kernel_stats.txt")) else "r02"
         if EB * SL == 262144:
-            for ln in open(os.path.join(ROOT, "profiles", "r02_bench_default.kernel_stats.txt")):
+            for ln in open(os.path.join(ROOT, "profiles", rnd + "_bench_default.kernel_stats.txt")):
                 if kname in ln:
                     avg_us = float(ln[80:].split()[2])
                     roof["achieved_rocprof"] = gemm_flop[dom] / avg_us / 1e6
                     roof["frac_rocprof"] = roof["achieved_rocprof"] / MFMA_BF16_PEAK_TFLOPS
                     roof["rocprof_avg_us"] = avg_us
-                    roof["rocprof_source"] = "profiles/r02_bench_default.kernel_stats.txt"
+                    roof["rocprof_source"] = "profiles/%s_bench_default.kernel_stats.txt" % rnd
                     break
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", rnd + "_pmc_hbm_traffic.json")))
             for kn, v in pmc.items():
                 if kname in kn:
                     roof["traffic"] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
-                    roof["traffic_source"] = "committed PMC run of this command (profiles/r02_pmc_hbm_traffic.json), NOT measured in this run"
+                    roof["traffic_source"] = "committed PMC run of this command (profiles/%s_pmc_hbm_traffic.json), NOT measured in this run" % rnd
                     roof["traffic_note"] = ("bytes per launch at the L2<->fabric boundary (Infinity-Cache hits included), "
-                                            "profiles/r02_pmc_hbm_traffic.json; algorithmic bytes = %d"
-                                            % (rows * H * 2 + rows * I * 2 + H * I * 2))
+                                            "profiles/%s_pmc_hbm_traffic.json; algorithmic bytes = %d"
+                                            % (rnd, rows * H * 2 + rows * I * 2 + H * I * 2))
     except Exception:
         pass
     if world == 1 and not dist_on and not args.no_extras:

@@ -5,7 +5,7 @@
 
 GRBM_GUI_ACTIVE is summed over the 8 XCDs; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GUI_ACTIVE / 8 * 1024 SIMDs);
 LdsUtil = SQ_LDS_IDX_ACTIVE / (GUI_ACTIVE / 8 * 256 CUs); conflicts = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE;
-MFMA flops = SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512.
+MFMA flops = (SQ_INSTS_VALU_MFMA_MOPS_BF16 + ..._F16) * 512.
 """
 import json
 import sys
@@ -28,6 +28,8 @@ def main(path):
         la = v.get("SQ_LDS_IDX_ACTIVE")
         bc = v.get("SQ_LDS_BANK_CONFLICT")
         mo = v.get("SQ_INSTS_VALU_MFMA_MOPS_BF16")
+        if v.get("SQ_INSTS_VALU_MFMA_MOPS_F16"):        # (the fp16 rung of the similarity scan)
+            mo = (mo or 0.0) + v["SQ_INSTS_VALU_MFMA_MOPS_F16"]
         f = lambda x: ("%7.1f%%" % x) if x is not None else "       -"
         print("%-72s %5d %10d %s %s %s %11s" % (k[:72], v.get("dispatches", 0), cyc,
                                               f(100.0 * mf / (cyc * 1024) if mf is not None else None),
