@@ -220,7 +220,7 @@ class FlatIPIndex:
     def _set_centre(self, t):
         import torch
         self._centre = torch.empty(self.d, dtype=torch.float32, device=self.device)
-        scratch = torch.empty(64 * self.d, dtype=torch.float32, device=self.device)
+        scratch = torch.empty(1024 * self.d, dtype=torch.float32, device=self.device)
         _lib.check(_lib.lib().convdr_ip_column_mean(_lib.ptr(t), t.shape[0], self.d, _lib.ptr(scratch),
                                                    _lib.ptr(self._centre), _lib.stream_ptr()), "convdr_ip_column_mean")
 

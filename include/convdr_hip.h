@@ -39,7 +39,7 @@ int convdr_prof_collect(const char* name, float* total_ms, int* launches);
  *   /root/reference/drivers/run_convdr_inference.py:353 (ctor), :180 (.add), :182 (.search), :202 (.reset)
  * ------------------------------------------------------------------------------------------ */
 
-/* Column mean of an fp32 block [n, d] (the centring vector of the scan copies).  scratch: >= 64 * d floats. */
+/* Column mean of an fp32 block [n, d] (the centring vector of the scan copies).  scratch: >= 1024 * d floats. */
 int convdr_ip_column_mean(const float* p_f32, int64_t n, int d, float* scratch, float* mean, convdr_stream_t stream);
 
 /* .add(block): build the bf16 scan copy of an fp32 block [n, d]:  p_bf16 = bf16(p - centre)  (centre: device fp32 [d]

@@ -44,7 +44,7 @@ static int run(bool f16) {
   int32_t* dStatus;
   CK(hipMalloc(&dP, P.size() * 4)); CK(hipMalloc(&dQ, Q.size() * 4)); CK(hipMalloc(&dPb, P.size() * 2));
   CK(hipMalloc(&dD, (size_t)nq * k * 4)); CK(hipMalloc(&dI, (size_t)nq * k * 8)); CK(hipMalloc(&dStatus, nq * 4));
-  CK(hipMalloc(&dTau, nq * 4)); CK(hipMalloc(&dMax, 4)); CK(hipMalloc(&dScratch, 64 * d * 4)); CK(hipMalloc(&dCentre, d * 4));
+  CK(hipMalloc(&dTau, nq * 4)); CK(hipMalloc(&dMax, 4)); CK(hipMalloc(&dScratch, 1024 * d * 4)); CK(hipMalloc(&dCentre, d * 4));
   CK(hipMemcpy(dP, P.data(), P.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dQ, Q.data(), Q.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemset(dMax, 0, 4));
