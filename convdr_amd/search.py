@@ -409,11 +409,13 @@ class FlatIPIndex:
         x3 = self.precision in ("bf16x3", "fp16x3") or (self.precision == "auto" and getattr(self, "_x3_first", False) and self.ntotal > 0)
         D, I, status, tau_retry = self.search_device(qt, k, x3=x3)
         rescaled = 0
-        if self.kind == "f16" and int((status == STATUS_RANGE).sum().item()):
+        n_range, n_bad = torch.stack([(status == STATUS_RANGE).sum(), (status != 0).sum()]).tolist()   # one host round trip
+        if self.kind == "f16" and n_range:
             self._rebuild_scaled()
             rescaled = 1
             D, I, status, tau_retry = self.search_device(qt, k, x3=x3)
-        self.stats = {"retried": int((status != 0).sum().item()), "rounds": 1, "x3_queries": nq if x3 else 0, "x3_first": bool(x3),
+            n_bad = int((status != 0).sum().item())
+        self.stats = {"retried": int(n_bad), "rounds": 1, "x3_queries": nq if x3 else 0, "x3_first": bool(x3),
                       "rescaled": rescaled}
         bad = []
         if self.stats["retried"]:
