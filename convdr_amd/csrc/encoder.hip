@@ -51,17 +51,21 @@ static int64_t g_fused_ln_min_rows = 128 * 192;   // below this the 128-token ti
 
 // Y = A W^T + bias + R, X = LayerNorm(Y): fused row-complete kernel for hidden size 768 and enough rows to fill the
 // chip, else GEMM (fp32 sums) + LayerNorm kernel.  `Yf` is the fp32 scratch of the unfused path.
+static bool fused_ln_applies(int64_t rows, int H, int K) {
+  return H == 768 && rows >= g_fused_ln_min_rows && K % LN_SLICE == 0 && K <= g_fused_ln_max_k;
+}
+// a_blocked: A is in the EPI_GELU_BLK layout (only ever set when fused_ln_applies)
 static int gemm_resid_ln(const bf16_t* W, const bf16_t* Wks, const bf16_t* A, int64_t rows, int H, int K, const float* bias,
                          const bf16_t* R, const float* gamma, const float* beta, float eps, float* Yf, bf16_t* X,
-                         const char* name, hipStream_t st) {
+                         const char* name, hipStream_t st, bool a_blocked = false) {
   // measured at 262k rows: K = 768: 0.52 ms fused vs 0.49 + 0.19 ms (GEMM + LayerNorm); K = 3072: 1.33 vs 1.17 + 0.19 ms
-  if (H == 768 && rows >= g_fused_ln_min_rows && K % LN_SLICE == 0 && K <= g_fused_ln_max_k) {
+  if (fused_ln_applies(rows, H, K)) {
     static DeviceOnce attr_done;
     if (attr_done.first())
       CONVDR_CHECK_HIP(
           hipFuncSetAttribute((const void*)k_gemm_resid_ln, hipFuncAttributeMaxDynamicSharedMemorySize, LN_SMEM_BYTES));
     GemmLnArgs a{W, A, rows, K, bias, R, gamma, beta, eps, X,
-                 K == 768 ? (unsigned long long*)g_gemm_trace_ln : nullptr, Wks};
+                 K == 768 ? (unsigned long long*)g_gemm_trace_ln : nullptr, Wks, a_blocked ? 1 : 0};
     ProfScope prof(name, st);
     hipLaunchKernelGGL(k_gemm_resid_ln, dim3((unsigned)ceil_div64(rows, TileLN::TL)), dim3(512), LN_SMEM_BYTES, st, a);
     CONVDR_CHECK_LAUNCH("k_gemm_resid_ln");
@@ -144,6 +148,16 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
   // FFN
   GemmArgs g2{};
   g2.rows = n; g2.W = (const bf16_t*)w->w1; g2.X = x1; g2.N = I; g2.K = H; g2.bias = w->b1; g2.Cb = p.Hm;
+  // FFN1 -> FFN2 through the blocked activation layout (EPI_GELU_BLK) whenever FFN2 is the row-complete kernel that can
+  // read it: the 1.6 GB tile output of FFN1 then leaves its registers in whole lines without passing through LDS.
+  // (CONVDR_HM_BLOCKED=0: row-major Hm, the round-2 path; A/B switch)
+  static const bool blk_on = !(getenv("CONVDR_HM_BLOCKED") && atoi(getenv("CONVDR_HM_BLOCKED")) == 0);
+  const bool blocked = blk_on && !cls_only && fused_ln_applies(n, H, I) && I % 256 == 0 && (I / 256) * ceil_div64(n, 256) >= 192;
+  if (blocked) {
+    if (int e = launch_gemm<EPI_GELU_BLK>(g2, st, "gemm_ffn1")) return e;
+    return gemm_resid_ln((const bf16_t*)w->w2, (const bf16_t*)w->w2_ks, p.Hm, n, H, I, w->b2, x1, w->ln2_g, w->ln2_b, c->ln_eps, p.Y,
+                         p.X, "gemm_ffn2", st, true);
+  }
   if (int e = launch_gemm<EPI_GELU_BF16>(g2, st, "gemm_ffn1")) return e;
   if (cls_only) {   // final embedding: fp32 pre-LN sums for the B CLS rows, LayerNorm'ed by the caller
     g2 = GemmArgs{};

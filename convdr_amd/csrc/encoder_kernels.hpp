@@ -247,7 +247,18 @@ static __global__ void __launch_bounds__(256) k_masked_mean(const bf16_t* __rest
 enum { EPI_BF16 = 0, EPI_GELU_BF16 = 1, EPI_RESID_F32 = 2, EPI_QKV = 3, EPI_F32 = 4,
        EPI_GELU_SAVE = 5,   // training FFN1: Cb = gelu(y) and Cb2 = y (pre-activation, for the backward)
        /* 6 was the gelu'-multiplying dgrad epilogue of round 1; that pass is k_dgelu_colsum now */
-       EPI_SLAB_F32 = 7 };  // wgrad partial: Cf[split][rows][N] = acc (no bias)
+       EPI_SLAB_F32 = 7,    // wgrad partial: Cf[split][rows][N] = acc (no bias)
+       // FFN1 of the inference forward when FFN2 is the row-complete projection + LayerNorm kernel: Cb = gelu(y) in the
+       // BLOCKED layout [rows / 32][N / 8][32 tokens][8 features] (hm_blocked_offset).  In the accumulator layout lanes
+       // (token, hi = 0 / 1) hold the two halves of a feature octet; one v_permlane32_swap per dword hands each lane a
+       // whole octet (16 bytes), and in this layout the 32 lanes of a half-wave then write 512 CONTIGUOUS bytes: the
+       // tile leaves straight from the registers in whole lines -- no LDS park, no barrier, no re-read -- and the
+       // consumer's LDS-DMA (16 tokens x 4 octets per instruction) reads whole lines too.
+       EPI_GELU_BLK = 8 };
+// element offset of (token t, feature f) in the blocked layout of a [rows, N] matrix
+__host__ __device__ inline int64_t hm_blocked_offset(int64_t t, int f, int N) {
+  return ((t >> 5) * (N >> 3) + (f >> 3)) * 256 + (t & 31) * 8 + (f & 7);
+}
 
 struct GemmArgs {
   const bf16_t* W;    // [N, K] weights (features)
@@ -654,6 +665,45 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
         CT::store_w(wb, we.lane, a.Vt + (int64_t)(n0 + (a.third0 - 2) * a.H + row0) * a.ldt + t0 + col0, a.ldt,
                     a.N - n0 - row0, a.rows - t0 - col0);
       }
+    } else if constexpr (EPI == EPI_GELU_BLK) {
+      // ---- blocked bf16 output straight from the registers (see EPI_GELU_BLK) ----
+      lds_barrier();     // (the next tile's sbias is visible; nothing of this epilogue touches LDS)
+      CONVDR_TRACE(2)
+      const int64_t rows32 = (a.rows + 31) & ~(int64_t)31;
+      const int oct_tile = a.N >> 3;
+#pragma unroll
+      for (int nt = 0; nt < T::NT; ++nt) {
+        const int64_t tb = t0 + (we.wl * T::NT + nt) * 32;   // first token of this 32-token block (wave-uniform)
+        if (nt == T::NT - 1 && has_next) {   // the prefetch is retired BEFORE the last stores enter the (in-order) queue
+          lds_dma_wait_all();
+          landed = true;
+        }
+        bf16_t* blk = a.Cb + ((tb >> 5) * oct_tile + ((n0 + we.wr * T::MT * 32) >> 3)) * 256 + we.li * 8;
+#pragma unroll
+        for (int mt = 0; mt < T::MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            uint2 o[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int g = 2 * j + e;
+              const f32x16& v = acc.c[mt][nt];
+              float y0 = v[4 * g + 0], y1 = v[4 * g + 1], y2 = v[4 * g + 2], y3 = v[4 * g + 3];   // bias included
+              gelu_tail2(y0, y1); gelu_tail2(y2, y3);
+              o[e].x = pack_bf16x2(y0, y1);
+              o[e].y = pack_bf16x2(y2, y3);
+            }
+            // lanes (li, 0) / (li, 1) hold features +0..3 / +4..7 of octets 2j (o[0]) and 2j + 1 (o[1]) of token li:
+            // after the swaps lane (li, 0) owns octet 2j, lane (li, 1) octet 2j + 1
+            const auto sx = __builtin_amdgcn_permlane32_swap(o[0].x, o[1].x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(o[0].y, o[1].y, false, false);
+            u32x4_t q;
+            q.x = sx[0]; q.y = sy[0]; q.z = sx[1]; q.w = sy[1];
+            if (tb < rows32 && n0 + we.wr * T::MT * 32 + mt * 32 < a.N)
+              *(u32x4_t*)(blk + (int64_t)(mt * 4 + 2 * j + we.hi) * 256) = q;
+          }
+      }
+      CONVDR_TRACE(6)
     } else {
       // ---- epilogue: the tile's bias slice is parked in LDS behind the stages (no vmcnt round trip per register
       // quad), all residual loads of a 32-token column block are issued up front ----

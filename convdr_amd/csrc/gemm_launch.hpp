@@ -55,7 +55,7 @@ template <int EPI>
 inline int launch_gemm(GemmArgs a, hipStream_t st, const char* prof_name) {
   CONVDR_REQUIRE(a.K % GEMM_BK == 0 && a.N % 4 == 0, "gemm: need K %% 64 == 0 and N %% 4 == 0 (K=%d N=%d)", a.K, a.N);
   if (EPI == EPI_QKV) CONVDR_REQUIRE(a.H % 128 == 0 && a.ldt % 8 == 0, "gemm: fused QKV needs hidden %% 128 == 0 (%d)", a.H);
-  if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_GELU_SAVE)
+  if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_GELU_SAVE || EPI == EPI_GELU_BLK)
     CONVDR_REQUIRE(a.N % 8 == 0, "gemm: bf16 outputs are stored 16 bytes at a time, need N %% 8 == 0 (N=%d)", a.N);
   const bool fits = a.N % 256 == 0 && (EPI != EPI_QKV || a.H % 256 == 0);
   int64_t tiles256 = (int64_t)(a.N / 256) * ceil_div64(a.rows, 256);

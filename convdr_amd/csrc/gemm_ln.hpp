@@ -32,6 +32,7 @@ struct GemmLnArgs {
   bf16_t* X;            // out [rows, 768] (may alias R: a workgroup reads its residual rows before it writes them)
   unsigned long long* trace;   // experiment: [workgroup][16] s_memtime stamps of thread 0 (or null)
   const bf16_t* Wks;    // W in K-slice-major order [K / 32][768][32] (or null: stream the row-major W)
+  int a_blocked;        // A is in the blocked layout [rows / 32][K / 8][32][8] the FFN1 epilogue EPI_GELU_BLK writes
 };
 #ifdef CONVDR_ENABLE_TRACE   // make TRACE=1: phase stamps for tools/gemm_trace_ln.py
 #define CONVDR_LN_TRACE(ph) \
@@ -113,7 +114,28 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
   StageSrc srcW = a.Wks ? ln_stage_src(a.Wks, LN_SLICE, 0, (int64_t)T::TR * (a.K / LN_SLICE), w.wave, w.lane)
                         : ln_stage_src(a.W, a.K, 0, T::TR, w.wave, w.lane);
   const uint32_t w_slice_stride = a.Wks ? T::TR * LN_SLICE * 2 : LN_SLICE * 2;
-  const StageSrc srcA = ln_stage_src(a.A, a.K, t0, a.rows, w.wave, w.lane);
+  StageSrc srcA = ln_stage_src(a.A, a.K, t0, a.rows, w.wave, w.lane);
+  uint32_t a_slice_stride = LN_SLICE * 2;
+  if (a.a_blocked) {
+    // blocked activations: a 16-token x 4-octet DMA instruction reads 4 runs of 256 contiguous bytes (whole lines; the
+    // row-major form reads 16 half lines).  Window: from this tile's first 32-token block to the end of the last block.
+    const int64_t rows32 = (a.rows + 31) & ~(int64_t)31;
+    const int64_t blk_elems = (int64_t)(a.K >> 3) * 256;            // one 32-token block, all K
+    int64_t bytes = (rows32 - t0) / 32 * blk_elems * 2;
+    bytes = bytes < 0 ? 0 : (bytes > 0xffffffffll ? 0xffffffffll : bytes);
+    const uint64_t base = (uint64_t)(a.A + (t0 >> 5) * blk_elems);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    const uint32_t nb = __builtin_amdgcn_readfirstlane((uint32_t)bytes);
+    srcA.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
+    const int wv = w.wave >= LN_DMA_FIRST ? w.wave - LN_DMA_FIRST : 0;
+    const int row = wv * 16 + (w.lane >> 2);                        // token inside the 128-token tile (one round)
+    const int gch = (w.lane & 3) ^ ((row >> 2) & 3);                // source octet of the slice for LDS chunk (lane & 3)
+    srcA.voff = (uint32_t)((row >> 5) * blk_elems * 2 + gch * 512 + (row & 31) * 16);
+    srcA.round_pitch = 0;                                           // (TL = 128 rows = one round of 8 issuing waves)
+    a_slice_stride = 4 * 512;                                       // four octets per 32-wide slice
+  }
+  static_assert(TileLN::TL == 16 * LN_DMA_WAVES, "blocked A staging assumes one DMA round per slice");
   // Three weight slots, two activation slots: the weight slice of step t + 2 is issued at step t.  With one slice in
   // flight (two stages) the stream was bound by bytes in flight / latency -- 56 KB per CU over a ~2 us loaded L2 round
   // trip = 28 GB/s per CU, 4.5 k cycles per 1,536-cycle step -- so the 48 KB of LDS this kernel left unused buy a
@@ -121,7 +143,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
   // "W(t), A(t) landed" = all but the newest weight group (LN_W_DPW instructions per issuing wave) retired.
   constexpr int LN_W_DPW = T::TR / (16 * LN_DMA_WAVES);   // weight DMA instructions per issuing wave per slice
   ln_stage32<T::TR>(srcW, 0, sW, w.wave, w_slice_stride);
-  ln_stage32<T::TL>(srcA, 0, sA, w.wave);
+  ln_stage32<T::TL>(srcA, 0, sA, w.wave, a_slice_stride);
   if (nk > 1) ln_stage32<T::TR>(srcW, 1, sW + LN_R_BYTES, w.wave, w_slice_stride);
 #ifdef CONVDR_ENABLE_TRACE   // per-wave stamps of K step 8 (and the top of step 9): a.trace[2048 * 16 + wg * 64 + wave * 8 + i]
 #define CONVDR_LN_STEP(i)                                                                                     \
@@ -139,7 +161,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
     CONVDR_LN_STEP(1)
     lds_barrier();   // NOT __syncthreads(): its fence would add vmcnt(0) and drain the slice that must stay in flight
     CONVDR_LN_STEP(2)
-    if (kt + 1 < nk) ln_stage32<T::TL>(srcA, kt + 1, sA + ((kt + 1) & 1) * LN_L_BYTES, w.wave);
+    if (kt + 1 < nk) ln_stage32<T::TL>(srcA, kt + 1, sA + ((kt + 1) & 1) * LN_L_BYTES, w.wave, a_slice_stride);
     // The 12 weight DMA instructions of slice t + 2 are issued one per MFMA pair below, not in a block here: an
     // issuing wave stalls ~70 cycles on each, and in a block those ~950 cycles come before its first MFMA (the wave
     // was the critical path of the step: 950 + 1,250 cycles); interleaved, its already-issued MFMAs run under the
