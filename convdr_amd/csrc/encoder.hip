@@ -47,6 +47,7 @@ static EncBufs enc_plan(const convdr_encoder_config* c, int64_t rows, int B, cha
 }
 
 static int64_t g_fused_ln_max_k = 1 << 30;
+static int64_t g_hm_blocked = -1;   // -1: CONVDR_HM_BLOCKED (default on); convdr_set_option("hm_blocked", 0 / 1) overrides
 static int64_t g_fused_ln_min_rows = 128 * 192;   // below this the 128-token tiles cannot fill the 256 CUs
 
 // Y = A W^T + bias + R, X = LayerNorm(Y): fused row-complete kernel for hidden size 768 and enough rows to fill the
@@ -109,12 +110,20 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
   const bf16_t *xin = p.X, *ctx = p.ctx;
   bf16_t* x1 = p.X;
   int64_t n = rows;
+  // blocked activation layouts between a producer's registers and the row-complete projection + LayerNorm kernel
+  // (EPI_GELU_BLK, k_attention_fwd<CTX_BLK>): on whenever that kernel serves the shape.  CONVDR_HM_BLOCKED=0 /
+  // convdr_set_option("hm_blocked", 0): the row-major round-2 paths
+  static const bool blk_env = !(getenv("CONVDR_HM_BLOCKED") && atoi(getenv("CONVDR_HM_BLOCKED")) == 0);
+  const bool blk_on = g_hm_blocked < 0 ? blk_env : g_hm_blocked != 0;
+  const bool ctx_blocked = blk_on && !cls_only && fused_ln_applies(rows, H, H);
   if (!cls_only) {
     if (int e = launch_gemm<EPI_QKV>(g, st, "gemm_qkv")) return e;
     AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, (int64_t)H, p.ctx, lse, 0.125f, (unsigned long long*)g_attn_trace};
     ProfScope prof("attention", st);
     static const bool qlds = getenv("CONVDR_ATT_QLDS") && atoi(getenv("CONVDR_ATT_QLDS"));   // A/B switch (see k_attention_fwd)
-    if (qlds) {
+    if (ctx_blocked) {
+      hipLaunchKernelGGL((k_attention_fwd<false, false, true>), dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
+    } else if (qlds) {
       static DeviceOnce attr_q;
       if (attr_q.first())
         CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_attention_fwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -143,7 +152,7 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
   }
   // attention output dense + residual + LayerNorm -> X1
   if (int e = gemm_resid_ln((const bf16_t*)w->wo, (const bf16_t*)w->wo_ks, ctx, n, H, H, w->bo, xin, w->ln1_g, w->ln1_b, c->ln_eps, p.Y, x1,
-                            "gemm_attn_out", st))
+                            "gemm_attn_out", st, ctx_blocked))
     return e;
   // FFN
   GemmArgs g2{};
@@ -151,7 +160,6 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
   // FFN1 -> FFN2 through the blocked activation layout (EPI_GELU_BLK) whenever FFN2 is the row-complete kernel that can
   // read it: the 1.6 GB tile output of FFN1 then leaves its registers in whole lines without passing through LDS.
   // (CONVDR_HM_BLOCKED=0: row-major Hm, the round-2 path; A/B switch)
-  static const bool blk_on = !(getenv("CONVDR_HM_BLOCKED") && atoi(getenv("CONVDR_HM_BLOCKED")) == 0);
   const bool blocked = blk_on && !cls_only && fused_ln_applies(n, H, I) && I % 256 == 0 && (I / 256) * ceil_div64(n, 256) >= 192;
   if (blocked) {
     if (int e = launch_gemm<EPI_GELU_BLK>(g2, st, "gemm_ffn1")) return e;
@@ -275,6 +283,10 @@ extern "C" int convdr_pack_kslice(const void* w_bf16, int n, int k, void* out, c
 extern "C" int convdr_set_option(const char* name, int64_t value) {
   if (strcmp(name, "fused_ln_min_rows") == 0) {
     g_fused_ln_min_rows = value;
+    return 0;
+  }
+  if (strcmp(name, "hm_blocked") == 0) {   // FFN1 -> FFN2 activation layout (EPI_GELU_BLK): 1 blocked, 0 row-major
+    g_hm_blocked = value;
     return 0;
   }
   if (strcmp(name, "fused_ln_max_k") == 0) {

@@ -916,7 +916,11 @@ __device__ __forceinline__ void attn_park_store(char* so, const f32x16 (&o)[2], 
 // 32 rows x 32 bytes per instruction (128 of a wave's 224 line operations).  Costs a workgroup of occupancy (48 KB: three
 // per CU instead of four).
 constexpr int ATT_SMEM_BYTES_QLDS = ATT_SMEM_BYTES + 128 * 128;
-template <bool CLS_Q, bool QLDS = false>
+// CTX_BLK: the output goes to the blocked layout [rows / 32][H / 8][32 tokens][8 dims] (hm_blocked_offset) that the
+// row-complete output projection stages with whole-line LDS-DMA: lanes (query, hi = 0 / 1) hold the two halves of a dim
+// octet, one v_permlane32_swap per dword gives each lane 16 bytes, and runs of 8 tokens are whole 128-byte lines
+// (sequences start at multiples of 8 rows) -- no LDS park, no barrier before the stores.
+template <bool CLS_Q, bool QLDS = false, bool CTX_BLK = false>
 static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.z, h = blockIdx.y;
@@ -1075,6 +1079,28 @@ static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(cons
           *(uint2*)(dst + dt * 32 + 8 * g + 4 * hi) = ov;
         }
     }
+    return;
+  }
+  if constexpr (CTX_BLK) {
+    const float inv = q < len ? 1.f / l : 0.f;     // alignment rows [len, plen) get zeros
+    const int64_t t = base + q;
+    bf16_t* blk = a.ctx + ((t >> 5) * (H >> 3) + h * 8) * 256 + (t & 31) * 8;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t x0 = pack_bf16x2(o[dt][8 * j + 0] * inv, o[dt][8 * j + 1] * inv);
+        const uint32_t y0 = pack_bf16x2(o[dt][8 * j + 2] * inv, o[dt][8 * j + 3] * inv);
+        const uint32_t x1 = pack_bf16x2(o[dt][8 * j + 4] * inv, o[dt][8 * j + 5] * inv);
+        const uint32_t y1 = pack_bf16x2(o[dt][8 * j + 6] * inv, o[dt][8 * j + 7] * inv);
+        const auto sx = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(y0, y1, false, false);
+        u32x4_t v;
+        v.x = sx[0]; v.y = sy[0]; v.z = sx[1]; v.w = sy[1];
+        if (q < plen) *(u32x4_t*)(blk + (dt * 4 + 2 * j + hi) * 256) = v;
+      }
+    if (q < plen && a.lse && hi == 0) a.lse[(int64_t)h * a.ldt + base + q] = q < len ? m * a.scale + logf(l) : 0.f;
+    CONVDR_ATT_TRACE(5)
     return;
   }
   __syncthreads();   // every wave is done with the last K / V^T tile: its buffers take the output tiles (attn_park_store)

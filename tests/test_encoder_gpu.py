@@ -240,6 +240,44 @@ def test_fused_gemm_layernorm_kernel_matches_oracle():
     assert cosine(a.cpu().numpy(), c.cpu().numpy()).min() > 1 - 1e-4
 
 
+def test_blocked_ffn_activation_layout_is_result_neutral():
+    """FFN1 hands its GELU output to the fused FFN2 + LayerNorm kernel in a blocked layout [rows / 32][I / 8][32][8]
+    (EPI_GELU_BLK: whole-line stores straight from the accumulator registers, whole-line LDS-DMA on the other side).
+    It is a workspace-internal choice: the embeddings must be bit-identical to the row-major path -- ragged sequences,
+    a row count that is not a multiple of 32, enough rows for 256 x 256 FFN1 tiles -- and match the oracle."""
+    from convdr_amd import _lib
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    torch.manual_seed(1)
+    model = MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig(vocab_size=1000, num_hidden_layers=2))
+    rs = np.random.RandomState(5)
+    B, Lmax = 44, 128
+    lens = rs.randint(40, Lmax + 1, size=B)
+    lens[:3] = (128, 41, 127)
+    ids = rs.randint(3, 1000, size=(B, Lmax)).astype(np.int64)
+    ids[:, 0] = 0
+    mask = np.zeros_like(ids)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+        ids[b, n:] = 0
+    assert int(((lens + 7) // 8 * 8).sum()) % 32 != 0 and int(((lens + 7) // 8 * 8).sum()) >= 3842
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = OE.rdot_nll_emb(sd, torch.from_numpy(ids), torch.from_numpy(mask), num_layers=2, num_heads=12).numpy()
+    model = model.cuda().eval()
+    L = _lib.lib()
+    out = {}
+    try:
+        _lib.check(L.convdr_set_option(b"fused_ln_min_rows", 1), "convdr_set_option")
+        for blk in (1, 0):
+            _lib.check(L.convdr_set_option(b"hm_blocked", blk), "convdr_set_option")
+            with torch.no_grad():
+                out[blk] = model.body_emb(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda())
+    finally:
+        L.convdr_set_option(b"fused_ln_min_rows", 128 * 192)
+        L.convdr_set_option(b"hm_blocked", -1)
+    assert torch.equal(out[1], out[0])
+    _check(out[1], ref, "blocked ffn layout")
+
+
 def test_pack_kslice_layout():
     """convdr_pack_kslice: out[(s * n + r) * 32 + c] == w[r, 32 s + c] (bit-exact copy, the layout k_gemm_resid_ln streams)."""
     import ctypes as C
