@@ -116,13 +116,15 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
   static const bool blk_env = !(getenv("CONVDR_HM_BLOCKED") && atoi(getenv("CONVDR_HM_BLOCKED")) == 0);
   const bool blk_on = g_hm_blocked < 0 ? blk_env : g_hm_blocked != 0;
   const bool ctx_blocked = blk_on && !cls_only && fused_ln_applies(rows, H, H);
+  const bool qk_blocked = blk_on && fused_ln_applies(rows, H, H);   // Q / K between the QKV projection and the attention
+  g.qk_blocked = qk_blocked ? 1 : 0;
   if (!cls_only) {
     if (int e = launch_gemm<EPI_QKV>(g, st, "gemm_qkv")) return e;
     AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, (int64_t)H, p.ctx, lse, 0.125f, (unsigned long long*)g_attn_trace};
     ProfScope prof("attention", st);
     static const bool qlds = getenv("CONVDR_ATT_QLDS") && atoi(getenv("CONVDR_ATT_QLDS"));   // A/B switch (see k_attention_fwd)
-    if (ctx_blocked) {
-      hipLaunchKernelGGL((k_attention_fwd<false, false, true>), dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
+    if (ctx_blocked && qk_blocked) {
+      hipLaunchKernelGGL((k_attention_fwd<false, false, true, true>), dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
     } else if (qlds) {
       static DeviceOnce attr_q;
       if (attr_q.first())
@@ -146,7 +148,8 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
     if (int e = launch_gemm<EPI_BF16>(gq, st, "gemm_qkv")) return e;
     AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, (int64_t)H, p.cls_ctx, nullptr, 0.125f, nullptr};
     ProfScope prof("attention", st);
-    hipLaunchKernelGGL(k_attention_fwd<true>, dim3(1, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
+    if (qk_blocked) hipLaunchKernelGGL((k_attention_fwd<true, false, false, true>), dim3(1, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
+    else hipLaunchKernelGGL(k_attention_fwd<true>, dim3(1, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
     CONVDR_CHECK_LAUNCH("k_attention_fwd<cls>");
     xin = p.cls_x; ctx = p.cls_ctx; x1 = p.cls_x1; n = B;
   }

@@ -275,6 +275,7 @@ struct GemmArgs {
   const float* Rf;    // EPI_RESID_F32: fp32 residual instead of R when non-null (gradient residual stream)
   bf16_t *Qo, *Ko, *Vt;  // EPI_QKV (N = 3H): Q [rows, H], K [rows, H], Vt [H, ldt]
   int third0;            // EPI_QKV: 1 = W / bias start at the K third and N = 2H (last layer: Q is needed for the CLS rows only)
+  int qk_blocked;        // EPI_QKV: Q and K go to the blocked layout [rows / 32][H / 8][32][8] (k_attention_fwd<.., QK_BLK>)
   int H;
   int64_t ldt;
   int tilesN, tilesT;
@@ -665,12 +666,19 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
         CT::store_w(wb, we.lane, a.Vt + (int64_t)(n0 + (a.third0 - 2) * a.H + row0) * a.ldt + t0 + col0, a.ldt,
                     a.N - n0 - row0, a.rows - t0 - col0);
       }
-    } else if constexpr (EPI == EPI_GELU_BLK) {
-      // ---- blocked bf16 output straight from the registers (see EPI_GELU_BLK) ----
+    } else if (EPI == EPI_GELU_BLK || (EPI == EPI_QKV && a.qk_blocked)) {
+      // ---- blocked bf16 output straight from the registers (see EPI_GELU_BLK; EPI_QKV: the Q and K thirds) ----
       lds_barrier();     // (the next tile's sbias is visible; nothing of this epilogue touches LDS)
       CONVDR_TRACE(2)
       const int64_t rows32 = (a.rows + 31) & ~(int64_t)31;
-      const int oct_tile = a.N >> 3;
+      bf16_t* dstm = a.Cb;        // destination matrix, its width in octets, the tile's first feature inside it
+      int oct_w = a.N >> 3, f0 = n0;
+      if constexpr (EPI == EPI_QKV) {
+        const int na = n0 + a.third0 * a.H;
+        dstm = na < a.H ? a.Qo : a.Ko;
+        f0 = na < a.H ? na : na - a.H;
+        oct_w = a.H >> 3;
+      }
 #pragma unroll
       for (int nt = 0; nt < T::NT; ++nt) {
         const int64_t tb = t0 + (we.wl * T::NT + nt) * 32;   // first token of this 32-token block (wave-uniform)
@@ -678,7 +686,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
           lds_dma_wait_all();
           landed = true;
         }
-        bf16_t* blk = a.Cb + ((tb >> 5) * oct_tile + ((n0 + we.wr * T::MT * 32) >> 3)) * 256 + we.li * 8;
+        bf16_t* blk = dstm + ((tb >> 5) * oct_w + ((f0 + we.wr * T::MT * 32) >> 3)) * 256 + we.li * 8;
 #pragma unroll
         for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
@@ -689,7 +697,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
               const int g = 2 * j + e;
               const f32x16& v = acc.c[mt][nt];
               float y0 = v[4 * g + 0], y1 = v[4 * g + 1], y2 = v[4 * g + 2], y3 = v[4 * g + 3];   // bias included
-              gelu_tail2(y0, y1); gelu_tail2(y2, y3);
+              if constexpr (EPI == EPI_GELU_BLK) { gelu_tail2(y0, y1); gelu_tail2(y2, y3); }
               o[e].x = pack_bf16x2(y0, y1);
               o[e].y = pack_bf16x2(y2, y3);
             }
@@ -920,7 +928,11 @@ constexpr int ATT_SMEM_BYTES_QLDS = ATT_SMEM_BYTES + 128 * 128;
 // row-complete output projection stages with whole-line LDS-DMA: lanes (query, hi = 0 / 1) hold the two halves of a dim
 // octet, one v_permlane32_swap per dword gives each lane 16 bytes, and runs of 8 tokens are whole 128-byte lines
 // (sequences start at multiples of 8 rows) -- no LDS park, no barrier before the stores.
-template <bool CLS_Q, bool QLDS = false, bool CTX_BLK = false>
+// QK_BLK: Q and K arrive in the same blocked layout (written by the QKV projection's blocked epilogue): a K tile's
+// LDS-DMA pieces are runs of 8 tokens x 16 bytes = whole lines as before, and the Q fragment loads -- four 16-byte
+// loads per lane that touched 32 rows x 32 bytes per instruction in the row-major form (128 of a wave's 224 line
+// operations) -- read 512 contiguous bytes per half-wave.  (CLS_Q keeps its [B, H] row-major query matrix.)
+template <bool CLS_Q, bool QLDS = false, bool CTX_BLK = false, bool QK_BLK = false>
 static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.z, h = blockIdx.y;
@@ -950,6 +962,11 @@ static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(cons
       const int gch = (lane & 7) ^ ((row >> 1) & 7);
       glds16((const char*)(a.Q + (base + q0 + row) * a.ldq + h * 64) + gch * 16, smem + ATT_SMEM_BYTES + r0 * 128);
     }
+  } else if constexpr (QK_BLK && !CLS_Q) {
+    const int64_t t = base + qc;
+    const bf16_t* qp = a.Q + ((t >> 5) * (a.H >> 3) + h * 8 + hi) * 256 + (t & 31) * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 2 * s * 256);   // dims 16 s + 8 hi .. + 7 = octet 2 s + hi
   } else {
     const bf16_t* qp = CLS_Q ? a.Q + (int64_t)b * a.ldq + h * 64 + 8 * hi : a.Q + (base + qc) * a.ldq + h * 64 + 8 * hi;
 #pragma unroll
@@ -972,7 +989,12 @@ static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(cons
       const int r0 = (i * 4 + wave) * 8;
       const int row = r0 + (lane >> 3);
       const int gch = (lane & 7) ^ ((row >> 1) & 7);
-      glds16((const char*)(a.K + (base + kv0 + row) * a.ldq + h * 64) + gch * 16, smem + buf * ATT_TILE_PAIR + r0 * 128);
+      if constexpr (QK_BLK) {
+        const int64_t t = base + kv0 + row;
+        glds16((const char*)(a.K + ((t >> 5) * (a.H >> 3) + h * 8 + gch) * 256 + (t & 31) * 8), smem + buf * ATT_TILE_PAIR + r0 * 128);
+      } else {
+        glds16((const char*)(a.K + (base + kv0 + row) * a.ldq + h * 64) + gch * 16, smem + buf * ATT_TILE_PAIR + r0 * 128);
+      }
       glds16((const char*)(a.Vt + (int64_t)(h * 64 + row) * a.ldt + base + kv0) + gch * 16,
              smem + buf * ATT_TILE_PAIR + 64 * 128 + r0 * 128);
     }
