@@ -33,3 +33,7 @@ du -sh $O
 python tools/pmc_table.py $O/pmc_mfma_lds.json > $O/pmc_mfma_lds.summary.txt
 python tools/pmc_table.py $O/pmc_mfma_train_kd.json > $O/pmc_mfma_train_kd.summary.txt
 timeout 300 python tools/dbg/train_graph_replay.py 0.1 > $O/train_graph_replay.json 2>/dev/null
+( export CONVDR_BENCH_SHARE_GPU=1 CONVDR_BENCH_BACKEND=gloo
+  timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --steps 4 --warmup 1 --passages 300000 2>$O/reh2_es.err | tail -1 > $O/rehearsal_2ranks_1gpu_gloo_encode_search.json
+  timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29572 bench.py --gpus 2 --steps 4 --warmup 1 --workload train_kd 2>$O/reh2_kd.err | tail -1 > $O/rehearsal_2ranks_1gpu_gloo_train_kd.json )
+for v in 0 1; do CONVDR_HM_BLOCKED=$v python tools/enc_kernels.py 2>/dev/null | tail -1; done > $O/blocked_layouts_ab.txt
