@@ -18,7 +18,7 @@ def main(seed0=0, cases=60):
         n = int(rs.choice([1, 7, 64, 300, 4097, 9000, 33000, 70000]))
         nq = int(rs.choice([1, 3, 32, 130, 257]))
         k = int(rs.choice([1, 10, 100, 100, 333]))
-        kind = rs.randint(5)
+        kind = rs.randint(7)
         P = rs.randn(n, d).astype(np.float32)
         if kind == 1:                      # exact duplicates -> ties
             src = rs.randint(0, n, size=n // 2 + 1)
@@ -32,6 +32,11 @@ def main(seed0=0, cases=60):
         Q = rs.randn(nq, d).astype(np.float32)
         if kind == 4:
             Q = np.round(Q * 2) / 2
+        elif kind == 5:                    # any magnitude: the fp16 scan copy / queries are moved by powers of two
+            P = (P * np.float32(10.0 ** rs.uniform(-18, 10))).astype(np.float32)
+            Q = (Q * np.float32(10.0 ** rs.uniform(-8, 8))).astype(np.float32)
+        elif kind == 6:                    # later rows far longer than the first ones: CONVDR_IP_RANGE -> rebuilt copy
+            P[n // 2:] *= np.float32(10.0 ** rs.uniform(1, 4))
         idx = FlatIPIndex(d)
         cuts = sorted(set([0, n] + list(rs.randint(0, n + 1, size=rs.randint(0, 3)))))
         for a, b in zip(cuts[:-1], cuts[1:]):
