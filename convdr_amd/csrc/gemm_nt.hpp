@@ -101,6 +101,11 @@ struct TileCfg {
 };
 using Tile128 = TileCfg<2, 2, 2, 2>;
 using Tile256 = TileCfg<2, 4, 4, 2>;
+// 256 x 128: the similarity scan with at most 128 queries (ip_topk.hip).  That regime is HBM-bound -- the passage block
+// streams once, the query tile is re-read from L2 -- so what matters is passage bytes in flight per CU: on the R3 K step
+// (3 R slots of 32 KB + 2 L slots of 16 KB = 128 KB) two 32 KB passage chunks are in flight per CU, against 2 x 16 KB with
+// two 128 x 128 workgroups.
+using TileTall = TileCfg<2, 4, 4, 1>;
 
 template <class T>
 struct GemmAcc {

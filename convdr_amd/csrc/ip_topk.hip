@@ -839,8 +839,10 @@ __global__ void __launch_bounds__(IP_SELECT_THREADS) k_ip_select(int k, int cap,
 // ------------------------------------------------------------------------------------------
 // host-side plan shared by workspace sizing and the search call
 // ------------------------------------------------------------------------------------------
+constexpr int IP_TILE_128 = 0, IP_TILE_256 = 1, IP_TILE_TALL = 2;
 struct IpPlan {
-  bool big;          // 256 x 256 scan tiles (more than 128 queries), else 128 x 128
+  int big;           // scan tile class: IP_TILE_256 (more than 128 queries), IP_TILE_TALL (256 passages x 128 queries: the
+                     // HBM-bound regime), IP_TILE_128 (CONVDR_DBG_SCAN_TILE128: the round-1/2 small tile)
   int tr, tl;        // tile extent over passages / queries
   int nq_pad, nQt, nPt;
   int mode;          // -1: no threshold pass (n <= cap), else IP_MODE_FULL / IP_MODE_TOP2
@@ -853,9 +855,9 @@ struct IpPlan {
 static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
   IpPlan p;
   static const bool dbg_small = getenv("CONVDR_DBG_SCAN_TILE128") != nullptr;
-  p.big = nq > 128 && !dbg_small;
-  p.tr = p.big ? Tile256::TR : Tile128::TR;
-  p.tl = p.big ? Tile256::TL : Tile128::TL;
+  p.big = dbg_small ? IP_TILE_128 : (nq > 128 ? IP_TILE_256 : IP_TILE_TALL);
+  p.tr = p.big == IP_TILE_128 ? Tile128::TR : Tile256::TR;
+  p.tl = p.big == IP_TILE_256 ? Tile256::TL : Tile128::TL;
   p.nq_pad = (nq + p.tl - 1) / p.tl * p.tl;
   p.nQt = p.nq_pad / p.tl;
   p.nPt = (int)ceil_div64(n, p.tr);
@@ -937,10 +939,15 @@ static int launch_scan_t(const ScanArgs& a, hipStream_t st) {
   return a.Plo ? launch_scan_x<MODE, T, true, F16>(a, st) : launch_scan_x<MODE, T, false, F16>(a, st);
 }
 
+template <int MODE, bool F16>
+static int launch_scan_k(const ScanArgs& a, int tile, hipStream_t st) {
+  if (tile == IP_TILE_256) return launch_scan_t<MODE, Tile256, F16>(a, st);
+  if (tile == IP_TILE_TALL) return launch_scan_t<MODE, TileTall, F16>(a, st);
+  return launch_scan_t<MODE, Tile128, F16>(a, st);
+}
 template <int MODE>
-static int launch_scan(const ScanArgs& a, bool big, int kind, hipStream_t st) {
-  if (kind == IP_KIND_F16) return big ? launch_scan_t<MODE, Tile256, true>(a, st) : launch_scan_t<MODE, Tile128, true>(a, st);
-  return big ? launch_scan_t<MODE, Tile256, false>(a, st) : launch_scan_t<MODE, Tile128, false>(a, st);
+static int launch_scan(const ScanArgs& a, int tile, int kind, hipStream_t st) {
+  return kind == IP_KIND_F16 ? launch_scan_k<MODE, true>(a, tile, st) : launch_scan_k<MODE, false>(a, tile, st);
 }
 
 }  // namespace convdr
