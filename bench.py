@@ -651,7 +651,7 @@ def main():
                       "scan": "fp16 MFMA (v_mfma_f32_32x32x16_f16), eps = 1.07e-3 |q| max|p - centre|; certified by the fp64 re-score",
                       "candidates_per_query": {"emitted": emitted, "rescored_band": band}},
         "kernels": kern,
-        "roofline": {"kernel": "k_gemm<EPI_GELU_BF16> (FFN1 [%d x 768] x [768 x 3072])" % rows, "bound": "mfma",
+        "roofline": {"kernel": "k_gemm<EPI_GELU_BLK> (FFN1 [%d x 768] x [768 x 3072], bias + GELU + blocked bf16 output fused)" % rows, "bound": "mfma",
                      "achieved": dom_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": dom_tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None},
     }
@@ -663,7 +663,7 @@ def main():
     roof = line["roofline"]
     roof["achieved_hipevent"] = dom_tf
     try:
-        kname = "k_gemm<1, convdr::TileCfg<2, 4, 4, 2>"
+        kname = "k_gemm<8, convdr::TileCfg<2, 4, 4, 2>"      # EPI_GELU_BLK on 256 x 256 tiles (k_gemm<1, ..> before round 3)
         rnd = "r03" if os.path.exists(os.path.join(ROOT, "profiles", "r03_bench_default.kernel_stats.txt")) else "r02"
         if EB * SL == 262144:
             for ln in open(os.path.join(ROOT, "profiles", rnd + "_bench_default.kernel_stats.txt")):
