@@ -278,7 +278,15 @@ constexpr int ATTB_DKV_SMEM = 2 * (2 * ATT_TILE + 512);   // two sets of (Q tile
 
 // dQ: workgroup = 128 queries of one (sequence, head); loop over 64-key tiles.  S^T = K Q^T and dP^T = V dO^T have lane =
 // query, registers = keys; dQ^T = K^T dS^T with dS^T fed from registers and K^T read transposed from the K tile.
-static __global__ void __launch_bounds__(256, 3) k_attention_bwd_dq(const AttnBwdArgs a) {
+// Two workgroups per CU, not three: at the 168-register cap of three the kernel spilled 73 VGPRs into its key loop
+// (scratch traffic per tile; 83 us per launch at the configs[2] size) -- found with the PMC pass of round 3
+// (SQ_INSTS_VMEM_WR 34 per wave for a kernel with 5 stores).  At 256 registers it needs 215, no spills: 58 us, the KD step
+// 11.63 -> 11.14 ms.  The kernel is latency-bound either way; the third resident workgroup bought less than the
+// spills cost.
+#ifndef CONVDR_ATT_DQ_OCC
+#define CONVDR_ATT_DQ_OCC 2
+#endif
+static __global__ void __launch_bounds__(256, CONVDR_ATT_DQ_OCC) k_attention_bwd_dq(const AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.z, h = blockIdx.y;
   const int len = a.lens[b];

@@ -1104,8 +1104,13 @@ static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(cons
     return;
   }
   if constexpr (CTX_BLK) {
-    const float inv = q < len ? 1.f / l : 0.f;     // alignment rows [len, plen) get zeros
-    const int64_t t = base + q;
+    // (lane-dependent addresses from an opaque copy of the thread index: otherwise hipcc computes them ahead of the key
+    //  loop and spills them across it -- 7 VGPR spills at this kernel's 128-register budget)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int q_e = q0 + (tid_e >> 6) * 32 + (tid_e & 31), hi_e = (tid_e >> 5) & 1;
+    const float inv = q_e < len ? 1.f / l : 0.f;     // alignment rows [len, plen) get zeros
+    const int64_t t = base + q_e;
     bf16_t* blk = a.ctx + ((t >> 5) * (H >> 3) + h * 8) * 256 + (t & 31) * 8;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -1119,9 +1124,9 @@ static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(cons
         const auto sy = __builtin_amdgcn_permlane32_swap(y0, y1, false, false);
         u32x4_t v;
         v.x = sx[0]; v.y = sy[0]; v.z = sx[1]; v.w = sy[1];
-        if (q < plen) *(u32x4_t*)(blk + (dt * 4 + 2 * j + hi) * 256) = v;
+        if (q_e < plen) *(u32x4_t*)(blk + (dt * 4 + 2 * j + hi_e) * 256) = v;
       }
-    if (q < plen && a.lse && hi == 0) a.lse[(int64_t)h * a.ldt + base + q] = q < len ? m * a.scale + logf(l) : 0.f;
+    if (q_e < plen && a.lse && hi_e == 0) a.lse[(int64_t)h * a.ldt + base + q_e] = q_e < len ? m * a.scale + logf(l) : 0.f;
     CONVDR_ATT_TRACE(5)
     return;
   }
