@@ -506,15 +506,31 @@ static __global__ void __launch_bounds__(256, 2) k_attention_bwd_dkv(const AttnB
         tr_frag<32>(tQ, trl, 0, qf[0][0]); tr_frag<32>(tQ, trl, 1, qf[0][1]);
       }
       // register r <-> query q0 + 32 qt + 16 (r >> 3) + 8 hi + (r & 7)
+      // Dropout masks (this lane's key, the register's query): the mask hash covers a PAIR of keys, and the two lanes of
+      // a pair would each compute it for every query.  Instead the even-key lane hashes query r, the odd-key lane query
+      // r + 1, and they swap (one DPP move): one hash per two elements, as in the kernels whose lanes are queries -- the
+      // hash was 2/3 of this kernel's VALU work.  (Same mask: drop_pair of csrc/dropout.hpp.)
+      float dmask[16];
+      if (a.drop.thresh) {
+        const int odd = kc & 1;   // (k0 + 32 wave is even: the lane parity is the key parity)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int qi_mine = 32 * qt + 16 * (r >> 3) + 8 * hi + (r & 7) + odd;
+          const uint32_t h_mine = drop_mix32((drop_att_base(base + q0 + qi_mine, gridDim.y, h) + (uint32_t)(kc >> 1)) ^ a.drop.key);
+          const uint32_t h_other = (uint32_t)__builtin_amdgcn_mov_dpp((int)h_mine, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+          const uint32_t h0 = odd ? h_other : h_mine, h1 = odd ? h_mine : h_other;   // hashes of queries r, r + 1
+          const uint32_t t0 = odd ? (h0 >> 16) : (h0 & 0xffffu), t1 = odd ? (h1 >> 16) : (h1 & 0xffffu);
+          dmask[r] = t0 >= a.drop.thresh ? a.drop.scale : 0.f;
+          dmask[r + 1] = t1 >= a.drop.thresh ? a.drop.scale : 0.f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = 32 * qt + 16 * (r >> 3) + 8 * hi + (r & 7);
         float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -sLse[qi]));
         float dpr = dp[r], pd = p;
-        if (a.drop.thresh) {   // this lane's key, the register's query: P_dropped = P * m feeds dV, dP = dP_dropped * m feeds dS
-          float m0, m1;
-          drop_pair(a.drop, drop_att_base(base + q0 + qi, gridDim.y, h) + (uint32_t)(kc >> 1), m0, m1);
-          const float m = (kc & 1) ? m1 : m0;
+        if (a.drop.thresh) {   // P_dropped = P * m feeds dV, dP = dP_dropped * m feeds dS
+          const float m = dmask[r];
           dpr *= m;
           pd *= m;
         }
