@@ -194,7 +194,8 @@ struct WgradItem {
   float* dW;
 };
 template <class T>
-static int wgrad_launch(const WgradItem* it, int count, int64_t rows, float* slab, size_t slab_elems, hipStream_t st) {
+static int wgrad_launch(const WgradItem* it, int count, int64_t rows, float* slab, size_t slab_elems, hipStream_t st,
+                        int tail_split) {
   static DeviceOnce attr_done;
   if (attr_done.first())
     CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_tn<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -222,7 +223,14 @@ static int wgrad_launch(const WgradItem* it, int count, int64_t rows, float* sla
   // 3) -- the branch runs beside the activation-gradient chain, which is the critical path and loses the compute units
   // the wider launch takes.  CONVDR_WGRAD_SPLIT=1 turns them on (convdr_wgrad callers with nothing running beside).
   static const bool no_ordered = !(getenv("CONVDR_WGRAD_SPLIT") && atoi(getenv("CONVDR_WGRAD_SPLIT")));
-  if (steps >= 512 && slab) {   // long contraction, few tiles: slices of >= 256 K steps until the chip is full
+  if (tail_split > 1 && slab && steps < 512) {
+    // the last branch of a backward pass has nothing left to hide behind: one tile's whole contraction (~250 us at
+    // configs[2]) is the tail of the step, so it is cut into slab slices that fill the idle chip
+    nsplit = tail_split;
+    if (nsplit > steps / 32) nsplit = steps / 32;
+    if ((size_t)nsplit * elems > slab_elems) nsplit = (int)(slab_elems / elems);
+    if (nsplit < 1) nsplit = 1;
+  } else if (steps >= 512 && slab) {   // long contraction, few tiles: slices of >= 256 K steps until the chip is full
     nsplit = (int)ceil_div64(device_cu_count(), tiles);
     if (nsplit > steps / 256) nsplit = steps / 256;
     if ((size_t)nsplit * elems > slab_elems) nsplit = (int)(slab_elems / elems);
@@ -273,7 +281,8 @@ static int wgrad_launch(const WgradItem* it, int count, int64_t rows, float* sla
     }
   return 0;
 }
-static int wgrad_batch(const WgradItem* it, int count, int64_t rows, float* slab, size_t slab_elems, hipStream_t st) {
+static int wgrad_batch(const WgradItem* it, int count, int64_t rows, float* slab, size_t slab_elems, hipStream_t st,
+                       int tail_split = 0) {
   CONVDR_REQUIRE(count >= 1 && count <= TN_MAX_PROBLEMS, "wgrad: %d problems in one batch", count);
   bool big = true;
   for (int i = 0; i < count; ++i) {
@@ -283,8 +292,8 @@ static int wgrad_batch(const WgradItem* it, int count, int64_t rows, float* slab
   }
   // 256 x 256 tiles (half the L2 -> LDS bytes per FLOP of 128 x 128: at two 128-tiles per CU the operand stream, not the
   // matrix pipe, bounded the round-1 kernel) unless a matrix is smaller than a tile
-  if (big) return wgrad_launch<Tile256>(it, count, rows, slab, slab_elems, st);
-  return wgrad_launch<Tile128>(it, count, rows, slab, slab_elems, st);
+  if (big) return wgrad_launch<Tile256>(it, count, rows, slab, slab_elems, st, tail_split);
+  return wgrad_launch<Tile128>(it, count, rows, slab, slab_elems, st, tail_split);
 }
 static int wgrad(const bf16_t* dY, int N, int64_t ld_dy, const bf16_t* X, int K, int64_t ld_x, int64_t rows, const TrainBufs& p,
                  float* dW, hipStream_t st) {
@@ -583,7 +592,8 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
                                   {d.dYb, H, H, s.Hm, I, I, lg->w2},            // Y2 = Hm W2^T
                                   {d.dQKV, 3 * H, 3 * H, s.Xin, H, H, lg->wqkv},   // QKV = Xin Wqkv^T
                                   {d.dYb2, H, H, s.ctx, H, H, lg->wo}};         // Y1 = ctx Wo^T
-      if (int e = wgrad_batch(items, 4, rows, p.slab, p.slab_elems, ss)) return e;
+      static const int tail_split = getenv("CONVDR_WGRAD_TAIL_SPLIT") ? atoi(getenv("CONVDR_WGRAD_TAIL_SPLIT")) : 2;
+      if (int e = wgrad_batch(items, 4, rows, p.slab, p.slab_elems, ss, l == 0 && fork_wgrad ? tail_split : 0)) return e;
     }
     // ---- QKV projection: QKV = Xin Wqkv^T + bqkv;  dXin = dQKV Wqkv (bf16 tile output) + dY1 (residual branch, fp32) ----
     g = GemmArgs{};
