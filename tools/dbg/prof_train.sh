@@ -9,5 +9,6 @@ cd $R
 DB=$(find gpurun_out/$TAG/prof_kd -name "*.db" | head -1)
 python tools/rocpd_summary.py $DB > gpurun_out/$TAG/train_kd.kernel_stats.txt
 python tools/train_timeline.py $DB > gpurun_out/$TAG/train_kd.timeline.txt
+python tools/train_timeline.py $DB --dispatches > gpurun_out/$TAG/train_kd.dispatches.txt
 find gpurun_out/$TAG -name "*.db" -delete
 cat gpurun_out/$TAG/train_kd.timeline.txt

@@ -25,6 +25,7 @@ cd $R
 python tools/rocpd_summary.py $(find $O/prof -name "*.db" | head -1) > $O/bench_default.kernel_stats.txt
 python tools/rocpd_summary.py $(find $O/prof_kd -name "*.db" | head -1) > $O/train_kd.kernel_stats.txt
 python tools/train_timeline.py $(find $O/prof_kd -name "*.db" | head -1) > $O/train_kd.timeline.txt
+python tools/train_timeline.py $(find $O/prof_kd -name "*.db" | head -1) --dispatches > $O/train_kd.dispatches.txt
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write > $O/pmc_hbm_traffic.json
 python tools/pmc_summary.py $O/pmc_mfma $O/pmc_lds > $O/pmc_mfma_lds.json
 python tools/pmc_summary.py $O/pmc_mfma_kd > $O/pmc_mfma_train_kd.json

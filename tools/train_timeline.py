@@ -56,5 +56,24 @@ def main(path):
         print("  %-70s %4d %9.1f us  avg %7.1f" % (n, c, t / 1e3, t / 1e3 / c))
 
 
+def dispatches(path):
+    """Every kernel of the last step in start order: start offset, duration, queue, grid, name (one line each)."""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    qcol = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else "0")
+    rows = db.execute("select name, start, end, %s, grid_x, workgroup_x from kernels order by start" % qcol).fetchall()
+    ends = [i for i, r in enumerate(rows) if "k_adamw_hf" in r[0]]
+    if len(ends) < 2:
+        return
+    step = rows[ends[-2] + 1:ends[-1] + 1]
+    t0 = step[0][1]
+    for n, s, e, q, gx, wx in step:
+        print("%9.1f us  +%7.1f us  q%-2s wg %5d  %s" % ((s - t0) / 1e3, (e - s) / 1e3, q, (gx or 0) // max(wx or 1, 1),
+                                                       n.replace("convdr::", "").replace("void ", "")[:90]))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) > 2 and sys.argv[2] == "--dispatches":
+        dispatches(sys.argv[1])
+    else:
+        main(sys.argv[1])
