@@ -164,6 +164,40 @@ def test_clip_and_adamw_match_oracle():
             assert torch.allclose(p.detach().cpu(), r, rtol=2e-5, atol=1e-7)
 
 
+def test_adamw_and_grad_norm_on_slices_that_are_not_16_byte_aligned():
+    """convdr_adamw_step / convdr_grad_norm_clip through the C-ABI on views that start 4, 8 and 12 bytes into an
+    allocation and whose lengths are not multiples of 4: the kernels take 16-byte accesses only when every array allows it
+    (head / tail elements and the unaligned case go one float at a time); results must not depend on the placement."""
+    from convdr_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(11)
+    scratch = torch.empty(1024, dtype=torch.float32, device="cuda")
+    for off, n in ((1, 4099), (2, 1), (3, 70001), (0, 6), (1, 1 << 20)):
+        host = [rs.randn(n).astype(np.float32) for _ in range(2)] + [np.abs(rs.randn(n)).astype(np.float32) * 1e-3]
+        p0, g0, v0 = host
+        m0 = (rs.randn(n) * 1e-2).astype(np.float32)
+        bufs = [torch.zeros(n + 8, dtype=torch.float32, device="cuda") for _ in range(4)]
+        views = [b[off:off + n] for b in bufs]
+        for v, h in zip(views, (p0, g0, m0, v0)):
+            v.copy_(torch.from_numpy(h))
+        out = torch.empty(2, dtype=torch.float32, device="cuda")
+        _lib.check(L.convdr_grad_norm_clip(_lib.ptr(views[1]), n, 1.0, 0.5, _lib.ptr(scratch), _lib.ptr(out), 0,
+                                           _lib.stream_ptr()), "convdr_grad_norm_clip")
+        norm = float(np.sqrt((0.25 * g0.astype(np.float64) ** 2).sum()))
+        assert abs(out[0].item() - norm) <= 2e-6 * norm + 1e-12, (off, n)
+        coef = 0.5 * min(1.0, 1.0 / (norm + 1e-6))
+        assert abs(out[1].item() - coef) <= 1e-6 * coef
+        _lib.check(L.convdr_adamw_step(_lib.ptr(views[0]), _lib.ptr(views[1]), _lib.ptr(views[2]), _lib.ptr(views[3]), n,
+                                       1e-3, 0.9, 0.999, 1e-8, 0.01, 3, 1, _lib.ptr(out[1:2]), _lib.stream_ptr()),
+                   "convdr_adamw_step")
+        p, m, v = torch.from_numpy(p0.copy()), torch.from_numpy(m0.copy()), torch.from_numpy(v0.copy())
+        OT.hf_adamw_step(p, torch.from_numpy(g0) * out[1].item(), m, v, 3, 1e-3, eps=1e-8, weight_decay=0.01)
+        assert torch.allclose(views[0].cpu(), p, rtol=2e-5, atol=1e-7), (off, n)
+        assert torch.allclose(views[2].cpu(), m, rtol=2e-5, atol=1e-9) and torch.allclose(views[3].cpu(), v, rtol=2e-5, atol=1e-12)
+        for b, h in zip(bufs, (p0, g0, m0, v0)):     # nothing outside the slice was touched
+            assert b[:off].abs().sum().item() == 0 and b[off + n:].abs().sum().item() == 0
+
+
 @pytest.mark.parametrize("fixture", ["train_step.npz", "train_step_b.npz"])
 def test_train_steps_match_reference_run(golden_dir, fixture):
     """Replay the 4 optimizer steps the reference's own train() ran (tests/golden/make_golden.py::gen_train):
