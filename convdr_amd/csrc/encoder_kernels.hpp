@@ -584,7 +584,8 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
     CONVDR_TRACE(0)
     int idle;   // the stage the last K step did not read
     if constexpr (R3) {
-      st = gemm_nt_mainloop_r3<T>(src3, c.swap ? a.K : klen, smem, acc, w, st, true, true, landed);
+      st = gemm_nt_mainloop_r3<T>(src3, c.swap ? a.K : klen, smem, acc, w, st, true, true, landed,
+                                  (a.trace && trace_tile == 8) ? a.trace + ((size_t)blockIdx.x * 64 + 56) * 16 : nullptr);
       idle = 0;
       sbias = sbias_of(st);   // free: neither read by the last step nor a prologue target
     } else {

@@ -317,14 +317,47 @@ __device__ __forceinline__ int gemm_nt_mainloop(const TileSrc<T>& src, int K, ch
 #ifndef CONVDR_R3_RSUB
 #define CONVDR_R3_RSUB 3
 #endif
+#ifndef CONVDR_R3_RSUB_OLD
+#define CONVDR_R3_RSUB_OLD 1
+#endif
+#ifndef CONVDR_R3_RSUB_YOUNG
+#define CONVDR_R3_RSUB_YOUNG 3
+#endif
 static_assert(CONVDR_R3_LSUB <= CONVDR_R3_RSUB, "the L chunk must be issued before the R chunk (counted vmcnt)");
+// CONVDR_R3_ROLES: who issues the LDS-DMA of the R3 K step.  0: every wave its share of both chunks.  1: the OLDER wave of
+// each SIMD (waves 0 .. WAVES / 2 - 1) issues the whole R chunk of step t + 2 after its MFMAs, the YOUNGER the whole L chunk
+// of step t + 1 at the top of the step.  The s_memtime anatomy of a step (tools/dbg/gemm_trace_blk.py) shows the older
+// wave -- served first by the matrix pipe -- done with its 32 MFMAs after ~1.25 k cycles and then ~1.15 k cycles in the
+// barrier, while the younger needs ~2.0 k, issues ITS R share (~210 cycles) only then, and everybody waits for it: with
+// roles the R issue rides in the older wave's idle time and the older wave starts its MFMAs without L issue in front.
+#ifndef CONVDR_R3_ROLES
+#define CONVDR_R3_ROLES 1
+#endif
+#if CONVDR_R3_ROLES && CONVDR_R3_VARIANT != 0
+#error "the between-the-rows variants of the R3 step assume that every wave issues its share"
+#endif
 template <class T>
-struct TileSrcAll {   // all waves issue
+struct R3Issue {
+  static constexpr bool ROLES = CONVDR_R3_ROLES && T::WAVES == 8;
+  static constexpr int RW = ROLES ? T::WAVES / 2 : T::WAVES;    // waves issuing an R chunk (from wave 0)
+  static constexpr int LW = ROLES ? T::WAVES / 2 : T::WAVES;    // waves issuing an L chunk ...
+  static constexpr int LFIRST = ROLES ? T::WAVES / 2 : 0;       // ... from this wave on
+  static constexpr int R_DPW = T::TR / (8 * RW);                // DMA instructions per issuing wave per R chunk
+  static __device__ __forceinline__ bool issues_r(int wave) { return !ROLES || wave < RW; }
+  static __device__ __forceinline__ void r(const StageSrc& s, int kt, char* dst, int wave) {
+    if (issues_r(wave)) gemm_stage<T::TR, RW, 0>(s, kt, dst, wave);
+  }
+  static __device__ __forceinline__ void l(const StageSrc& s, int kt, char* dst, int wave) {
+    gemm_stage<T::TL, LW, LFIRST>(s, kt, dst, wave);   // (returns at once for waves below LFIRST)
+  }
+};
+template <class T>
+struct TileSrcAll {   // all waves issue (or by role, see CONVDR_R3_ROLES)
   StageSrc R, L;
   __device__ __forceinline__ TileSrcAll(const bf16_t* __restrict__ Rp, int64_t ldr, int64_t nR, const bf16_t* __restrict__ Lp,
                                         int64_t ldl, int64_t nL, int64_t r0, int64_t l0, const WavePos<T>& w)
-      : R(gemm_stage_src<T::WAVES, 0>(Rp, ldr, r0, nR, w.wave, w.lane)),
-        L(gemm_stage_src<T::WAVES, 0>(Lp, ldl, l0, nL, w.wave, w.lane)) {}
+      : R(gemm_stage_src<R3Issue<T>::RW, 0>(Rp, ldr, r0, nR, w.wave, w.lane)),
+        L(gemm_stage_src<R3Issue<T>::LW, R3Issue<T>::LFIRST>(Lp, ldl, l0, nL, w.wave, w.lane)) {}
 };
 // Slot state of the R3 loop: R chunk 0 of a tile goes to R slot `rs`, chunk 1 to rs + 1 (mod 3), L chunk 0 to L slot `ls`.
 struct R3Slots { int rs, ls; };
@@ -336,9 +369,9 @@ __device__ __forceinline__ void gemm_r3_prologue(const TileSrcAll<T>& src, int K
                                                  bool with_r1 = true) {
   char* sR = smem;
   char* sL = smem + 3 * T::R_BYTES;
-  gemm_stage<T::TR, T::WAVES, 0>(src.R, 0, sR + s.rs * T::R_BYTES, w.wave);
-  gemm_stage<T::TL, T::WAVES, 0>(src.L, 0, sL + s.ls * T::L_BYTES, w.wave);
-  if (with_r1 && K > GEMM_BK) gemm_stage<T::TR, T::WAVES, 0>(src.R, 1, sR + (s.rs == 2 ? 0 : s.rs + 1) * T::R_BYTES, w.wave);
+  R3Issue<T>::r(src.R, 0, sR + s.rs * T::R_BYTES, w.wave);
+  R3Issue<T>::l(src.L, 0, sL + s.ls * T::L_BYTES, w.wave);
+  if (with_r1 && K > GEMM_BK) R3Issue<T>::r(src.R, 1, sR + (s.rs == 2 ? 0 : s.rs + 1) * T::R_BYTES, w.wave);
 }
 // Returns the slot state for the NEXT tile: once a wave is back from this call, the R slots `rs`, rs + 1 and the L slot
 // `ls` of the returned state are free (the last step read the other ones), so the next tile's prologue may be issued
@@ -347,8 +380,9 @@ template <class T, bool F16 = false>
 __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src, int K, char* smem, GemmAcc<T>& acc,
                                                        const WavePos<T>& w, R3Slots st = R3Slots{0, 0},
                                                        bool prologue_in_flight = false, bool r1_deferred = false,
-                                                       bool stage0_landed = false) {
-  constexpr int R_DPW = T::TR / (8 * T::WAVES);   // DMA instructions per wave per R chunk
+                                                       bool stage0_landed = false, unsigned long long* step_trace = nullptr) {
+  constexpr int R_DPW = R3Issue<T>::R_DPW;   // DMA instructions per issuing wave per R chunk
+  const bool r_wave = R3Issue<T>::issues_r(w.wave);   // (wave-uniform) this wave has R chunks in flight
   const int nk = K / GEMM_BK;
   const int sw = (w.lane >> 1) & 7;
   const int offR = (w.wr * T::MT * 32 + w.li) * 128;
@@ -360,14 +394,24 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
 #if defined(CONVDR_R3_STATIC_PRIO)   // experiment (cdna guide T5, static form): the younger half of the workgroup at priority 1
   if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= T::THREADS / 2) __builtin_amdgcn_s_setprio(1);
 #endif
+#ifdef CONVDR_ENABLE_TRACE   // stamps of K step 6 (and the top of step 7) for lane 0 of every wave: [wave][0..6]
+#define CONVDR_R3_STEP(i) \
+  if (step_trace && kt == 6 + (i) / 6 && w.lane == 0) step_trace[w.wave * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define CONVDR_R3_STEP(i)
+#endif
   for (int kt = 0; kt < nk; ++kt) {
+    CONVDR_R3_STEP(6)
+    CONVDR_R3_STEP(0)
     // (r1_deferred: at step 0 only chunks 0 are in flight -- there is no newer R group to leave outstanding;
     //  stage0_landed: the caller has already waited for them, ahead of its epilogue's stores)
     if (kt == 0 && (r1_deferred || stage0_landed)) {
       if (!stage0_landed) lds_dma_wait_all();
-    } else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R_DPW) : "memory");
-    else lds_dma_wait_all();
+    } else if (kt + 1 < nk && r_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R_DPW) : "memory");
+    else lds_dma_wait_all();   // (a wave without R chunks has only the L chunk of this step outstanding)
+    CONVDR_R3_STEP(1)
     lds_barrier();
+    CONVDR_R3_STEP(2)
     const char* tR = sR + rs * T::R_BYTES + offR;
     const char* tL = sL + ls * T::L_BYTES + offL;
     bf16x8 fa[2][T::MT], fb[2][T::NT];
@@ -380,7 +424,7 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
     };
     load_frags(0, 0);
     constexpr int L_DPW = T::TL / (8 * T::WAVES);
-    static_assert(L_DPW <= T::MT && R_DPW <= T::MT, "one DMA instruction per MFMA row of a sub-step");
+    static_assert(CONVDR_R3_VARIANT == 0 || (L_DPW <= T::MT && R_DPW <= T::MT), "one DMA instruction per MFMA row of a sub-step");
     const bool issue_l = kt + 1 < nk, issue_r = kt + 2 < nk;
     char* l_dst = sL + (ls ^ 1) * T::L_BYTES;
     const int rnext = rs == 0 ? 2 : rs - 1;   // (kt + 2) % 3
@@ -389,9 +433,10 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
     // MFMAs; 1 = both ride between the MFMA rows (L in sub-step 0, R in sub-step 3); 2 = L block, R between the rows
 #if CONVDR_R3_VARIANT != 1
     __builtin_amdgcn_sched_barrier(0);
-    if (r1_deferred && kt == 0 && issue_l) gemm_stage<T::TR, T::WAVES, 0>(src.R, 1, sR + (rs == 2 ? 0 : rs + 1) * T::R_BYTES, w.wave);
-    if (issue_l) gemm_stage<T::TL, T::WAVES, 0>(src.L, kt + 1, l_dst, w.wave);
+    if (r1_deferred && kt == 0 && issue_l) R3Issue<T>::r(src.R, 1, sR + (rs == 2 ? 0 : rs + 1) * T::R_BYTES, w.wave);
+    if (issue_l) R3Issue<T>::l(src.L, kt + 1, l_dst, w.wave);
 #endif
+    CONVDR_R3_STEP(3)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       if (s + 1 < 4) load_frags(s + 1, (s + 1) & 1);
@@ -412,15 +457,21 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
 #if CONVDR_R3_VARIANT == 1 || CONVDR_R3_VARIANT == 2
         if (s == CONVDR_R3_RSUB && issue_r && i < R_DPW) gemm_stage_round<T::WAVES>(src.R, i, kt + 2, r_dst, w.wave);
 #endif
+#if CONVDR_R3_VARIANT == 3   // the two waves of a SIMD issue their R chunk in DIFFERENT sub-steps (one stalls, the other multiplies)
+        if (s == (w.wave < T::WAVES / 2 ? CONVDR_R3_RSUB_OLD : CONVDR_R3_RSUB_YOUNG) && issue_r && i < R_DPW)
+          gemm_stage_round<T::WAVES>(src.R, i, kt + 2, r_dst, w.wave);
+#endif
       }
 #if defined(CONVDR_R3_SETPRIO)
       __builtin_amdgcn_s_setprio(0);
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
+    CONVDR_R3_STEP(4)
 #if CONVDR_R3_VARIANT == 0
-    if (issue_r) gemm_stage<T::TR, T::WAVES, 0>(src.R, kt + 2, r_dst, w.wave);
+    if (issue_r) R3Issue<T>::r(src.R, kt + 2, r_dst, w.wave);
 #endif
+    CONVDR_R3_STEP(5)
     rs = rs == 2 ? 0 : rs + 1;
     ls ^= 1;
   }
