@@ -50,11 +50,21 @@ struct GemmLnArgs {
 // otherwise the younger half issues everything up front (TileCfg::DMA_WAVES)
 constexpr int LN_DMA_WAVES = (CONVDR_LN_DMA_LATE || !CONVDR_DMA_YOUNG_HALF) ? 8 : 4;
 constexpr int LN_DMA_FIRST = 8 - LN_DMA_WAVES;
+// CONVDR_LN_ROLES (with CONVDR_LN_DMA_LATE): as CONVDR_R3_ROLES in gemm_nt.hpp -- the older wave of each SIMD (waves 0-3),
+// which the matrix pipe serves first and which then idles in the barrier, issues the WHOLE weight slice of step t + 2 after
+// its MFMAs; the younger (waves 4-7) issues the activation slice of step t + 1 at the top of the step.
+#ifndef CONVDR_LN_ROLES
+#define CONVDR_LN_ROLES 1
+#endif
+constexpr bool LN_ROLES = CONVDR_LN_ROLES && CONVDR_LN_DMA_LATE;
+constexpr int LN_W_WAVES = LN_ROLES ? 4 : LN_DMA_WAVES, LN_W_FIRST = LN_ROLES ? 0 : LN_DMA_FIRST;   // weight slices
+constexpr int LN_A_WAVES = LN_ROLES ? 4 : LN_DMA_WAVES, LN_A_FIRST = LN_ROLES ? 4 : LN_DMA_FIRST;   // activation slices
 
+template <int WAVES = LN_DMA_WAVES, int FIRST = LN_DMA_FIRST>   // WAVES issuing waves, the first of which is wave FIRST
 __device__ __forceinline__ StageSrc ln_stage_src(const bf16_t* __restrict__ G, int64_t ld, int64_t row0, int64_t nrows,
                                                   int wave, int lane) {
   StageSrc s;
-  wave = wave >= LN_DMA_FIRST ? wave - LN_DMA_FIRST : 0;
+  wave = wave >= FIRST ? wave - FIRST : 0;
   int64_t bytes = (nrows - row0) * ld * 2;
   bytes = bytes < 0 ? 0 : (bytes > 0xffffffffll ? 0xffffffffll : bytes);
   const uint64_t base = (uint64_t)(G + row0 * ld);
@@ -65,20 +75,20 @@ __device__ __forceinline__ StageSrc ln_stage_src(const bf16_t* __restrict__ G, i
   const int row = wave * 16 + (lane >> 2);
   const int gch = (lane & 3) ^ ((row >> 2) & 3);
   s.voff = (uint32_t)(row * ld * 2) + gch * 16;
-  s.round_pitch = __builtin_amdgcn_readfirstlane((uint32_t)(16 * LN_DMA_WAVES * ld * 2));
+  s.round_pitch = __builtin_amdgcn_readfirstlane((uint32_t)(16 * WAVES * ld * 2));
   return s;
 }
 
-template <int ROWS>
+template <int ROWS, int WAVES = LN_DMA_WAVES, int FIRST = LN_DMA_FIRST>
 __device__ __forceinline__ void ln_stage32(const StageSrc& s, int ks, char* lds_tile, int wave,
                                            uint32_t slice_stride = LN_SLICE * 2) {
-  if (LN_DMA_FIRST > 0 && wave < LN_DMA_FIRST) return;   // wave-uniform
-  wave -= LN_DMA_FIRST;
-  constexpr int ROUNDS = ROWS / (16 * LN_DMA_WAVES);
-  static_assert(ROUNDS * 16 * LN_DMA_WAVES == ROWS, "rows must be a multiple of 16 x issuing waves");
+  if (wave < FIRST || wave >= FIRST + WAVES) return;   // wave-uniform
+  wave -= FIRST;
+  constexpr int ROUNDS = ROWS / (16 * WAVES);
+  static_assert(ROUNDS * 16 * WAVES == ROWS, "rows must be a multiple of 16 x issuing waves");
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds_tile + (i * LN_DMA_WAVES + wave) * 16 * 64), 16, s.voff,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds_tile + (i * WAVES + wave) * 16 * 64), 16, s.voff,
                                              i * s.round_pitch + ks * slice_stride, 0, 0);
 }
 
@@ -111,10 +121,10 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
   // 768 half cache lines, every line is fetched twice (once per slice) and the 112 KB that leaves L2 per CU per step
   // made this kernel L2-bandwidth-bound (5.2 k cycles per 1,536-cycle step); in slice-major order a slice is 48 KB of
   // whole lines.
-  StageSrc srcW = a.Wks ? ln_stage_src(a.Wks, LN_SLICE, 0, (int64_t)T::TR * (a.K / LN_SLICE), w.wave, w.lane)
-                        : ln_stage_src(a.W, a.K, 0, T::TR, w.wave, w.lane);
+  StageSrc srcW = a.Wks ? ln_stage_src<LN_W_WAVES, LN_W_FIRST>(a.Wks, LN_SLICE, 0, (int64_t)T::TR * (a.K / LN_SLICE), w.wave, w.lane)
+                        : ln_stage_src<LN_W_WAVES, LN_W_FIRST>(a.W, a.K, 0, T::TR, w.wave, w.lane);
   const uint32_t w_slice_stride = a.Wks ? T::TR * LN_SLICE * 2 : LN_SLICE * 2;
-  StageSrc srcA = ln_stage_src(a.A, a.K, t0, a.rows, w.wave, w.lane);
+  StageSrc srcA = ln_stage_src<LN_A_WAVES, LN_A_FIRST>(a.A, a.K, t0, a.rows, w.wave, w.lane);
   uint32_t a_slice_stride = LN_SLICE * 2;
   if (a.a_blocked) {
     // blocked activations: a 16-token x 4-octet DMA instruction reads 4 runs of 256 contiguous bytes (whole lines; the
@@ -128,23 +138,26 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
     const uint32_t nb = __builtin_amdgcn_readfirstlane((uint32_t)bytes);
     srcA.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
-    const int wv = w.wave >= LN_DMA_FIRST ? w.wave - LN_DMA_FIRST : 0;
-    const int row = wv * 16 + (w.lane >> 2);                        // token inside the 128-token tile (one round)
+    const int wv = w.wave >= LN_A_FIRST ? w.wave - LN_A_FIRST : 0;
+    const int row = wv * 16 + (w.lane >> 2);                        // token inside a round of 16 x LN_A_WAVES tokens
     const int gch = (w.lane & 3) ^ ((row >> 2) & 3);                // source octet of the slice for LDS chunk (lane & 3)
     srcA.voff = (uint32_t)((row >> 5) * blk_elems * 2 + gch * 512 + (row & 31) * 16);
-    srcA.round_pitch = 0;                                           // (TL = 128 rows = one round of 8 issuing waves)
+    // rounds are 16 * LN_A_WAVES tokens apart: a multiple of 32, so (row & 31) is round-independent and a round advances
+    // whole 32-token blocks
+    srcA.round_pitch = __builtin_amdgcn_readfirstlane((uint32_t)((16 * LN_A_WAVES / 32) * blk_elems * 2));
     a_slice_stride = 4 * 512;                                       // four octets per 32-wide slice
   }
-  static_assert(TileLN::TL == 16 * LN_DMA_WAVES, "blocked A staging assumes one DMA round per slice");
+  static_assert((16 * LN_A_WAVES) % 32 == 0 && TileLN::TL % (16 * LN_A_WAVES) == 0, "blocked A staging: rounds of whole 32-token blocks");
   // Three weight slots, two activation slots: the weight slice of step t + 2 is issued at step t.  With one slice in
   // flight (two stages) the stream was bound by bytes in flight / latency -- 56 KB per CU over a ~2 us loaded L2 round
   // trip = 28 GB/s per CU, 4.5 k cycles per 1,536-cycle step -- so the 48 KB of LDS this kernel left unused buy a
   // second weight slice in flight.  Issue order per step: A(t+1), then W(t+2); completion is in issue order, so
   // "W(t), A(t) landed" = all but the newest weight group (LN_W_DPW instructions per issuing wave) retired.
-  constexpr int LN_W_DPW = T::TR / (16 * LN_DMA_WAVES);   // weight DMA instructions per issuing wave per slice
-  ln_stage32<T::TR>(srcW, 0, sW, w.wave, w_slice_stride);
-  ln_stage32<T::TL>(srcA, 0, sA, w.wave, a_slice_stride);
-  if (nk > 1) ln_stage32<T::TR>(srcW, 1, sW + LN_R_BYTES, w.wave, w_slice_stride);
+  constexpr int LN_W_DPW = T::TR / (16 * LN_W_WAVES);   // weight DMA instructions per issuing wave per slice
+  const bool w_wave = w.wave >= LN_W_FIRST && w.wave < LN_W_FIRST + LN_W_WAVES;   // (wave-uniform) this wave has weight slices in flight
+  ln_stage32<T::TR, LN_W_WAVES, LN_W_FIRST>(srcW, 0, sW, w.wave, w_slice_stride);
+  ln_stage32<T::TL, LN_A_WAVES, LN_A_FIRST>(srcA, 0, sA, w.wave, a_slice_stride);
+  if (nk > 1) ln_stage32<T::TR, LN_W_WAVES, LN_W_FIRST>(srcW, 1, sW + LN_R_BYTES, w.wave, w_slice_stride);
 #ifdef CONVDR_ENABLE_TRACE   // per-wave stamps of K step 8 (and the top of step 9): a.trace[2048 * 16 + wg * 64 + wave * 8 + i]
 #define CONVDR_LN_STEP(i)                                                                                     \
   if (a.trace && kt == 8 + (i) / 5 && w.lane == 0 && blockIdx.x < 256)                                        \
@@ -156,12 +169,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
   for (int kt = 0; kt < nk; ++kt) {
     CONVDR_LN_STEP(5)
     CONVDR_LN_STEP(0)
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LN_W_DPW) : "memory");
-    else lds_dma_wait_all();
+    if (kt + 1 < nk && w_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LN_W_DPW) : "memory");
+    else lds_dma_wait_all();   // (a wave without weight slices has only this step's activation slice outstanding)
     CONVDR_LN_STEP(1)
     lds_barrier();   // NOT __syncthreads(): its fence would add vmcnt(0) and drain the slice that must stay in flight
     CONVDR_LN_STEP(2)
-    if (kt + 1 < nk) ln_stage32<T::TL>(srcA, kt + 1, sA + ((kt + 1) & 1) * LN_L_BYTES, w.wave, a_slice_stride);
+    if (kt + 1 < nk) ln_stage32<T::TL, LN_A_WAVES, LN_A_FIRST>(srcA, kt + 1, sA + ((kt + 1) & 1) * LN_L_BYTES, w.wave, a_slice_stride);
     // The 12 weight DMA instructions of slice t + 2 are issued one per MFMA pair below, not in a block here: an
     // issuing wave stalls ~70 cycles on each, and in a block those ~950 cycles come before its first MFMA (the wave
     // was the critical path of the step: 950 + 1,250 cycles); interleaved, its already-issued MFMAs run under the
@@ -195,7 +208,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
     // every wave issues its share of slice t + 2 once its MFMAs of this step are in the pipe: the ~60-cycle issue
     // stalls then cost no matrix-pipe time (two steps of slack for the landing), and no wave has more DMA work than
     // another
-    if (issue_w) ln_stage32<T::TR>(srcW, kt + 2, w_dst, w.wave, w_slice_stride);
+    if (issue_w) ln_stage32<T::TR, LN_W_WAVES, LN_W_FIRST>(srcW, kt + 2, w_dst, w.wave, w_slice_stride);
 #endif
     CONVDR_LN_STEP(4)
   }
