@@ -407,7 +407,7 @@ struct CTile {
         const int row = (i0 + j) * RPI + r0;
         bf16_t* pr = dst + (int64_t)row * ld + c * 8;
         if (row < row_limit && nv > 0) {
-          if (nv >= 8) *(u32x4_t*)pr = v[j];
+          if (nv >= 8) store16<CONVDR_NT_CTILE>(pr, v[j]);
           else *(uint2*)pr = make_uint2(v[j].x, v[j].y);
         }
       }
@@ -433,7 +433,7 @@ struct CTile {
         const int row = (i0 + j) * RPI + r0;
         bf16_t* pr = dst + (int64_t)row * ld + c * 8;
         if (row < row_limit && nv > 0) {
-          if (nv >= 8) *(u32x4_t*)pr = v[j];
+          if (nv >= 8) store16<CONVDR_NT_CTILE>(pr, v[j]);
           else *(uint2*)pr = make_uint2(v[j].x, v[j].y);
         }
       }
@@ -709,7 +709,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
             u32x4_t q;
             q.x = sx[0]; q.y = sy[0]; q.z = sx[1]; q.w = sy[1];
             if (tb < rows32 && n0 + we.wr * T::MT * 32 + mt * 32 < a.N)
-              *(u32x4_t*)(blk + (int64_t)(mt * 4 + 2 * j + we.hi) * 256) = q;
+              store16<CONVDR_NT_GEMM_BLK>(blk + (int64_t)(mt * 4 + 2 * j + we.hi) * 256, q);
           }
       }
       CONVDR_TRACE(6)
@@ -865,6 +865,12 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
 // Online softmax over key tiles; lanes q and q+32 hold the two halves of a query's keys / head dims and
 // exchange only the running max and the final row sum.  Writes LSE (natural log) when lse != nullptr.
 // ---------------------------------------------------------------------------------------------
+#ifndef CONVDR_NT_ATT_Q
+#define CONVDR_NT_ATT_Q 1
+#endif
+#ifndef CONVDR_ATT_KV_AUX
+#define CONVDR_ATT_KV_AUX 2   // cache policy of the K / V^T tile DMA of k_attention_fwd
+#endif
 struct AttnArgs {
   const bf16_t *Q, *K, *Vt;
   int64_t ldt;
@@ -967,7 +973,13 @@ static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(cons
     const int64_t t = base + qc;
     const bf16_t* qp = a.Q + ((t >> 5) * (a.H >> 3) + h * 8 + hi) * 256 + (t & 31) * 8;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qp + 2 * s * 256);   // dims 16 s + 8 hi .. + 7 = octet 2 s + hi
+    for (int s = 0; s < 4; ++s) {   // dims 16 s + 8 hi .. + 7 = octet 2 s + hi
+#if CONVDR_NT_ATT_Q
+      qf[s] = __builtin_nontemporal_load((const bf16x8*)(qp + 2 * s * 256));   // (read by this workgroup only)
+#else
+      qf[s] = *(const bf16x8*)(qp + 2 * s * 256);
+#endif
+    }
   } else {
     const bf16_t* qp = CLS_Q ? a.Q + (int64_t)b * a.ldq + h * 64 + 8 * hi : a.Q + (base + qc) * a.ldq + h * 64 + 8 * hi;
 #pragma unroll
@@ -992,11 +1004,11 @@ static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(cons
       const int gch = (lane & 7) ^ ((row >> 1) & 7);
       if constexpr (QK_BLK) {
         const int64_t t = base + kv0 + row;
-        glds16((const char*)(a.K + ((t >> 5) * (a.H >> 3) + h * 8 + gch) * 256 + (t & 31) * 8), smem + buf * ATT_TILE_PAIR + r0 * 128);
+        glds16_aux<CONVDR_ATT_KV_AUX>((const char*)(a.K + ((t >> 5) * (a.H >> 3) + h * 8 + gch) * 256 + (t & 31) * 8), smem + buf * ATT_TILE_PAIR + r0 * 128);
       } else {
-        glds16((const char*)(a.K + (base + kv0 + row) * a.ldq + h * 64) + gch * 16, smem + buf * ATT_TILE_PAIR + r0 * 128);
+        glds16_aux<CONVDR_ATT_KV_AUX>((const char*)(a.K + (base + kv0 + row) * a.ldq + h * 64) + gch * 16, smem + buf * ATT_TILE_PAIR + r0 * 128);
       }
-      glds16((const char*)(a.Vt + (int64_t)(h * 64 + row) * a.ldt + base + kv0) + gch * 16,
+      glds16_aux<CONVDR_ATT_KV_AUX>((const char*)(a.Vt + (int64_t)(h * 64 + row) * a.ldt + base + kv0) + gch * 16,
              smem + buf * ATT_TILE_PAIR + 64 * 128 + r0 * 128);
     }
   };
@@ -1125,7 +1137,7 @@ static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(cons
         const auto sy = __builtin_amdgcn_permlane32_swap(y0, y1, false, false);
         u32x4_t v;
         v.x = sx[0]; v.y = sy[0]; v.z = sx[1]; v.w = sy[1];
-        if (q_e < plen) *(u32x4_t*)(blk + (dt * 4 + 2 * j + hi_e) * 256) = v;
+        if (q_e < plen) store16<CONVDR_NT_ATT>(blk + (dt * 4 + 2 * j + hi_e) * 256, v);
       }
     if (q_e < plen && a.lse && hi_e == 0) a.lse[(int64_t)h * a.ldt + base + q_e] = q_e < len ? m * a.scale + logf(l) : 0.f;
     CONVDR_ATT_TRACE(5)

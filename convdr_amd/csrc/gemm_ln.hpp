@@ -79,7 +79,13 @@ __device__ __forceinline__ StageSrc ln_stage_src(const bf16_t* __restrict__ G, i
   return s;
 }
 
-template <int ROWS, int WAVES = LN_DMA_WAVES, int FIRST = LN_DMA_FIRST>
+#ifndef CONVDR_LN_RES_AUX
+#define CONVDR_LN_RES_AUX 0   // cache policy of the residual half-tile DMA of the epilogue
+#endif
+#ifndef CONVDR_LN_A_AUX
+#define CONVDR_LN_A_AUX 2   // cache policy of the activation-slice DMA (2 = nt: every activation row is read by ONE workgroup)
+#endif
+template <int ROWS, int WAVES = LN_DMA_WAVES, int FIRST = LN_DMA_FIRST, int AUX = 0>
 __device__ __forceinline__ void ln_stage32(const StageSrc& s, int ks, char* lds_tile, int wave,
                                            uint32_t slice_stride = LN_SLICE * 2) {
   if (wave < FIRST || wave >= FIRST + WAVES) return;   // wave-uniform
@@ -89,7 +95,7 @@ __device__ __forceinline__ void ln_stage32(const StageSrc& s, int ks, char* lds_
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds_tile + (i * WAVES + wave) * 16 * 64), 16, s.voff,
-                                             i * s.round_pitch + ks * slice_stride, 0, 0);
+                                             i * s.round_pitch + ks * slice_stride, 0, AUX);
 }
 
 // one DMA instruction (round i) of ln_stage32
@@ -156,7 +162,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
   constexpr int LN_W_DPW = T::TR / (16 * LN_W_WAVES);   // weight DMA instructions per issuing wave per slice
   const bool w_wave = w.wave >= LN_W_FIRST && w.wave < LN_W_FIRST + LN_W_WAVES;   // (wave-uniform) this wave has weight slices in flight
   ln_stage32<T::TR, LN_W_WAVES, LN_W_FIRST>(srcW, 0, sW, w.wave, w_slice_stride);
-  ln_stage32<T::TL, LN_A_WAVES, LN_A_FIRST>(srcA, 0, sA, w.wave, a_slice_stride);
+  ln_stage32<T::TL, LN_A_WAVES, LN_A_FIRST, CONVDR_LN_A_AUX>(srcA, 0, sA, w.wave, a_slice_stride);
   if (nk > 1) ln_stage32<T::TR, LN_W_WAVES, LN_W_FIRST>(srcW, 1, sW + LN_R_BYTES, w.wave, w_slice_stride);
 #ifdef CONVDR_ENABLE_TRACE   // per-wave stamps of K step 8 (and the top of step 9): a.trace[2048 * 16 + wg * 64 + wave * 8 + i]
 #define CONVDR_LN_STEP(i)                                                                                     \
@@ -174,7 +180,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
     CONVDR_LN_STEP(1)
     lds_barrier();   // NOT __syncthreads(): its fence would add vmcnt(0) and drain the slice that must stay in flight
     CONVDR_LN_STEP(2)
-    if (kt + 1 < nk) ln_stage32<T::TL, LN_A_WAVES, LN_A_FIRST>(srcA, kt + 1, sA + ((kt + 1) & 1) * LN_L_BYTES, w.wave, a_slice_stride);
+    if (kt + 1 < nk) ln_stage32<T::TL, LN_A_WAVES, LN_A_FIRST, CONVDR_LN_A_AUX>(srcA, kt + 1, sA + ((kt + 1) & 1) * LN_L_BYTES, w.wave, a_slice_stride);
     // The 12 weight DMA instructions of slice t + 2 are issued one per MFMA pair below, not in a block here: an
     // issuing wave stalls ~70 cycles on each, and in a block those ~950 cycles come before its first MFMA (the wave
     // was the critical path of the step: 950 + 1,250 cycles); interleaved, its already-issued MFMAs run under the
@@ -253,7 +259,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
       const int c = (pp & ~31) | ((pp ^ lr) & 31);
       const int tok = (lr >> 5) * 64 + nt * 32 + (lr & 31);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srcR.rsrc, (lptr_t)(sC + (i * 512 + w.wave * 64) * 16), 16,
-                                               (uint32_t)(tok * 1536 + c * 16), 0, 0, 0);
+                                               (uint32_t)(tok * 1536 + c * 16), 0, 0, CONVDR_LN_RES_AUX);
     }
     if (nt == 0) {
       // the LayerNorm parameters ride under the first residual half's flight (staged before it, their loads and the
@@ -350,7 +356,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
         const int lr = idx / 96, pp = idx - lr * 96;
         const int c = (pp & ~31) | ((pp ^ lr) & 31);
         const int64_t tok = t0 + (lr >> 5) * 64 + nt * 32 + (lr & 31);
-        if (tok < a.rows) *(uint4*)(a.X + tok * 768 + c * 8) = v4[j];
+        if (tok < a.rows) store16<CONVDR_NT_LN>(a.X + tok * 768 + c * 8, v4[j]);
       }
     }
     if (nt == 0) { CONVDR_LN_TRACE(14) }

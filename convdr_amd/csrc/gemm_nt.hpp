@@ -40,6 +40,32 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
+// 16-byte global store, optionally non-temporal (activations that the next kernel streams from HBM anyway: keeping them
+// out of L2 leaves it to the weights)
+template <bool NT, class V>
+__device__ __forceinline__ void store16(void* p, const V& v) {
+  static_assert(sizeof(V) == 16, "16-byte store");
+  typedef uint32_t raw4_t __attribute__((ext_vector_type(4)));
+  if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(raw4_t, v), (raw4_t*)p);
+  else *(V*)p = v;
+}
+#ifndef CONVDR_NT_GEMM_BLK
+#define CONVDR_NT_GEMM_BLK 1
+#endif
+#ifndef CONVDR_NT_CTILE
+#define CONVDR_NT_CTILE 1
+#endif
+#ifndef CONVDR_NT_ATT
+#define CONVDR_NT_ATT 1
+#endif
+#ifndef CONVDR_NT_LN
+#define CONVDR_NT_LN 1
+#endif
+// the same with a cache policy (aux 2 = nt: data that ONE workgroup reads once)
+template <int AUX>
+__device__ __forceinline__ void glds16_aux(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, AUX);
+}
 
 // all of this wave's outstanding LDS-DMA (and other vector-memory) operations have completed
 __device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
