@@ -202,7 +202,7 @@ __device__ __forceinline__ StageSrc gemm_stage_src(const bf16_t* __restrict__ G,
   return s;
 }
 
-template <int ROWS, int WAVES, int FIRST>
+template <int ROWS, int WAVES, int FIRST, int AUX = 0>   // AUX: cache policy of the DMA (2 = nt)
 __device__ __forceinline__ void gemm_stage(const StageSrc& s, int kt, char* lds_tile, int wave) {
   if (FIRST > 0 && wave < FIRST) return;   // wave-uniform
   wave -= FIRST;
@@ -211,7 +211,7 @@ __device__ __forceinline__ void gemm_stage(const StageSrc& s, int kt, char* lds_
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds_tile + (i * WAVES + wave) * 8 * 128), 16, s.voff,
-                                             i * s.round_pitch + kt * (GEMM_BK * 2), 0, 0);
+                                             i * s.round_pitch + kt * (GEMM_BK * 2), 0, AUX);
 }
 
 // one DMA instruction of a chunk (round i of gemm_stage), for the loops that thread the issue between their MFMAs
@@ -370,8 +370,9 @@ struct R3Issue {
   static constexpr int LFIRST = ROLES ? T::WAVES / 2 : 0;       // ... from this wave on
   static constexpr int R_DPW = T::TR / (8 * RW);                // DMA instructions per issuing wave per R chunk
   static __device__ __forceinline__ bool issues_r(int wave) { return !ROLES || wave < RW; }
+  template <int AUX = 0>
   static __device__ __forceinline__ void r(const StageSrc& s, int kt, char* dst, int wave) {
-    if (issues_r(wave)) gemm_stage<T::TR, RW, 0>(s, kt, dst, wave);
+    if (issues_r(wave)) gemm_stage<T::TR, RW, 0, AUX>(s, kt, dst, wave);
   }
   static __device__ __forceinline__ void l(const StageSrc& s, int kt, char* dst, int wave) {
     gemm_stage<T::TL, LW, LFIRST>(s, kt, dst, wave);   // (returns at once for waves below LFIRST)
@@ -390,19 +391,21 @@ struct R3Slots { int rs, ls; };
 // the first three DMA groups of a tile (R chunk 0, L chunk 0, R chunk 1 -- in this order: the counted waits rely on it)
 // with_r1 = false leaves R chunk 1 to step 0 of the main loop (r1_deferred): its slot then stays untouched until every
 // wave has entered the loop -- k_gemm keeps the tile's bias slice there.
-template <class T>
+// R_AUX: cache policy of the R operand's DMA (2 = nt, for an R operand that is streamed exactly once: the passage block
+// of a scan with a single query tile)
+template <class T, int R_AUX = 0>
 __device__ __forceinline__ void gemm_r3_prologue(const TileSrcAll<T>& src, int K, char* smem, const WavePos<T>& w, R3Slots s,
                                                  bool with_r1 = true) {
   char* sR = smem;
   char* sL = smem + 3 * T::R_BYTES;
-  R3Issue<T>::r(src.R, 0, sR + s.rs * T::R_BYTES, w.wave);
+  R3Issue<T>::template r<R_AUX>(src.R, 0, sR + s.rs * T::R_BYTES, w.wave);
   R3Issue<T>::l(src.L, 0, sL + s.ls * T::L_BYTES, w.wave);
-  if (with_r1 && K > GEMM_BK) R3Issue<T>::r(src.R, 1, sR + (s.rs == 2 ? 0 : s.rs + 1) * T::R_BYTES, w.wave);
+  if (with_r1 && K > GEMM_BK) R3Issue<T>::template r<R_AUX>(src.R, 1, sR + (s.rs == 2 ? 0 : s.rs + 1) * T::R_BYTES, w.wave);
 }
 // Returns the slot state for the NEXT tile: once a wave is back from this call, the R slots `rs`, rs + 1 and the L slot
 // `ls` of the returned state are free (the last step read the other ones), so the next tile's prologue may be issued
 // at once -- under this tile's epilogue (prologue_in_flight on the next call).
-template <class T, bool F16 = false>
+template <class T, bool F16 = false, int R_AUX = 0>
 __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src, int K, char* smem, GemmAcc<T>& acc,
                                                        const WavePos<T>& w, R3Slots st = R3Slots{0, 0},
                                                        bool prologue_in_flight = false, bool r1_deferred = false,
@@ -415,7 +418,7 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
   const int offL = (w.wl * T::NT * 32 + w.li) * 128;
   char* sR = smem;
   char* sL = smem + 3 * T::R_BYTES;
-  if (!prologue_in_flight) gemm_r3_prologue<T>(src, K, smem, w, st, !r1_deferred);
+  if (!prologue_in_flight) gemm_r3_prologue<T, R_AUX>(src, K, smem, w, st, !r1_deferred);
   int rs = st.rs, ls = st.ls;
 #if defined(CONVDR_R3_STATIC_PRIO)   // experiment (cdna guide T5, static form): the younger half of the workgroup at priority 1
   if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= T::THREADS / 2) __builtin_amdgcn_s_setprio(1);
@@ -459,7 +462,7 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
     // MFMAs; 1 = both ride between the MFMA rows (L in sub-step 0, R in sub-step 3); 2 = L block, R between the rows
 #if CONVDR_R3_VARIANT != 1
     __builtin_amdgcn_sched_barrier(0);
-    if (r1_deferred && kt == 0 && issue_l) R3Issue<T>::r(src.R, 1, sR + (rs == 2 ? 0 : rs + 1) * T::R_BYTES, w.wave);
+    if (r1_deferred && kt == 0 && issue_l) R3Issue<T>::template r<R_AUX>(src.R, 1, sR + (rs == 2 ? 0 : rs + 1) * T::R_BYTES, w.wave);
     if (issue_l) R3Issue<T>::l(src.L, kt + 1, l_dst, w.wave);
 #endif
     CONVDR_R3_STEP(3)
@@ -495,7 +498,7 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
     }
     CONVDR_R3_STEP(4)
 #if CONVDR_R3_VARIANT == 0
-    if (issue_r) R3Issue<T>::r(src.R, kt + 2, r_dst, w.wave);
+    if (issue_r) R3Issue<T>::template r<R_AUX>(src.R, kt + 2, r_dst, w.wave);
 #endif
     CONVDR_R3_STEP(5)
     rs = rs == 2 ? 0 : rs + 1;

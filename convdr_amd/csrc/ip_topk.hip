@@ -498,6 +498,12 @@ __device__ __forceinline__ void scan_emit_flush(const ScanArgs& a, const WavePos
 template <class T, bool F16>
 __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan_r3(const ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // the 256 x 128 tile serves scans with ONE query tile (at most 128 queries): every passage chunk is read exactly once,
+  // so its DMA is non-temporal -- the block streams past L2 instead of through it
+#ifndef CONVDR_SCAN_P_NT
+#define CONVDR_SCAN_P_NT 1
+#endif
+  constexpr int P_AUX = (CONVDR_SCAN_P_NT && T::TL <= 128) ? 2 : 0;
   const uint32_t ntiles = (uint32_t)a.nPt * (uint32_t)a.nQt;
   const uint32_t xcd = blockIdx.x & 7u, q8 = ntiles >> 3, r8 = ntiles & 7u;
   const uint32_t chunk_base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
@@ -518,7 +524,7 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan_r3(const ScanArgs a) 
   coords(idx, ts, m0, n0);
   TileSrcAll<T> src(a.P, a.d, a.n, a.Qb, a.d, a.nq_pad, m0, n0, w);
   R3Slots slots{0, 0};
-  gemm_r3_prologue<T>(src, a.d, smem, w, slots);
+  gemm_r3_prologue<T, P_AUX>(src, a.d, smem, w, slots);
   float tau_next[T::NT];
   auto load_tau = [&](int64_t n0_) {
 #pragma unroll
@@ -536,7 +542,7 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan_r3(const ScanArgs a) 
     float tau_lane[T::NT];
 #pragma unroll
     for (int nt = 0; nt < T::NT; ++nt) tau_lane[nt] = tau_next[nt];
-    slots = gemm_nt_mainloop_r3<T, F16>(src, a.d, smem, acc, w, slots, true);
+    slots = gemm_nt_mainloop_r3<T, F16, P_AUX>(src, a.d, smem, acc, w, slots, true);
 #pragma unroll
     for (int nt = 0; nt < T::NT; ++nt) asm volatile("" : "+v"(tau_lane[nt]));
     int tid_e = threadIdx.x;
@@ -550,7 +556,7 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan_r3(const ScanArgs a) 
       coords(next, ts, m0, n0);
       load_tau(n0);
       src = TileSrcAll<T>(a.P, a.d, a.n, a.Qb, a.d, a.nq_pad, m0, n0, w);
-      gemm_r3_prologue<T>(src, a.d, smem, w, slots);
+      gemm_r3_prologue<T, P_AUX>(src, a.d, smem, w, slots);
     }
     scan_emit_capture<T>(a, acc, we, m0_cur, n0_cur, tau_lane, pend);
     if (!has_next) break;
