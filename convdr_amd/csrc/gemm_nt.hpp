@@ -362,6 +362,9 @@ static_assert(CONVDR_R3_LSUB <= CONVDR_R3_RSUB, "the L chunk must be issued befo
 #if CONVDR_R3_ROLES && CONVDR_R3_VARIANT != 0
 #error "the between-the-rows variants of the R3 step assume that every wave issues its share"
 #endif
+#ifndef CONVDR_R3_L_AUX
+#define CONVDR_R3_L_AUX 0   // cache policy of the L operand's DMA (A/B builds)
+#endif
 template <class T>
 struct R3Issue {
   static constexpr bool ROLES = CONVDR_R3_ROLES && T::WAVES == 8;
@@ -375,7 +378,7 @@ struct R3Issue {
     if (issues_r(wave)) gemm_stage<T::TR, RW, 0, AUX>(s, kt, dst, wave);
   }
   static __device__ __forceinline__ void l(const StageSrc& s, int kt, char* dst, int wave) {
-    gemm_stage<T::TL, LW, LFIRST>(s, kt, dst, wave);   // (returns at once for waves below LFIRST)
+    gemm_stage<T::TL, LW, LFIRST, CONVDR_R3_L_AUX>(s, kt, dst, wave);   // (returns at once for waves below LFIRST)
   }
 };
 template <class T>
