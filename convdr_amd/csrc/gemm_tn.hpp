@@ -34,6 +34,19 @@ struct TnCfg {
   static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
 };
 
+// CONVDR_TN_ROLES: in the 8-wave tile the YOUNGER wave of each SIMD (waves 4-7) issues the whole next K step's DMA at the top
+// of the step -- the matrix pipe serves the older wave first, so the younger is not on the critical path there -- and the
+// older wave goes straight to its fragments (see CONVDR_R3_ROLES in gemm_nt.hpp).
+#ifndef CONVDR_TN_ROLES
+#define CONVDR_TN_ROLES 0
+#endif
+template <class T>
+struct TnIssue {
+  static constexpr bool ROLES = CONVDR_TN_ROLES && T::WAVES == 8;
+  static constexpr int W = ROLES ? T::WAVES / 2 : T::WAVES;      // issuing waves ...
+  static constexpr int FIRST = ROLES ? T::WAVES / 2 : 0;        // ... from this one on
+};
+
 // Stage source of one operand: window [first t of the split, end of operand), this lane's byte offset inside a DMA
 // instruction's rows (with the segment swizzle), column guard folded into the offset.
 template <int TW, int WAVES>
@@ -62,7 +75,7 @@ struct TnStageSrc {
     step_pitch = __builtin_amdgcn_readfirstlane((uint32_t)(64 * ld * 2));
     static_assert((RPI * WAVES) % 4 == 0, "rounds must keep (row & 3)");
   }
-  __device__ __forceinline__ void issue(int kt, char* lds_tile, int wave) const {
+  __device__ __forceinline__ void issue(int kt, char* lds_tile, int wave) const {   // wave: index among the issuing waves
 #pragma unroll
     for (int i = 0; i < ROUNDS; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds_tile + (i * WAVES + wave) * 1024), 16, voff,
@@ -109,8 +122,11 @@ __device__ __forceinline__ void tn_wait_frags(TnFrag* fa, TnFrag* fb) {
 // acc += sum over K steps [0, nk) of the staged operands.  Two stages, one barrier per step; every wave issues its share
 // of step kt + 1 right after the barrier of step kt.
 template <class T>
-__device__ __forceinline__ void gemm_tn_mainloop(const TnStageSrc<T::TR, T::WAVES>& srcR, const TnStageSrc<T::TL, T::WAVES>& srcL,
+__device__ __forceinline__ void gemm_tn_mainloop(const TnStageSrc<T::TR, TnIssue<T>::W>& srcR,
+                                                 const TnStageSrc<T::TL, TnIssue<T>::W>& srcL,
                                                  int nk, char* smem, GemmAcc<T>& acc, const WavePos<T>& w) {
+  const bool issuer = w.wave >= TnIssue<T>::FIRST;            // wave-uniform
+  const int iw = w.wave - TnIssue<T>::FIRST;
   using C = TnCfg<T>;
   // this lane's byte offset inside an operand image for MFMA column block 0 of its wave, sub-step 0, first read:
   //   row = 8 (lane >> 5) + ((lane & 15) >> 2),  column = 16 ((lane >> 4) & 1) + 4 (lane & 3), segment swizzle by row & 3
@@ -131,15 +147,17 @@ __device__ __forceinline__ void gemm_tn_mainloop(const TnStageSrc<T::TR, T::WAVE
     offL[j] = s0 + C::R_BYTES + trow * C::L_ROWB + (((seg & ~3) | ((seg ^ rsw) & 3)) << 6) + cb;
   }
   constexpr int NFRAG_READS = 2 * (T::MT + T::NT);   // LDS instructions per fragment set
-  srcR.issue(0, smem, w.wave);
-  srcL.issue(0, smem + C::R_BYTES, w.wave);
+  if (issuer) {
+    srcR.issue(0, smem, iw);
+    srcL.issue(0, smem + C::R_BYTES, iw);
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     lds_dma_wait_all();
     lds_barrier();
-    if (kt + 1 < nk) {
-      srcR.issue(kt + 1, smem + (buf ^ 1) * C::STAGE_BYTES, w.wave);
-      srcL.issue(kt + 1, smem + (buf ^ 1) * C::STAGE_BYTES + C::R_BYTES, w.wave);
+    if (kt + 1 < nk && issuer) {
+      srcR.issue(kt + 1, smem + (buf ^ 1) * C::STAGE_BYTES, iw);
+      srcL.issue(kt + 1, smem + (buf ^ 1) * C::STAGE_BYTES + C::R_BYTES, iw);
     }
     const uint32_t sb = buf * C::STAGE_BYTES;
     TnFrag fa[2][T::MT], fb[2][T::NT];
@@ -222,8 +240,9 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm_tn(const GemmTnAr
   GemmAcc<T> acc;
   acc.zero();
   if (nk > 0) {
-    const TnStageSrc<T::TR, T::WAVES> srcR(q.Rm, q.ldr, q.NR, r0, t_begin, a.rows, w.wave, w.lane);
-    const TnStageSrc<T::TL, T::WAVES> srcL(q.Lm, q.ldl, q.NL, l0, t_begin, a.rows, w.wave, w.lane);
+    const int iw = w.wave >= TnIssue<T>::FIRST ? w.wave - TnIssue<T>::FIRST : 0;   // index among the issuing waves
+    const TnStageSrc<T::TR, TnIssue<T>::W> srcR(q.Rm, q.ldr, q.NR, r0, t_begin, a.rows, iw, w.lane);
+    const TnStageSrc<T::TL, TnIssue<T>::W> srcL(q.Lm, q.ldl, q.NL, l0, t_begin, a.rows, iw, w.lane);
     gemm_tn_mainloop<T>(srcR, srcL, nk, smem, acc, w);
   }
   const bool ordered = a.nsplit > 1 && a.flags != nullptr;
