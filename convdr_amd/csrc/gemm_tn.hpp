@@ -38,7 +38,7 @@ struct TnCfg {
 // of the step -- the matrix pipe serves the older wave first, so the younger is not on the critical path there -- and the
 // older wave goes straight to its fragments (see CONVDR_R3_ROLES in gemm_nt.hpp).
 #ifndef CONVDR_TN_ROLES
-#define CONVDR_TN_ROLES 0
+#define CONVDR_TN_ROLES 1
 #endif
 template <class T>
 struct TnIssue {
