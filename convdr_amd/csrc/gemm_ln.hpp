@@ -237,10 +237,18 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
   const int slot = w.wr * 2 + w.hi;
   // residual window [t0, rows) as a buffer: rows past the end read as zeros
   const StageSrc srcR = ln_stage_src(a.R, 768, t0, a.rows, w.wave, w.lane);   // (only .rsrc is used)
+  const __amdgpu_buffer_rsrc_t dstX = ln_stage_src(a.X, 768, t0, a.rows, w.wave, w.lane).rsrc;   // output window [t0, rows)
   // byte offset of this lane's 8 bytes of feature chunk `chunk` in the image.  lrl / tid are handed in as opaque
   // per-phase copies: with 192 accumulators live, addresses that the compiler CSEs across phases end up in scratch
-  auto img_off = [&](int lrl, int chunk) {
-    return lrl * 1536 + (((chunk & ~31) | ((chunk ^ lrl) & 31)) << 4) + w.hi * 8;
+  // = lrl * 1536 + (((chunk & ~31) | ((chunk ^ lrl) & 31)) << 4) + hi * 8, evaluated as ONE v_xor per access: the row base
+  // lrl * 1536 and the image base have zeros in bits 4-8, so with B = base + lrl * 1536 + ((lrl & 31) << 4) + hi * 8 the
+  // address is (B ^ ((chunk & 31) << 4)) + ((chunk & ~31) << 4), the second term a compile-time DS offset.  (The closed
+  // form cost ~5 integer instructions per access, 96 accesses per wave: the epilogue is VALU-bound.)
+  typedef __attribute__((address_space(3))) u32x2_t lds_u2_t;
+  static_assert((16384 & 511) == 0, "the image base must leave bits 4-8 to the swizzle");
+  auto img_base = [&](int lrl) { return lds_off(sC) + (uint32_t)(lrl * 1536 + ((lrl & 31) << 4) + w.hi * 8); };
+  auto img_at = [&](uint32_t B, int chunk) {
+    return (lds_u2_t*)(uintptr_t)((B ^ (uint32_t)((chunk & 31) << 4)) + (uint32_t)((chunk & ~31) << 4));
   };
   auto opaque = [](int x) {
     asm volatile("" : "+v"(x));
@@ -251,15 +259,17 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
   for (int nt = 0; nt < T::NT; ++nt) {
     if (nt) __syncthreads();   // every lane has consumed the previous half
     // 6144 chunks: thread t fills positions i * 512 + t (lane-linear per wave instruction, as LDS-DMA requires)
+    // (position idx = i * 512 + t is row idx / 96, chunk idx % 96: one division for i = 0, then 512 = 5 * 96 + 32)
     const int tid_a = opaque((int)threadIdx.x);
+    int lr = tid_a / 96, pp = tid_a - lr * 96;
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
-      const int idx = i * 512 + tid_a;
-      const int lr = idx / 96, pp = idx - lr * 96;
       const int c = (pp & ~31) | ((pp ^ lr) & 31);
       const int tok = (lr >> 5) * 64 + nt * 32 + (lr & 31);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srcR.rsrc, (lptr_t)(sC + (i * 512 + w.wave * 64) * 16), 16,
                                                (uint32_t)(tok * 1536 + c * 16), 0, 0, CONVDR_LN_RES_AUX);
+      pp += 32; lr += 5;
+      if (pp >= 96) { pp -= 96; lr += 1; }
     }
     if (nt == 0) {
       // the LayerNorm parameters ride under the first residual half's flight (staged before it, their loads and the
@@ -272,17 +282,17 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
     __syncthreads();           // (first half: also publishes the LayerNorm parameters)
     if (nt == 0) { CONVDR_LN_TRACE(10) }
     float s = 0.f;
-    const int lrl = opaque(w.wl * 32 + w.li);
+    const uint32_t imgB = img_base(opaque(w.wl * 32 + w.li));
 #pragma unroll
     for (int mt = 0; mt < T::MT; ++mt) {
-      uint2 res[4];
+      u32x2_t res[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) res[g] = *(const uint2*)(sC + img_off(lrl, (w.wr * T::MT + mt) * 4 + g));
+      for (int g = 0; g < 4; ++g) res[g] = *img_at(imgB, (w.wr * T::MT + mt) * 4 + g);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x16& v = acc.c[mt][nt];
         const float4 bv = *(const float4*)(sBias + w.r_base(mt, g));
-        const uint2 r = res[g];
+        const u32x2_t r = res[g];
         v[4 * g + 0] += bv.x + __uint_as_float(r.x << 16);
         v[4 * g + 1] += bv.y + __uint_as_float(r.x & 0xffff0000u);
         v[4 * g + 2] += bv.z + __uint_as_float(r.y << 16);
@@ -328,7 +338,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
   for (int nt = 0; nt < T::NT; ++nt) {
     if (nt) __syncthreads();   // the previous half has been read out
     const float rstd = sStat[128 + w.wl * 64 + nt * 32 + w.li];
-    const int lrl = opaque(w.wl * 32 + w.li);
+    const uint32_t imgB = img_base(opaque(w.wl * 32 + w.li));
 #pragma unroll
     for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
@@ -336,27 +346,29 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
         const int f = w.r_base(mt, g);
         const float4 gg = *(const float4*)(sGam + f), bb = *(const float4*)(sBet + f);
         const f32x16& v = acc.c[mt][nt];
-        uint2 o;
+        u32x2_t o;
         o.x = pack_bf16x2((v[4 * g + 0] - mean[nt]) * rstd * gg.x + bb.x, (v[4 * g + 1] - mean[nt]) * rstd * gg.y + bb.y);
         o.y = pack_bf16x2((v[4 * g + 2] - mean[nt]) * rstd * gg.z + bb.z, (v[4 * g + 3] - mean[nt]) * rstd * gg.w + bb.w);
-        *(uint2*)(sC + img_off(lrl, (w.wr * T::MT + mt) * 4 + g)) = o;
+        *img_at(imgB, (w.wr * T::MT + mt) * 4 + g) = o;
       }
     if (nt == 0) { CONVDR_LN_TRACE(12) }
     __syncthreads();
     if (nt == 0) { CONVDR_LN_TRACE(13) }
     const int tid_s = opaque((int)threadIdx.x);
+    int lr = tid_s / 96, pp = tid_s - lr * 96;
 #pragma unroll
     for (int i0 = 0; i0 < 12; i0 += 4) {
-      uint4 v4[4];
+      u32x4_t v4[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v4[j] = *(const uint4*)(sC + ((i0 + j) * 512 + tid_s) * 16);
+      for (int j = 0; j < 4; ++j) v4[j] = *(const u32x4_t*)(sC + ((i0 + j) * 512 + tid_s) * 16);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int idx = (i0 + j) * 512 + tid_s;
-        const int lr = idx / 96, pp = idx - lr * 96;
         const int c = (pp & ~31) | ((pp ^ lr) & 31);
-        const int64_t tok = t0 + (lr >> 5) * 64 + nt * 32 + (lr & 31);
-        if (tok < a.rows) store16<CONVDR_NT_LN>(a.X + tok * 768 + c * 8, v4[j]);
+        const int tok = (lr >> 5) * 64 + nt * 32 + (lr & 31);
+        // through the output window [t0, rows): rows past the end are dropped by the bounds check; one 32-bit offset
+        __builtin_amdgcn_raw_buffer_store_b128(v4[j], dstX, (uint32_t)(tok * 1536 + c * 16), 0, CONVDR_NT_LN ? 2 : 0);
+        pp += 32; lr += 5;
+        if (pp >= 96) { pp -= 96; lr += 1; }
       }
     }
     if (nt == 0) { CONVDR_LN_TRACE(14) }
