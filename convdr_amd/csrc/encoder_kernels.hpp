@@ -279,6 +279,8 @@ struct GemmArgs {
   int H;
   int64_t ldt;
   int tilesN, tilesT;
+  int nt_out;         // bf16 tile outputs leave non-temporally (set by the launcher for outputs of 128 MB and more: what the next
+                      // kernel streams from HBM anyway stays out of L2; a training-size output its consumer finds in L2 does not)
   int dbg_same_tile;  // experiment: every workgroup reads tile (0, 0) (all-L2-hit upper bound); results are garbage
   int dbg_skip_epi;   // experiment: 1 no epilogue, 3 no global stores of bf16 tiles, 4 every tile stores to tile 0 (garbage results)
   unsigned long long* trace;   // experiment: [workgroup][64 tiles][16 phases] s_memtime stamps of wave 0 (or null)
@@ -388,7 +390,7 @@ struct CTile {
   }
   // chunks [C0, C0 + CN) of every row only (CN * 16 bytes per row, 64 / CN rows per instruction)
   template <int C0, int CN>
-  __device__ static __forceinline__ void store_w_part(uint32_t wb, int lane, bf16_t* dst, int64_t ld, int64_t row_limit,
+  __device__ static __forceinline__ void store_w_part(bool nt, uint32_t wb, int lane, bf16_t* dst, int64_t ld, int64_t row_limit,
                                                       int64_t col_limit) {
     constexpr int RPI = 64 / CN, N_ST = RW / RPI;
     static_assert(64 % CN == 0 && N_ST % 4 == 0, "store_w_part geometry");
@@ -407,14 +409,17 @@ struct CTile {
         const int row = (i0 + j) * RPI + r0;
         bf16_t* pr = dst + (int64_t)row * ld + c * 8;
         if (row < row_limit && nv > 0) {
-          if (nv >= 8) store16<CONVDR_NT_CTILE>(pr, v[j]);
+          if (nv >= 8) {   // (nt: wave-uniform, GemmArgs::nt_out)
+            if (nt) store16<true>(pr, v[j]);
+            else store16<false>(pr, v[j]);
+          }
           else *(uint2*)pr = make_uint2(v[j].x, v[j].y);
         }
       }
     }
   }
   // dst -> element (row 0, column 0) of the WAVE's part of the pass; rows < row_limit and columns < col_limit are written
-  __device__ static __forceinline__ void store_w(uint32_t wb, int lane, bf16_t* dst, int64_t ld, int64_t row_limit,
+  __device__ static __forceinline__ void store_w(bool nt, uint32_t wb, int lane, bf16_t* dst, int64_t ld, int64_t row_limit,
                                                  int64_t col_limit) {
     constexpr int RPI = 64 / CW;
     const int r0 = lane / CW, c = lane - r0 * CW;
@@ -433,7 +438,10 @@ struct CTile {
         const int row = (i0 + j) * RPI + r0;
         bf16_t* pr = dst + (int64_t)row * ld + c * 8;
         if (row < row_limit && nv > 0) {
-          if (nv >= 8) store16<CONVDR_NT_CTILE>(pr, v[j]);
+          if (nv >= 8) {   // (nt: wave-uniform, GemmArgs::nt_out)
+            if (nt) store16<true>(pr, v[j]);
+            else store16<false>(pr, v[j]);
+          }
           else *(uint2*)pr = make_uint2(v[j].x, v[j].y);
         }
       }
@@ -664,7 +672,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
           landed = true;
         }
         const int row0 = (we.wl * T::NT + pass * CT::NTP) * 32, col0 = we.wr * T::MT * 32;   // feature / token offsets
-        CT::store_w(wb, we.lane, a.Vt + (int64_t)(n0 + (a.third0 - 2) * a.H + row0) * a.ldt + t0 + col0, a.ldt,
+        CT::store_w(a.nt_out != 0, wb, we.lane, a.Vt + (int64_t)(n0 + (a.third0 - 2) * a.H + row0) * a.ldt + t0 + col0, a.ldt,
                     a.N - n0 - row0, a.rows - t0 - col0);
       }
     } else if (EPI == EPI_GELU_BLK || (EPI == EPI_QKV && a.qk_blocked)) {
@@ -803,7 +811,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                   if constexpr (HALVES) {
                     if (mt == T::MT / 2 - 1 && g == 3) {   // the first half of the row is parked: send it off
                       if (out == NOUT - 1 && pass == CT::PASSES - 1 && has_next) { lds_dma_wait_all(); landed = true; }
-                      CT::template store_w_part<0, CT::CW / 2>(wb, we.lane, wdst, wld, wrows, wcols);
+                      CT::template store_w_part<0, CT::CW / 2>(a.nt_out != 0, wb, we.lane, wdst, wld, wrows, wcols);
                     }
                   }
                 } else if (t_ok && (full_n || f < a.N)) {
@@ -835,10 +843,10 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                 ldo = a.N; cols = a.N - n0;
               }
               if constexpr (HALVES) {
-                CT::template store_w_part<CT::CW / 2, CT::CW / 2>(wb, we.lane, wdst, wld, wrows, wcols);
+                CT::template store_w_part<CT::CW / 2, CT::CW / 2>(a.nt_out != 0, wb, we.lane, wdst, wld, wrows, wcols);
               } else {
                 const int row0 = (we.wl * T::NT + pass * CT::NTP) * 32, col0 = we.wr * T::MT * 32;
-                CT::store_w(wb, we.lane, dst + (int64_t)row0 * ldo + col0, ldo, a.rows - t0 - row0, cols - col0);
+                CT::store_w(a.nt_out != 0, wb, we.lane, dst + (int64_t)row0 * ldo + col0, ldo, a.rows - t0 - row0, cols - col0);
               }
             }
             CONVDR_TRACE(6 + 4 * pass)

@@ -28,6 +28,7 @@ inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
 #endif
   static const int trace_epi = getenv("CONVDR_TRACE_EPI") ? atoi(getenv("CONVDR_TRACE_EPI")) : (int)EPI_GELU_BF16;
   a.trace = (EPI == trace_epi) ? (unsigned long long*)g_gemm_trace : nullptr;
+  a.nt_out = CONVDR_NT_CTILE && (int64_t)a.rows * a.N * 2 >= ((int64_t)128 << 20);
   a.tilesN = (a.N + T::TR - 1) / T::TR;
   a.tilesT = (int)ceil_div64(a.rows, T::TL);
   if (a.tilesT == 0) return 0;
