@@ -283,10 +283,7 @@ constexpr int ATTB_DKV_SMEM = 2 * (2 * ATT_TILE + 512);   // two sets of (Q tile
 // (SQ_INSTS_VMEM_WR 34 per wave for a kernel with 5 stores).  At 256 registers it needs 215, no spills: 58 us, the KD step
 // 11.63 -> 11.14 ms.  The kernel is latency-bound either way; the third resident workgroup bought less than the
 // spills cost.
-#ifndef CONVDR_ATT_DQ_OCC
-#define CONVDR_ATT_DQ_OCC 2
-#endif
-static __global__ void __launch_bounds__(256, CONVDR_ATT_DQ_OCC) k_attention_bwd_dq(const AttnBwdArgs a) {
+static __global__ void __launch_bounds__(256, 2) k_attention_bwd_dq(const AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.z, h = blockIdx.y;
   const int len = a.lens[b];
@@ -512,7 +509,9 @@ static __global__ void __launch_bounds__(256, 2) k_attention_bwd_dkv(const AttnB
       // hash was 2/3 of this kernel's VALU work.  (Same mask: drop_pair of csrc/dropout.hpp.)
       float dmask[16];
       if (a.drop.thresh) {
-        const int odd = kc & 1;   // (k0 + 32 wave is even: the lane parity is the key parity)
+        // parity of the UNCLAMPED key (= the lane parity: k0 + 32 wave is even).  The clamped key would give the partner
+        // lane of an odd-length sequence's last key (key == len, clamped to the even len - 1) the wrong role in the swap.
+        const int odd = key & 1;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const int qi_mine = 32 * qt + 16 * (r >> 3) + 8 * hi + (r & 7) + odd;

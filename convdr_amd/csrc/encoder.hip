@@ -47,7 +47,7 @@ static EncBufs enc_plan(const convdr_encoder_config* c, int64_t rows, int B, cha
 }
 
 static int64_t g_fused_ln_max_k = 1 << 30;
-static int64_t g_hm_blocked = -1;   // -1: CONVDR_HM_BLOCKED (default on); convdr_set_option("hm_blocked", 0 / 1) overrides
+static int64_t g_hm_blocked = 1;    // blocked activation hand-offs; convdr_set_option("hm_blocked", 0) gives the row-major paths back
 static int64_t g_fused_ln_min_rows = 128 * 192;   // below this the 128-token tiles cannot fill the 256 CUs
 
 // Y = A W^T + bias + R, X = LayerNorm(Y): fused row-complete kernel for hidden size 768 and enough rows to fill the
@@ -111,10 +111,9 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
   bf16_t* x1 = p.X;
   int64_t n = rows;
   // blocked activation layouts between a producer's registers and the row-complete projection + LayerNorm kernel
-  // (EPI_GELU_BLK, k_attention_fwd<CTX_BLK>): on whenever that kernel serves the shape.  CONVDR_HM_BLOCKED=0 /
+  // (EPI_GELU_BLK, k_attention_fwd<CTX_BLK>): on whenever that kernel serves the shape.
   // convdr_set_option("hm_blocked", 0): the row-major round-2 paths
-  static const bool blk_env = !(getenv("CONVDR_HM_BLOCKED") && atoi(getenv("CONVDR_HM_BLOCKED")) == 0);
-  const bool blk_on = g_hm_blocked < 0 ? blk_env : g_hm_blocked != 0;
+  const bool blk_on = g_hm_blocked != 0;
   const bool ctx_blocked = blk_on && !cls_only && fused_ln_applies(rows, H, H);
   const bool qk_blocked = blk_on && fused_ln_applies(rows, H, H);   // Q / K between the QKV projection and the attention
   g.qk_blocked = qk_blocked ? 1 : 0;
@@ -122,15 +121,8 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
     if (int e = launch_gemm<EPI_QKV>(g, st, "gemm_qkv")) return e;
     AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, (int64_t)H, p.ctx, lse, 0.125f, (unsigned long long*)g_attn_trace};
     ProfScope prof("attention", st);
-    static const bool qlds = getenv("CONVDR_ATT_QLDS") && atoi(getenv("CONVDR_ATT_QLDS"));   // A/B switch (see k_attention_fwd)
     if (ctx_blocked && qk_blocked) {
-      hipLaunchKernelGGL((k_attention_fwd<false, false, true, true>), dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
-    } else if (qlds) {
-      static DeviceOnce attr_q;
-      if (attr_q.first())
-        CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_attention_fwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             ATT_SMEM_BYTES_QLDS));
-      hipLaunchKernelGGL((k_attention_fwd<false, true>), dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES_QLDS, st, a);
+      hipLaunchKernelGGL((k_attention_fwd<false, true, true>), dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
     } else {
       hipLaunchKernelGGL(k_attention_fwd<false>, dim3((max_len + 127) / 128, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
     }
@@ -148,7 +140,7 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
     if (int e = launch_gemm<EPI_BF16>(gq, st, "gemm_qkv")) return e;
     AttnArgs a{p.Q, p.K, p.Vt, p.ldt, cu, lens, H, (int64_t)H, p.cls_ctx, nullptr, 0.125f, nullptr};
     ProfScope prof("attention", st);
-    if (qk_blocked) hipLaunchKernelGGL((k_attention_fwd<true, false, false, true>), dim3(1, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
+    if (qk_blocked) hipLaunchKernelGGL((k_attention_fwd<true, false, true>), dim3(1, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
     else hipLaunchKernelGGL(k_attention_fwd<true>, dim3(1, c->heads, B), dim3(256), ATT_SMEM_BYTES, st, a);
     CONVDR_CHECK_LAUNCH("k_attention_fwd<cls>");
     xin = p.cls_x; ctx = p.cls_ctx; x1 = p.cls_x1; n = B;

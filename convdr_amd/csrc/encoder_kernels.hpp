@@ -356,9 +356,6 @@ __device__ __forceinline__ float gelu_grad(float x) {
 // cooperatively (a workgroup barrier, then every thread stored rows other waves had written); since round 2 every
 // wave parks and stores ITS OWN 32 NTP x 32 MT part (put_w / store_w / store_w_part) with no barrier inside the
 // passes -- the token-major outputs and the transposed V^T tiles of the QKV projection alike.
-#ifndef CONVDR_EPI_HALVES
-#define CONVDR_EPI_HALVES 1   // 256^2 tiles: the two 128-byte halves of a pass row are stored as soon as each is parked (FFN1 -0.8 %)
-#endif
 template <class T>
 struct CTile {
   static constexpr int PASSES = (T::TL * T::TR * 2) / T::STAGE_BYTES;    // Tile256: 2, Tile128: 1
@@ -491,16 +488,13 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                   : TileSrc<T>(a.W + kbeg, ldw, a.N, a.X + kbeg, ldx, a.rows, c.n0, c.t0, w);
   };
 
-#ifndef CONVDR_GEMM_R3
-#define CONVDR_GEMM_R3 1   // 0: the two-stage K step for the 256 x 256 tiles too (A/B builds)
-#endif
   // R3 (256 x 256 tiles): the 3 R-slot / 2 L-slot K step of gemm_nt.hpp.  All 160 KB are operand slots, so between two
   // tiles every byte has a second job: when a tile's main loop returns the slot state {rs, ls} of the next tile, R[rs]
   // and L[ls] take the next tile's chunks 0 at once, the first KB of R[rs + 1] holds the next tile's bias slice (its
   // chunk 1 is issued in step 0 of the next main loop, after every wave has folded the bias into its accumulators),
   // and the two slots the last step read -- R[rs + 2] and L[ls ^ 1], dead after the epilogue's first barrier -- are the
   // two halves of the parked output tile.
-  constexpr bool R3 = CONVDR_GEMM_R3 && T::WAVES == 8;
+  constexpr bool R3 = T::WAVES == 8;   // (the two-stage K step serves the 4-wave 128 x 128 tiles)
   R3Slots st{0, 0};
   auto sbias_of = [&](R3Slots s) { return (float*)(smem + (s.rs == 2 ? 0 : s.rs + 1) * T::R_BYTES); };
   auto tile_src_all = [&](const Coord& cc) {
@@ -717,7 +711,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
             u32x4_t q;
             q.x = sx[0]; q.y = sy[0]; q.z = sx[1]; q.w = sy[1];
             if (tb < rows32 && n0 + we.wr * T::MT * 32 + mt * 32 < a.N)
-              store16<CONVDR_NT_GEMM_BLK>(blk + (int64_t)(mt * 4 + 2 * j + we.hi) * 256, q);
+              store16<NT_GEMM_BLK>(blk + (int64_t)(mt * 4 + 2 * j + we.hi) * 256, q);
           }
       }
       CONVDR_TRACE(6)
@@ -734,7 +728,8 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
 #pragma unroll
         for (int pass = 0; pass < CT::PASSES; ++pass) {
           const uint32_t wb = CT::wave_base(sC, we.wave);   // (wave-local park: a wave re-reads only what it wrote)
-          constexpr bool HALVES = CONVDR_EPI_HALVES && BF16_OUT && T::MT >= 4 && CT::NTP == 1;
+          // wide wave rows: the two 128-byte halves of a pass row are stored as soon as each is parked (FFN1 -0.8 %)
+          constexpr bool HALVES = BF16_OUT && T::MT >= 4 && CT::NTP == 1;
           bf16_t* wdst = nullptr;
           int64_t wld = 0, wrows = 0, wcols = 0;
           if constexpr (HALVES) {
@@ -873,12 +868,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
 // Online softmax over key tiles; lanes q and q+32 hold the two halves of a query's keys / head dims and
 // exchange only the running max and the final row sum.  Writes LSE (natural log) when lse != nullptr.
 // ---------------------------------------------------------------------------------------------
-#ifndef CONVDR_NT_ATT_Q
-#define CONVDR_NT_ATT_Q 1
-#endif
-#ifndef CONVDR_ATT_KV_AUX
-#define CONVDR_ATT_KV_AUX 2   // cache policy of the K / V^T tile DMA of k_attention_fwd
-#endif
+constexpr int ATT_KV_AUX = 2;   // cache policy of the K / V^T tile DMA of k_attention_fwd (nt: read by this workgroup only; 3.61 -> 3.29 ms per 12 layers)
 struct AttnArgs {
   const bf16_t *Q, *K, *Vt;
   int64_t ldt;
@@ -934,11 +924,6 @@ __device__ __forceinline__ void attn_park_store(char* so, const f32x16 (&o)[2], 
 // CLS_Q (last layer of an inference pass): only the CLS row of every sequence is needed downstream.  Q is then a
 // [B, H] matrix of CLS queries (row b), the workgroup still streams the sequence's K / V^T tiles, wave 0 alone does the
 // arithmetic (all of its 32 query columns carry the same query) and one lane pair stores ctx[b] ([B, H]).
-// QLDS: the workgroup's 128 x 64 Q tile (16 KB behind the K / V^T buffers) arrives by LDS-DMA in whole 128-byte lines
-// like the K / V^T tiles and the fragments are ds_read_b128s, instead of four 16-byte global loads per lane that touch
-// 32 rows x 32 bytes per instruction (128 of a wave's 224 line operations).  Costs a workgroup of occupancy (48 KB: three
-// per CU instead of four).
-constexpr int ATT_SMEM_BYTES_QLDS = ATT_SMEM_BYTES + 128 * 128;
 // CTX_BLK: the output goes to the blocked layout [rows / 32][H / 8][32 tokens][8 dims] (hm_blocked_offset) that the
 // row-complete output projection stages with whole-line LDS-DMA: lanes (query, hi = 0 / 1) hold the two halves of a dim
 // octet, one v_permlane32_swap per dword gives each lane 16 bytes, and runs of 8 tokens are whole 128-byte lines
@@ -947,8 +932,8 @@ constexpr int ATT_SMEM_BYTES_QLDS = ATT_SMEM_BYTES + 128 * 128;
 // LDS-DMA pieces are runs of 8 tokens x 16 bytes = whole lines as before, and the Q fragment loads -- four 16-byte
 // loads per lane that touched 32 rows x 32 bytes per instruction in the row-major form (128 of a wave's 224 line
 // operations) -- read 512 contiguous bytes per half-wave.  (CLS_Q keeps its [B, H] row-major query matrix.)
-template <bool CLS_Q, bool QLDS = false, bool CTX_BLK = false, bool QK_BLK = false>
-static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(const AttnArgs a) {
+template <bool CLS_Q, bool CTX_BLK = false, bool QK_BLK = false>
+static __global__ void __launch_bounds__(256, 4) k_attention_fwd(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.z, h = blockIdx.y;
   const int len = a.lens[b];
@@ -967,26 +952,12 @@ static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(cons
   CONVDR_ATT_TRACE(1)
 
   bf16x8 qf[4];
-  if constexpr (QLDS && !CLS_Q) {
-    // 128 rows x 128 B = 4 LDS-DMA rounds of 256 lanes x 16 B (rows past the sequence are other rows of the buffer or its
-    // slack: their scores are never stored)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r0 = (i * 4 + wave) * 8;
-      const int row = r0 + (lane >> 3);
-      const int gch = (lane & 7) ^ ((row >> 1) & 7);
-      glds16((const char*)(a.Q + (base + q0 + row) * a.ldq + h * 64) + gch * 16, smem + ATT_SMEM_BYTES + r0 * 128);
-    }
-  } else if constexpr (QK_BLK && !CLS_Q) {
+  if constexpr (QK_BLK && !CLS_Q) {
     const int64_t t = base + qc;
     const bf16_t* qp = a.Q + ((t >> 5) * (a.H >> 3) + h * 8 + hi) * 256 + (t & 31) * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {   // dims 16 s + 8 hi .. + 7 = octet 2 s + hi
-#if CONVDR_NT_ATT_Q
       qf[s] = __builtin_nontemporal_load((const bf16x8*)(qp + 2 * s * 256));   // (read by this workgroup only)
-#else
-      qf[s] = *(const bf16x8*)(qp + 2 * s * 256);
-#endif
     }
   } else {
     const bf16_t* qp = CLS_Q ? a.Q + (int64_t)b * a.ldq + h * 64 + 8 * hi : a.Q + (base + qc) * a.ldq + h * 64 + 8 * hi;
@@ -1012,11 +983,11 @@ static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(cons
       const int gch = (lane & 7) ^ ((row >> 1) & 7);
       if constexpr (QK_BLK) {
         const int64_t t = base + kv0 + row;
-        glds16_aux<CONVDR_ATT_KV_AUX>((const char*)(a.K + ((t >> 5) * (a.H >> 3) + h * 8 + gch) * 256 + (t & 31) * 8), smem + buf * ATT_TILE_PAIR + r0 * 128);
+        glds16_aux<ATT_KV_AUX>((const char*)(a.K + ((t >> 5) * (a.H >> 3) + h * 8 + gch) * 256 + (t & 31) * 8), smem + buf * ATT_TILE_PAIR + r0 * 128);
       } else {
-        glds16_aux<CONVDR_ATT_KV_AUX>((const char*)(a.K + (base + kv0 + row) * a.ldq + h * 64) + gch * 16, smem + buf * ATT_TILE_PAIR + r0 * 128);
+        glds16_aux<ATT_KV_AUX>((const char*)(a.K + (base + kv0 + row) * a.ldq + h * 64) + gch * 16, smem + buf * ATT_TILE_PAIR + r0 * 128);
       }
-      glds16_aux<CONVDR_ATT_KV_AUX>((const char*)(a.Vt + (int64_t)(h * 64 + row) * a.ldt + base + kv0) + gch * 16,
+      glds16_aux<ATT_KV_AUX>((const char*)(a.Vt + (int64_t)(h * 64 + row) * a.ldt + base + kv0) + gch * 16,
              smem + buf * ATT_TILE_PAIR + 64 * 128 + r0 * 128);
     }
   };
@@ -1030,15 +1001,6 @@ static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(cons
     lds_dma_wait_all();  // explicit: hipcc's automatic vmcnt wait for LDS-DMA is not reliable (gemm_nt.hpp)
     __syncthreads();     // tile `it` landed for everyone; everyone finished reading tile it-1 (the other buffer)
     if (it >= 1 && kv0 + 64 < len) stage_tile(kv0 + 64, buf ^ 1);
-    if constexpr (QLDS && !CLS_Q) {
-      if (it == 0) {   // (the Q tile was issued before the K / V^T tiles: it has landed with them)
-        const int qrow = wave * 32 + li;
-        const char* qs = smem + ATT_SMEM_BYTES + qrow * 128;
-        const int qsw = (qrow >> 1) & 7;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qs + (((2 * s + hi) ^ qsw) * 16));
-      }
-    }
     if (it == 0) { CONVDR_ATT_TRACE(2) }
     if (it == 1) { CONVDR_ATT_TRACE(3) }
     if (CLS_Q && wave != 0) continue;   // (has staged its share and passed the barrier)
@@ -1145,7 +1107,7 @@ static __global__ void __launch_bounds__(256, QLDS ? 3 : 4) k_attention_fwd(cons
         const auto sy = __builtin_amdgcn_permlane32_swap(y0, y1, false, false);
         u32x4_t v;
         v.x = sx[0]; v.y = sy[0]; v.z = sx[1]; v.w = sy[1];
-        if (q_e < plen) store16<CONVDR_NT_ATT>(blk + (dt * 4 + 2 * j + hi_e) * 256, v);
+        if (q_e < plen) store16<NT_ATT>(blk + (dt * 4 + 2 * j + hi_e) * 256, v);
       }
     if (q_e < plen && a.lse && hi_e == 0) a.lse[(int64_t)h * a.ldt + base + q_e] = q_e < len ? m * a.scale + logf(l) : 0.f;
     CONVDR_ATT_TRACE(5)

@@ -18,7 +18,7 @@ inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
   if (attr_done.first()) {
     CONVDR_CHECK_HIP(
         hipFuncSetAttribute((const void*)k_gemm<EPI, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (CONVDR_GEMM_R3 && T::WAVES == 8) ? 160 * 1024 : T::SMEM_BYTES + T::TR * 4));
+                            T::WAVES == 8 ? 160 * 1024 : T::SMEM_BYTES + T::TR * 4));
   }
 #ifdef CONVDR_ENABLE_TRACE   // timing experiments that produce garbage results: only in the `make TRACE=1` library
   static const int dbg = getenv("CONVDR_DBG_SAME_TILE") ? atoi(getenv("CONVDR_DBG_SAME_TILE")) : 0;
@@ -28,7 +28,7 @@ inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
 #endif
   static const int trace_epi = getenv("CONVDR_TRACE_EPI") ? atoi(getenv("CONVDR_TRACE_EPI")) : (int)EPI_GELU_BF16;
   a.trace = (EPI == trace_epi) ? (unsigned long long*)g_gemm_trace : nullptr;
-  a.nt_out = CONVDR_NT_CTILE && (int64_t)a.rows * a.N * 2 >= ((int64_t)128 << 20);
+  a.nt_out = NT_CTILE && (int64_t)a.rows * a.N * 2 >= ((int64_t)128 << 20);
   a.tilesN = (a.N + T::TR - 1) / T::TR;
   a.tilesT = (int)ceil_div64(a.rows, T::TL);
   if (a.tilesT == 0) return 0;
@@ -44,7 +44,7 @@ inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
   const int64_t slots = (int64_t)device_cu_count() * (T::SMEM_BYTES > 80 * 1024 ? 1 : 2);
   int64_t grid = (int64_t)a.tilesN * a.tilesT;
   if (!dbg_np && splits == 1 && grid > slots) grid = slots;
-  const size_t lds = (CONVDR_GEMM_R3 && T::WAVES == 8) ? 160 * 1024 : T::SMEM_BYTES + T::TR * 4;
+  const size_t lds = T::WAVES == 8 ? 160 * 1024 : T::SMEM_BYTES + T::TR * 4;
   hipLaunchKernelGGL((k_gemm<EPI, T>), dim3((unsigned)grid, splits), dim3(T::THREADS), lds, st, a);
   CONVDR_CHECK_LAUNCH("k_gemm");
   return 0;

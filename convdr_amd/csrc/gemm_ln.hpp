@@ -43,22 +43,13 @@ struct GemmLnArgs {
 
 // 32-wide K slices: 64-byte LDS rows, 16 rows per wave per round, rounds 128 rows apart (so the swizzle term
 // (row >> 2) & 3 does not depend on the round).  Same buffer-descriptor addressing as gemm_nt.hpp's gemm_stage.
-#ifndef CONVDR_LN_DMA_LATE
-#define CONVDR_LN_DMA_LATE 1
-#endif
-// issuing waves: with the weight slice two steps ahead every wave issues its share AFTER its MFMAs (CONVDR_LN_DMA_LATE);
-// otherwise the younger half issues everything up front (TileCfg::DMA_WAVES)
-constexpr int LN_DMA_WAVES = (CONVDR_LN_DMA_LATE || !CONVDR_DMA_YOUNG_HALF) ? 8 : 4;
-constexpr int LN_DMA_FIRST = 8 - LN_DMA_WAVES;
-// CONVDR_LN_ROLES (with CONVDR_LN_DMA_LATE): as CONVDR_R3_ROLES in gemm_nt.hpp -- the older wave of each SIMD (waves 0-3),
-// which the matrix pipe serves first and which then idles in the barrier, issues the WHOLE weight slice of step t + 2 after
-// its MFMAs; the younger (waves 4-7) issues the activation slice of step t + 1 at the top of the step.
-#ifndef CONVDR_LN_ROLES
-#define CONVDR_LN_ROLES 1
-#endif
-constexpr bool LN_ROLES = CONVDR_LN_ROLES && CONVDR_LN_DMA_LATE;
-constexpr int LN_W_WAVES = LN_ROLES ? 4 : LN_DMA_WAVES, LN_W_FIRST = LN_ROLES ? 0 : LN_DMA_FIRST;   // weight slices
-constexpr int LN_A_WAVES = LN_ROLES ? 4 : LN_DMA_WAVES, LN_A_FIRST = LN_ROLES ? 4 : LN_DMA_FIRST;   // activation slices
+// Who issues the LDS-DMA, as R3Issue in gemm_nt.hpp: the older wave of each SIMD (waves 0-3), which the matrix pipe serves
+// first and which then idles in the barrier, issues the WHOLE weight slice of step t + 2 after its MFMAs; the younger
+// (waves 4-7) issues the activation slice of step t + 1 at the top of the step (FFN2 12.95 -> 12.44 ms per 12 layers).
+constexpr int LN_DMA_WAVES = 8, LN_DMA_FIRST = 0;                 // cooperative loads outside the main loop
+constexpr int LN_W_WAVES = 4, LN_W_FIRST = 0;                     // weight slices
+constexpr int LN_A_WAVES = 4, LN_A_FIRST = 4;                     // activation slices
+constexpr int LN_A_AUX = 2;   // cache policy of the activation-slice DMA (2 = nt: every activation row is read by ONE workgroup)
 
 template <int WAVES = LN_DMA_WAVES, int FIRST = LN_DMA_FIRST>   // WAVES issuing waves, the first of which is wave FIRST
 __device__ __forceinline__ StageSrc ln_stage_src(const bf16_t* __restrict__ G, int64_t ld, int64_t row0, int64_t nrows,
@@ -79,12 +70,6 @@ __device__ __forceinline__ StageSrc ln_stage_src(const bf16_t* __restrict__ G, i
   return s;
 }
 
-#ifndef CONVDR_LN_RES_AUX
-#define CONVDR_LN_RES_AUX 0   // cache policy of the residual half-tile DMA of the epilogue
-#endif
-#ifndef CONVDR_LN_A_AUX
-#define CONVDR_LN_A_AUX 2   // cache policy of the activation-slice DMA (2 = nt: every activation row is read by ONE workgroup)
-#endif
 template <int ROWS, int WAVES = LN_DMA_WAVES, int FIRST = LN_DMA_FIRST, int AUX = 0>
 __device__ __forceinline__ void ln_stage32(const StageSrc& s, int ks, char* lds_tile, int wave,
                                            uint32_t slice_stride = LN_SLICE * 2) {
@@ -96,16 +81,6 @@ __device__ __forceinline__ void ln_stage32(const StageSrc& s, int ks, char* lds_
   for (int i = 0; i < ROUNDS; ++i)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds_tile + (i * WAVES + wave) * 16 * 64), 16, s.voff,
                                              i * s.round_pitch + ks * slice_stride, 0, AUX);
-}
-
-// one DMA instruction (round i) of ln_stage32
-template <int ROWS>
-__device__ __forceinline__ void ln_stage32_round(const StageSrc& s, int ks, char* lds_tile, int wave, int i,
-                                                 uint32_t slice_stride) {
-  if (LN_DMA_FIRST > 0 && wave < LN_DMA_FIRST) return;   // wave-uniform
-  wave -= LN_DMA_FIRST;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds_tile + (i * LN_DMA_WAVES + wave) * 16 * 64), 16, s.voff,
-                                           i * s.round_pitch + ks * slice_stride, 0, 0);
 }
 
 __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
@@ -162,7 +137,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
   constexpr int LN_W_DPW = T::TR / (16 * LN_W_WAVES);   // weight DMA instructions per issuing wave per slice
   const bool w_wave = w.wave >= LN_W_FIRST && w.wave < LN_W_FIRST + LN_W_WAVES;   // (wave-uniform) this wave has weight slices in flight
   ln_stage32<T::TR, LN_W_WAVES, LN_W_FIRST>(srcW, 0, sW, w.wave, w_slice_stride);
-  ln_stage32<T::TL, LN_A_WAVES, LN_A_FIRST, CONVDR_LN_A_AUX>(srcA, 0, sA, w.wave, a_slice_stride);
+  ln_stage32<T::TL, LN_A_WAVES, LN_A_FIRST, LN_A_AUX>(srcA, 0, sA, w.wave, a_slice_stride);
   if (nk > 1) ln_stage32<T::TR, LN_W_WAVES, LN_W_FIRST>(srcW, 1, sW + LN_R_BYTES, w.wave, w_slice_stride);
 #ifdef CONVDR_ENABLE_TRACE   // per-wave stamps of K step 8 (and the top of step 9): a.trace[2048 * 16 + wg * 64 + wave * 8 + i]
 #define CONVDR_LN_STEP(i)                                                                                     \
@@ -180,11 +155,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
     CONVDR_LN_STEP(1)
     lds_barrier();   // NOT __syncthreads(): its fence would add vmcnt(0) and drain the slice that must stay in flight
     CONVDR_LN_STEP(2)
-    if (kt + 1 < nk) ln_stage32<T::TL, LN_A_WAVES, LN_A_FIRST, CONVDR_LN_A_AUX>(srcA, kt + 1, sA + ((kt + 1) & 1) * LN_L_BYTES, w.wave, a_slice_stride);
-    // The 12 weight DMA instructions of slice t + 2 are issued one per MFMA pair below, not in a block here: an
-    // issuing wave stalls ~70 cycles on each, and in a block those ~950 cycles come before its first MFMA (the wave
-    // was the critical path of the step: 950 + 1,250 cycles); interleaved, its already-issued MFMAs run under the
-    // stalls.  (Only affordable with the slice two steps ahead: the later issue delays the landing.)
+    if (kt + 1 < nk) ln_stage32<T::TL, LN_A_WAVES, LN_A_FIRST, LN_A_AUX>(srcA, kt + 1, sA + ((kt + 1) & 1) * LN_L_BYTES, w.wave, a_slice_stride);
     const bool issue_w = kt + 2 < nk;
     char* w_dst = sW + (wslot == 0 ? 2 : wslot - 1) * LN_R_BYTES;   // slot (kt + 2) % 3
     CONVDR_LN_STEP(3)
@@ -204,18 +175,11 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
 #pragma unroll
         for (int j = 0; j < T::NT; ++j)
           acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc.c[i][j], 0, 0, 0);
-#if !CONVDR_LN_DMA_LATE
-        static_assert(2 * T::MT == LN_W_DPW, "one weight DMA instruction per MFMA pair");
-        if (issue_w) ln_stage32_round<T::TR>(srcW, kt + 2, w_dst, w.wave, s * T::MT + i, w_slice_stride);
-#endif
       }
     }
-#if CONVDR_LN_DMA_LATE
-    // every wave issues its share of slice t + 2 once its MFMAs of this step are in the pipe: the ~60-cycle issue
-    // stalls then cost no matrix-pipe time (two steps of slack for the landing), and no wave has more DMA work than
-    // another
+    // the weight slice of step t + 2 once this wave's MFMAs of the step are in the pipe: the ~60-cycle issue stalls then
+    // cost no matrix-pipe time (two steps of slack for the landing)
     if (issue_w) ln_stage32<T::TR, LN_W_WAVES, LN_W_FIRST>(srcW, kt + 2, w_dst, w.wave, w_slice_stride);
-#endif
     CONVDR_LN_STEP(4)
   }
 
@@ -267,7 +231,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
       const int c = (pp & ~31) | ((pp ^ lr) & 31);
       const int tok = (lr >> 5) * 64 + nt * 32 + (lr & 31);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srcR.rsrc, (lptr_t)(sC + (i * 512 + w.wave * 64) * 16), 16,
-                                               (uint32_t)(tok * 1536 + c * 16), 0, 0, CONVDR_LN_RES_AUX);
+                                               (uint32_t)(tok * 1536 + c * 16), 0, 0, 0);
       pp += 32; lr += 5;
       if (pp >= 96) { pp -= 96; lr += 1; }
     }
@@ -366,7 +330,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
         const int c = (pp & ~31) | ((pp ^ lr) & 31);
         const int tok = (lr >> 5) * 64 + nt * 32 + (lr & 31);
         // through the output window [t0, rows): rows past the end are dropped by the bounds check; one 32-bit offset
-        __builtin_amdgcn_raw_buffer_store_b128(v4[j], dstX, (uint32_t)(tok * 1536 + c * 16), 0, CONVDR_NT_LN ? 2 : 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v4[j], dstX, (uint32_t)(tok * 1536 + c * 16), 0, NT_LN ? 2 : 0);
         pp += 32; lr += 5;
         if (pp >= 96) { pp -= 96; lr += 1; }
       }

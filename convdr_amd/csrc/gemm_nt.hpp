@@ -27,12 +27,6 @@
 namespace convdr {
 
 constexpr int GEMM_BK = 64;
-#ifndef CONVDR_FRAG_PIPELINE
-#define CONVDR_FRAG_PIPELINE 1
-#endif
-#ifndef CONVDR_DMA_YOUNG_HALF
-#define CONVDR_DMA_YOUNG_HALF 1
-#endif
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -49,18 +43,13 @@ __device__ __forceinline__ void store16(void* p, const V& v) {
   if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(raw4_t, v), (raw4_t*)p);
   else *(V*)p = v;
 }
-#ifndef CONVDR_NT_GEMM_BLK
-#define CONVDR_NT_GEMM_BLK 1
-#endif
-#ifndef CONVDR_NT_CTILE
-#define CONVDR_NT_CTILE 1
-#endif
-#ifndef CONVDR_NT_ATT
-#define CONVDR_NT_ATT 1
-#endif
-#ifndef CONVDR_NT_LN
-#define CONVDR_NT_LN 1
-#endif
+// Cache policy of the streamed activation stores (measured one at a time, DESIGN.md section 5.0: 45.22 -> 44.45 ms per
+// 2048-passage forward together): what the next kernel streams from HBM anyway stays out of L2, which is left to the
+// weights and the activation tile the column tiles of one token tile share.
+constexpr bool NT_GEMM_BLK = true;   // blocked GEMM outputs (FFN1's Hm, Q / K)
+constexpr bool NT_CTILE = true;      // parked bf16 tile outputs of 128 MB and more (V^T, ...)
+constexpr bool NT_ATT = true;        // attention context
+constexpr bool NT_LN = true;         // LayerNorm output of the projection + LayerNorm kernel
 // the same with a cache policy (aux 2 = nt: data that ONE workgroup reads once)
 template <int AUX>
 __device__ __forceinline__ void glds16_aux(const void* g, void* lds_wave_base) {
@@ -118,7 +107,7 @@ struct TileCfg {
   // texture path pass with the matrix pipe idle (s_memtime: 544 cycles for the older wave of a SIMD, 1,590 for the
   // younger, then both start their MFMAs).  With only the younger half (waves 4-7) issuing, the older wave of each
   // SIMD runs its MFMAs under the younger's DMA issue and the younger follows.
-  static constexpr int DMA_WAVES = (WAVES == 8 && CONVDR_DMA_YOUNG_HALF) ? 4 : WAVES;
+  static constexpr int DMA_WAVES = WAVES == 8 ? 4 : WAVES;
   static constexpr int DMA_FIRST = WAVES - DMA_WAVES;
   static constexpr int R_BYTES = TR * 128, L_BYTES = TL * 128;  // one K step of each operand
   static constexpr int STAGE_BYTES = R_BYTES + L_BYTES;
@@ -214,13 +203,6 @@ __device__ __forceinline__ void gemm_stage(const StageSrc& s, int kt, char* lds_
                                              i * s.round_pitch + kt * (GEMM_BK * 2), 0, AUX);
 }
 
-// one DMA instruction of a chunk (round i of gemm_stage), for the loops that thread the issue between their MFMAs
-template <int WAVES>
-__device__ __forceinline__ void gemm_stage_round(const StageSrc& s, int i, int kt, char* lds_tile, int wave) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds_tile + (i * WAVES + wave) * 8 * 128), 16, s.voff,
-                                           i * s.round_pitch + kt * (GEMM_BK * 2), 0, 0);
-}
-
 // LDS image: two stages of STAGE_BYTES = R_BYTES + L_BYTES, each [R tile | L tile] (a whole stage is one contiguous
 // region, so the idle stage can serve as epilogue scratch while the other already receives the next tile).
 template <class T>
@@ -277,7 +259,6 @@ __device__ __forceinline__ int gemm_nt_mainloop(const TileSrc<T>& src, int K, ch
     CONVDR_STEP_TRACE(3)
     const char* tR = smem + buf * T::STAGE_BYTES + offR;
     const char* tL = smem + buf * T::STAGE_BYTES + offL;
-#if CONVDR_FRAG_PIPELINE
     // Fragments of 16-wide K sub-step s + 1 are read while the MFMAs of sub-step s run (two register sets).  Left to
     // itself hipcc reuses one small set and parks an LDS round trip (s_waitcnt lgkmcnt(0..2)) in front of every
     // second MFMA pair -- ~240 idle pipe cycles per sub-step per wave in the s_memtime trace.
@@ -301,73 +282,29 @@ __device__ __forceinline__ int gemm_nt_mainloop(const TileSrc<T>& src, int K, ch
           acc.c[i][j] = mfma_32x32x16<F16>(fa[s & 1][i], fb[s & 1][j], acc.c[i][j]);
       __builtin_amdgcn_sched_barrier(0);
     }
-#else
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int ch = ((2 * s + w.hi) ^ sw) * 16;
-      bf16x8 a[T::MT], b[T::NT];
-#pragma unroll
-      for (int j = 0; j < T::NT; ++j) b[j] = *(const bf16x8*)(tL + j * 32 * 128 + ch);
-#pragma unroll
-      for (int i = 0; i < T::MT; ++i) a[i] = *(const bf16x8*)(tR + i * 32 * 128 + ch);
-#pragma unroll
-      for (int i = 0; i < T::MT; ++i)
-#pragma unroll
-        for (int j = 0; j < T::NT; ++j)
-          acc.c[i][j] = mfma_32x32x16<F16>(a[i], b[j], acc.c[i][j]);
-    }
-#endif
     CONVDR_STEP_TRACE(4)
   }
   return (nk + first_buf) & 1;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// The "R3" K step: THREE R slots and TWO L slots (3 x 32 KB + 2 x 32 KB = the whole 160 KB for 256 x 256 tiles).  Every
-// wave issues its share of the L chunk of step t + 1 right after its first fragment reads (the issue stalls pass under
-// the LDS round trip) and its share of the R chunk of step t + 2 AFTER its MFMAs of step t; counted vmcnt as in
+// The "R3" K step: THREE R slots and TWO L slots (3 x 32 KB + 2 x 32 KB = the whole 160 KB for 256 x 256 tiles; tiles with a
+// 128-row L operand leave 32 KB over).  The L chunk of step t + 1 is issued right after the first fragment reads (the issue
+// stalls pass under the LDS round trip) and the R chunk of step t + 2 AFTER the MFMAs of step t; counted vmcnt as in
 // gemm_ln.hpp.  No wave has a block of DMA issue in front of its MFMAs any more (in the two-stage loop the issuing wave of
 // a SIMD is the critical path of the step: 1.15 k cycles of issue, then its MFMAs, while its partner idles), and the two
 // waves of a SIMD run their MFMA phases together.  Measured on the scan (same box, A/B): 1.600 -> 1.502 ms emitting,
-// 1.327 -> 1.266 ms with +inf thresholds; the variants that ride the DMA instructions between the MFMA rows
-// (CONVDR_R3_VARIANT 1 / 2) are 1-2 % behind the two blocks -- re-measured in round 2 on the encoder GEMMs for every
-// placement (L sub-step, R sub-step) in {0,1} x {2,3}: 48.4-49.7 ms per 2048-passage forward against 47.8 for the blocks.
-// (gemm_stage_round exists because hipcc's host pass silently drops a template that calls the LDS-DMA builtin directly
-// inside the doubly nested unrolled MFMA loop; through a helper it instantiates.)
-#ifndef CONVDR_R3_VARIANT
-#define CONVDR_R3_VARIANT 0
-#endif
-#ifndef CONVDR_R3_LSUB   // variant 1: the sub-steps (0..3) whose MFMA rows carry the L / the R chunk's DMA instructions
-#define CONVDR_R3_LSUB 0
-#endif
-#ifndef CONVDR_R3_RSUB
-#define CONVDR_R3_RSUB 3
-#endif
-#ifndef CONVDR_R3_RSUB_OLD
-#define CONVDR_R3_RSUB_OLD 1
-#endif
-#ifndef CONVDR_R3_RSUB_YOUNG
-#define CONVDR_R3_RSUB_YOUNG 3
-#endif
-static_assert(CONVDR_R3_LSUB <= CONVDR_R3_RSUB, "the L chunk must be issued before the R chunk (counted vmcnt)");
-// CONVDR_R3_ROLES: who issues the LDS-DMA of the R3 K step.  0: every wave its share of both chunks.  1: the OLDER wave of
-// each SIMD (waves 0 .. WAVES / 2 - 1) issues the whole R chunk of step t + 2 after its MFMAs, the YOUNGER the whole L chunk
-// of step t + 1 at the top of the step.  The s_memtime anatomy of a step (tools/dbg/gemm_trace_blk.py) shows the older
-// wave -- served first by the matrix pipe -- done with its 32 MFMAs after ~1.25 k cycles and then ~1.15 k cycles in the
-// barrier, while the younger needs ~2.0 k, issues ITS R share (~210 cycles) only then, and everybody waits for it: with
+// 1.327 -> 1.266 ms with +inf thresholds.
+// Who issues the LDS-DMA of the R3 K step (8-wave tiles): the OLDER wave of each SIMD (waves 0 .. WAVES / 2 - 1) issues
+// the whole R chunk of step t + 2 after its MFMAs, the YOUNGER the whole L chunk of step t + 1 at the top of the step.
+// The s_memtime anatomy of a step (tools/dbg/gemm_trace_blk.py) shows the older wave -- served first by the matrix pipe --
+// done with its 32 MFMAs after ~1.25 k cycles and then ~1.15 k cycles in the barrier, while the younger needs ~2.0 k: with
 // roles the R issue rides in the older wave's idle time and the older wave starts its MFMAs without L issue in front.
-#ifndef CONVDR_R3_ROLES
-#define CONVDR_R3_ROLES 1
-#endif
-#if CONVDR_R3_ROLES && CONVDR_R3_VARIANT != 0
-#error "the between-the-rows variants of the R3 step assume that every wave issues its share"
-#endif
-#ifndef CONVDR_R3_L_AUX
-#define CONVDR_R3_L_AUX 0   // cache policy of the L operand's DMA (A/B builds)
-#endif
+// (Variants that thread the DMA instructions between the MFMA rows, s_setprio patterns and every-wave-its-share issue
+// were measured null or slower in rounds 2-3: DESIGN.md section 5.0; they live in the git history, not here.)
 template <class T>
 struct R3Issue {
-  static constexpr bool ROLES = CONVDR_R3_ROLES && T::WAVES == 8;
+  static constexpr bool ROLES = T::WAVES == 8;
   static constexpr int RW = ROLES ? T::WAVES / 2 : T::WAVES;    // waves issuing an R chunk (from wave 0)
   static constexpr int LW = ROLES ? T::WAVES / 2 : T::WAVES;    // waves issuing an L chunk ...
   static constexpr int LFIRST = ROLES ? T::WAVES / 2 : 0;       // ... from this wave on
@@ -378,11 +315,11 @@ struct R3Issue {
     if (issues_r(wave)) gemm_stage<T::TR, RW, 0, AUX>(s, kt, dst, wave);
   }
   static __device__ __forceinline__ void l(const StageSrc& s, int kt, char* dst, int wave) {
-    gemm_stage<T::TL, LW, LFIRST, CONVDR_R3_L_AUX>(s, kt, dst, wave);   // (returns at once for waves below LFIRST)
+    gemm_stage<T::TL, LW, LFIRST>(s, kt, dst, wave);   // (returns at once for waves below LFIRST)
   }
 };
 template <class T>
-struct TileSrcAll {   // all waves issue (or by role, see CONVDR_R3_ROLES)
+struct TileSrcAll {   // staging sources of the R3 loop (issue by role, see R3Issue)
   StageSrc R, L;
   __device__ __forceinline__ TileSrcAll(const bf16_t* __restrict__ Rp, int64_t ldr, int64_t nR, const bf16_t* __restrict__ Lp,
                                         int64_t ldl, int64_t nL, int64_t r0, int64_t l0, const WavePos<T>& w)
@@ -423,9 +360,6 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
   char* sL = smem + 3 * T::R_BYTES;
   if (!prologue_in_flight) gemm_r3_prologue<T, R_AUX>(src, K, smem, w, st, !r1_deferred);
   int rs = st.rs, ls = st.ls;
-#if defined(CONVDR_R3_STATIC_PRIO)   // experiment (cdna guide T5, static form): the younger half of the workgroup at priority 1
-  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= T::THREADS / 2) __builtin_amdgcn_s_setprio(1);
-#endif
 #ifdef CONVDR_ENABLE_TRACE   // stamps of K step 6 (and the top of step 7) for lane 0 of every wave: [wave][0..6]
 #define CONVDR_R3_STEP(i) \
   if (step_trace && kt == 6 + (i) / 6 && w.lane == 0) step_trace[w.wave * 8 + (i)] = __builtin_amdgcn_s_memtime();
@@ -455,61 +389,33 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
       for (int i = 0; i < T::MT; ++i) fa[set][i] = *(const bf16x8*)(tR + i * 32 * 128 + ch);
     };
     load_frags(0, 0);
-    constexpr int L_DPW = T::TL / (8 * T::WAVES);
-    static_assert(CONVDR_R3_VARIANT == 0 || (L_DPW <= T::MT && R_DPW <= T::MT), "one DMA instruction per MFMA row of a sub-step");
     const bool issue_l = kt + 1 < nk, issue_r = kt + 2 < nk;
     char* l_dst = sL + (ls ^ 1) * T::L_BYTES;
     const int rnext = rs == 0 ? 2 : rs - 1;   // (kt + 2) % 3
     char* r_dst = sR + rnext * T::R_BYTES;
-    // CONVDR_R3_VARIANT: 0 = L chunk as a block under the first fragments' LDS round trip, R chunk as a block after the
-    // MFMAs; 1 = both ride between the MFMA rows (L in sub-step 0, R in sub-step 3); 2 = L block, R between the rows
-#if CONVDR_R3_VARIANT != 1
+    // the L chunk of step t + 1 as a block under the first fragments' LDS round trip, the R chunk of step t + 2 as a
+    // block after the MFMAs
     __builtin_amdgcn_sched_barrier(0);
     if (r1_deferred && kt == 0 && issue_l) R3Issue<T>::template r<R_AUX>(src.R, 1, sR + (rs == 2 ? 0 : rs + 1) * T::R_BYTES, w.wave);
     if (issue_l) R3Issue<T>::l(src.L, kt + 1, l_dst, w.wave);
-#endif
     CONVDR_R3_STEP(3)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       if (s + 1 < 4) load_frags(s + 1, (s + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
-#if defined(CONVDR_R3_SETPRIO)   // experiment (cdna guide T5): priority 1 around each MFMA cluster
-      __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
-      for (int i = 0; i < T::MT; ++i) {
+      for (int i = 0; i < T::MT; ++i)
 #pragma unroll
         for (int j = 0; j < T::NT; ++j)
           acc.c[i][j] = mfma_32x32x16<F16>(fa[s & 1][i], fb[s & 1][j], acc.c[i][j]);
-#if CONVDR_R3_VARIANT == 1
-        if (s == CONVDR_R3_LSUB && r1_deferred && kt == 0 && issue_l && i < R_DPW)
-          gemm_stage_round<T::WAVES>(src.R, i, 1, sR + (rs == 2 ? 0 : rs + 1) * T::R_BYTES, w.wave);
-        if (s == CONVDR_R3_LSUB && issue_l && i < L_DPW) gemm_stage_round<T::WAVES>(src.L, i, kt + 1, l_dst, w.wave);
-#endif
-#if CONVDR_R3_VARIANT == 1 || CONVDR_R3_VARIANT == 2
-        if (s == CONVDR_R3_RSUB && issue_r && i < R_DPW) gemm_stage_round<T::WAVES>(src.R, i, kt + 2, r_dst, w.wave);
-#endif
-#if CONVDR_R3_VARIANT == 3   // the two waves of a SIMD issue their R chunk in DIFFERENT sub-steps (one stalls, the other multiplies)
-        if (s == (w.wave < T::WAVES / 2 ? CONVDR_R3_RSUB_OLD : CONVDR_R3_RSUB_YOUNG) && issue_r && i < R_DPW)
-          gemm_stage_round<T::WAVES>(src.R, i, kt + 2, r_dst, w.wave);
-#endif
-      }
-#if defined(CONVDR_R3_SETPRIO)
-      __builtin_amdgcn_s_setprio(0);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     CONVDR_R3_STEP(4)
-#if CONVDR_R3_VARIANT == 0
     if (issue_r) R3Issue<T>::template r<R_AUX>(src.R, kt + 2, r_dst, w.wave);
-#endif
     CONVDR_R3_STEP(5)
     rs = rs == 2 ? 0 : rs + 1;
     ls ^= 1;
   }
-#if defined(CONVDR_R3_STATIC_PRIO)
-  __builtin_amdgcn_s_setprio(0);
-#endif
   return R3Slots{rs, ls};
 }
 

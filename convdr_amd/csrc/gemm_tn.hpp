@@ -34,15 +34,12 @@ struct TnCfg {
   static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
 };
 
-// CONVDR_TN_ROLES: in the 8-wave tile the YOUNGER wave of each SIMD (waves 4-7) issues the whole next K step's DMA at the top
+// Issue by role: in the 8-wave tile the YOUNGER wave of each SIMD (waves 4-7) issues the whole next K step's DMA at the top
 // of the step -- the matrix pipe serves the older wave first, so the younger is not on the critical path there -- and the
-// older wave goes straight to its fragments (see CONVDR_R3_ROLES in gemm_nt.hpp).
-#ifndef CONVDR_TN_ROLES
-#define CONVDR_TN_ROLES 1
-#endif
+// older wave goes straight to its fragments (see R3Issue in gemm_nt.hpp).
 template <class T>
 struct TnIssue {
-  static constexpr bool ROLES = CONVDR_TN_ROLES && T::WAVES == 8;
+  static constexpr bool ROLES = T::WAVES == 8;
   static constexpr int W = ROLES ? T::WAVES / 2 : T::WAVES;      // issuing waves ...
   static constexpr int FIRST = ROLES ? T::WAVES / 2 : 0;        // ... from this one on
 };

@@ -500,10 +500,7 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan_r3(const ScanArgs a) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // the 256 x 128 tile serves scans with ONE query tile (at most 128 queries): every passage chunk is read exactly once,
   // so its DMA is non-temporal -- the block streams past L2 instead of through it
-#ifndef CONVDR_SCAN_P_NT
-#define CONVDR_SCAN_P_NT 1
-#endif
-  constexpr int P_AUX = (CONVDR_SCAN_P_NT && T::TL <= 128) ? 2 : 0;
+  constexpr int P_AUX = T::TL <= 128 ? 2 : 0;
   const uint32_t ntiles = (uint32_t)a.nPt * (uint32_t)a.nQt;
   const uint32_t xcd = blockIdx.x & 7u, q8 = ntiles >> 3, r8 = ntiles & 7u;
   const uint32_t chunk_base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;

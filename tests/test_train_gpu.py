@@ -993,6 +993,33 @@ def test_dropout_forward_backward_match_oracle_with_replayed_mask(p_h, p_a):
     margin(tag + "/eval_emb_1-cos", 1 - cosine(e1.cpu().numpy(), eval_emb.numpy()).min(), 5e-5)
 
 
+def test_attention_dropout_backward_on_odd_lengths():
+    """The dK / dV kernel shares one mask hash between the two lanes of a key pair (DPP swap).  For an odd-length sequence
+    the last key's partner lane lies past the sequence; its role in the swap must come from the lane parity, not from the
+    clamped key (round-3 advisor finding: dK / dV of the last token of every odd-length sequence used another mask than
+    the forward).  Short odd sequences make that token a large share of the key / value weight gradients."""
+    from convdr_amd import train as TR
+    rs = np.random.RandomState(47)
+    B, L, lens = 8, 16, [1, 3, 5, 7, 9, 11, 13, 15]
+    p_h, p_a = 0.0, 0.4
+    model = _tiny_dropout(p_h, p_a, layers=1)
+    model.dropout_seed = 99
+    ids, mask = _batch(rs, B, L, lens)
+    G = torch.from_numpy(rs.randn(B, 768).astype(np.float32))
+    seed = TR.dropout_seed_of(model, 0)
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    ref_emb = OE.rdot_nll_emb(sd, ids, mask, num_layers=1, num_heads=2, dropout=(p_h, p_a, seed))
+    (ref_emb * G).sum().backward()
+    model = model.cuda().train()
+    emb = model(ids.cuda(), mask.cuda())
+    (emb * G.cuda()).sum().backward()
+    tag = "dropout_odd_lengths"
+    for n, p in model.named_parameters():
+        if any(s in n for s in ("self.value.weight", "self.key.weight", "self.query.weight", "self.value.bias")):
+            _compare(n, p.grad, sd[n].grad, cos_tol=1 - 3e-4, norm_tol=0.01, tag=tag)
+    _record_worst(tag, 3e-4, 0.01)
+
+
 def test_dropout_statistics():
     """Keep rate, inverted scaling and independence of the device masks, read back through a model whose activations make
     the mask observable: with all-ones LayerNorm-free probes this would need kernel hooks, so the check goes through the
