@@ -146,6 +146,8 @@ register("convdr_grad_norm_clip", C.c_int, [_p, C.c_int64, C.c_float, C.c_float,
 register("convdr_scale_f32", C.c_int, [_p, C.c_int64, _p, _p])
 register("convdr_adamw_step", C.c_int, [_p, _p, _p, _p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                                         C.c_double, C.c_int, C.c_int, _p, _p])
+register("convdr_adamw_step_packed", C.c_int, [_p, _p, _p, _p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                               C.c_double, C.c_int, C.c_int, _p, _p, C.c_int64, _p])
 register("convdr_set_option", C.c_int, [C.c_char_p, C.c_int64])
 register("convdr_topk_merge", C.c_int, [_p, _p, C.c_int, C.c_int64, _p, _p, C.c_int, C.c_int64, C.c_int, C.c_int, _p, _p,
                                         C.c_int64, _p])

@@ -271,6 +271,8 @@ struct AttnBwdArgs {
   bf16_t* dQKV;        // [rows, 3H]
   float scale;
   DropSite drop;       // attention-probability dropout of the forward (thresh 0 = off)
+  int q_limit;         // dK / dV kernel: > 0 = only the first q_limit queries of a sequence carry gradient (last layer: the
+                       // CLS query; a multiple of 64): the query loop stops there
 };
 
 constexpr int ATTB_DQ_SMEM = 2 * 2 * ATT_TILE;            // two sets of (K tile | V tile)
@@ -464,14 +466,15 @@ static __global__ void __launch_bounds__(256, 2) k_attention_bwd_dkv(const AttnB
                                                (uint32_t)lane * 4, soff, 0, 0);
     }
   };
+  const int qlen = (a.q_limit > 0 && a.q_limit < len) ? a.q_limit : len;   // queries that carry gradient
   stage(0, 0);
-  if (len > 64) stage(64, 1);
+  if (qlen > 64) stage(64, 1);
   const bool active = k0 + wave * 32 < len;
-  for (int q0 = 0, it = 0; q0 < len; q0 += 64, ++it) {
+  for (int q0 = 0, it = 0; q0 < qlen; q0 += 64, ++it) {
     const int buf = it & 1;
     lds_dma_wait_all();
     __syncthreads();
-    if (it >= 1 && q0 + 64 < len) stage(q0 + 64, buf ^ 1);
+    if (it >= 1 && q0 + 64 < qlen) stage(q0 + 64, buf ^ 1);
     if (!active) continue;
     const char* sQ = smem + buf * SET;
     const char* sdO = sQ + ATT_TILE;

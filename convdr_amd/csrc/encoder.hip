@@ -284,6 +284,10 @@ extern "C" int convdr_set_option(const char* name, int64_t value) {
     g_hm_blocked = value;
     return 0;
   }
+  if (strcmp(name, "gemm_tile_policy") == 0) {   // 0 cost model, 1 / 2 / 3 force 256 x 256 / 256 x 128 / 128 x 128 (gemm_launch.hpp)
+    g_gemm_tile_policy = value;
+    return 0;
+  }
   if (strcmp(name, "fused_ln_max_k") == 0) {
     g_fused_ln_max_k = value;
     return 0;

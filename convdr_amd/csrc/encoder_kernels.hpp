@@ -361,12 +361,15 @@ struct CTile {
   static constexpr int PASSES = (T::TL * T::TR * 2) / T::STAGE_BYTES;    // Tile256: 2, Tile128: 1
   static constexpr int NTP = T::NT / PASSES;                             // MFMA column blocks per pass
   static constexpr int ROWS = T::TL / PASSES;
-  static_assert(PASSES >= 1 && PASSES * NTP == T::NT && ROWS * T::TR * 2 <= T::STAGE_BYTES, "C tile must fit a stage");
+  static_assert(PASSES >= 1 && PASSES * NTP == T::NT, "a pass is a whole number of MFMA column blocks");
   // The parked pass lives in two half regions (rows [0, HALF) and [HALF, ROWS)): one contiguous stage in the
   // two-stage kernels (hi = lo + HALF_BYTES), two separate dead operand slots in the R3 form.
   static constexpr int HALF = ROWS / 2, HALF_BYTES = HALF * T::TR * 2;
   struct Base { uint32_t lo, hi; };
-  __device__ static __forceinline__ Base contiguous(const char* sC) { return Base{lds_off(sC), lds_off(sC) + HALF_BYTES}; }
+  __device__ static __forceinline__ Base contiguous(const char* sC) {
+    static_assert(2 * HALF_BYTES <= T::STAGE_BYTES, "a parked pass must fit the idle stage");
+    return Base{lds_off(sC), lds_off(sC) + HALF_BYTES};
+  }
   // Wave-local form: a wave parks ITS OWN part of the pass -- 32 NTP token rows x the 32 MT features it computed, 8 KB,
   // rows of MT * 64 bytes, 16-byte chunk index XOR row -- and writes it out itself, 64 / CW whole rows per instruction.
   // No workgroup barrier between a pass's arithmetic and its stores, so the two waves of a SIMD drift apart and one
@@ -620,10 +623,18 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
       }
     }
     // epilogue scratch: the stage (R3: the two slots) the last K step read
-    const typename CT::Base sC =
-        R3 ? typename CT::Base{lds_off(smem + (st.rs == 0 ? 2 : st.rs - 1) * T::R_BYTES),
-                               lds_off(smem + 3 * T::R_BYTES + (st.ls ^ 1) * T::L_BYTES)}
-           : CT::contiguous(smem + (idle ^ 1) * T::STAGE_BYTES);
+    // (tiles with a 128-row L operand: an L slot is smaller than half a parked pass, and the 32 KB of the 160 that the
+    //  operand slots leave over take its place)
+    typename CT::Base sC;
+    if constexpr (R3) {
+      static_assert(T::R_BYTES >= CT::HALF_BYTES && 3 * T::R_BYTES + 2 * T::L_BYTES + (T::L_BYTES >= CT::HALF_BYTES ? 0 : CT::HALF_BYTES) <= 160 * 1024,
+                    "parked pass: one dead R slot + one dead L slot (or the spare LDS behind the slots)");
+      sC = typename CT::Base{lds_off(smem + (st.rs == 0 ? 2 : st.rs - 1) * T::R_BYTES),
+                             T::L_BYTES >= CT::HALF_BYTES ? lds_off(smem + 3 * T::R_BYTES + (st.ls ^ 1) * T::L_BYTES)
+                                                          : lds_off(smem + 3 * T::R_BYTES + 2 * T::L_BYTES)};
+    } else {
+      sC = CT::contiguous(smem + (idle ^ 1) * T::STAGE_BYTES);
+    }
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));   // opaque: keeps the epilogue's lane-dependent addresses out of the main loop's registers
     const WavePos<T> we(tid_e);

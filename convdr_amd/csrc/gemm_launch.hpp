@@ -13,7 +13,7 @@ inline void* g_attn_trace = nullptr;
 
 template <int EPI, class T>
 inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
-  static_assert(T::TR == T::TL, "square tiles: the QKV kernel swaps operand roles per tile");
+  static_assert(T::TR == T::TL || EPI != EPI_QKV, "square tiles: the QKV kernel swaps operand roles per tile");
   static DeviceOnce attr_done;   // function attributes are per device
   if (attr_done.first()) {
     CONVDR_CHECK_HIP(
@@ -50,8 +50,17 @@ inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
   return 0;
 }
 
-// 256 x 256 tiles when the problem fills them (N % 256 == 0, for QKV also H % 256 == 0, and enough token rows
-// to occupy the 256 CUs), else 128 x 128.
+// Tile choice.  256 x 256 when the problem fills the chip with them (N % 256 == 0, for QKV also H % 256 == 0, >= 192
+// tiles); else, for N % 256 == 0, whichever of 256 x 256 / 256 x 128 (TileWide) / 128 x 128 has the cheapest last round:
+// cost = rounds over the resident slots x (K steps x step time + epilogue), step times as measured on MI355X at the
+// configs[2] training size (profiles/r04_tile_policy.txt).  g_gemm_tile_policy (convdr_set_option "gemm_tile_policy"):
+// 0 = this model, 1 / 2 / 3 = force 256 x 256 / 256 x 128 / 128 x 128 where the shape allows (A/B runs).
+inline int64_t g_gemm_tile_policy = 0;
+struct TileCost { double step_us, epi_us; int per_cu; };
+inline double gemm_tile_cost(int64_t tiles, int nk, const TileCost& c) {
+  const int64_t slots = (int64_t)device_cu_count() * c.per_cu;
+  return (double)ceil_div64(tiles, slots) * (nk * c.step_us + c.epi_us);
+}
 template <int EPI>
 inline int launch_gemm(GemmArgs a, hipStream_t st, const char* prof_name) {
   CONVDR_REQUIRE(a.K % GEMM_BK == 0 && a.N % 4 == 0, "gemm: need K %% 64 == 0 and N %% 4 == 0 (K=%d N=%d)", a.K, a.N);
@@ -59,11 +68,31 @@ inline int launch_gemm(GemmArgs a, hipStream_t st, const char* prof_name) {
   if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_GELU_SAVE || EPI == EPI_GELU_BLK)
     CONVDR_REQUIRE(a.N % 8 == 0, "gemm: bf16 outputs are stored 16 bytes at a time, need N %% 8 == 0 (N=%d)", a.N);
   const bool fits = a.N % 256 == 0 && (EPI != EPI_QKV || a.H % 256 == 0);
-  int64_t tiles256 = (int64_t)(a.N / 256) * ceil_div64(a.rows, 256);
-  if (EPI == EPI_SLAB_F32 && a.k_split_len) tiles256 *= a.K / a.k_split_len;
+  int splits = 1;
+  if (EPI == EPI_SLAB_F32 && a.k_split_len) splits = a.K / a.k_split_len;
+  const int64_t tiles256 = (int64_t)(a.N / 256) * ceil_div64(a.rows, 256) * splits;
   static const int force128 = getenv("CONVDR_DBG_TILE128") ? atoi(getenv("CONVDR_DBG_TILE128")) : 0;
   static const int min256 = getenv("CONVDR_TILE256_MIN_TILES") ? atoi(getenv("CONVDR_TILE256_MIN_TILES")) : 192;   // A/B knob
-  if (fits && tiles256 >= min256 && !force128) return launch_gemm_t<EPI, Tile256>(a, st, prof_name);
+  constexpr bool WIDE_OK = EPI == EPI_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU_SAVE || EPI == EPI_GELU_BF16 || EPI == EPI_F32;
+  int choice = (fits && tiles256 >= min256) ? 256 : 128;
+  if (fits && WIDE_OK && !force128) {
+    if (g_gemm_tile_policy == 1) choice = 256;
+    else if (g_gemm_tile_policy == 2) choice = 192;
+    else if (g_gemm_tile_policy == 3) choice = 128;
+    else {
+      const int nk = (EPI == EPI_SLAB_F32 && a.k_split_len ? a.k_split_len : a.K) / GEMM_BK;
+      const int64_t tilesW = (int64_t)(a.N / 256) * ceil_div64(a.rows, 128) * splits;
+      const int64_t tiles128 = (int64_t)(a.N / 128) * ceil_div64(a.rows, 128) * splits;
+      static const TileCost c256{1.42, 4.0, 1}, cW{1.32, 2.5, 1}, c128{1.30, 2.0, 2};
+      const double t256 = gemm_tile_cost(tiles256, nk, c256), tW = gemm_tile_cost(tilesW, nk, cW), t128 = gemm_tile_cost(tiles128, nk, c128);
+      choice = (t256 <= tW && t256 <= t128) ? 256 : (tW <= t128 ? 192 : 128);
+    }
+  }
+  if (force128) choice = 128;
+  if (choice == 256) return launch_gemm_t<EPI, Tile256>(a, st, prof_name);
+  if constexpr (WIDE_OK) {
+    if (choice == 192) return launch_gemm_t<EPI, TileWide>(a, st, prof_name);
+  }
   return launch_gemm_t<EPI, Tile128>(a, st, prof_name);
 }
 

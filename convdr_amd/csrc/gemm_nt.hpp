@@ -121,6 +121,12 @@ using Tile256 = TileCfg<2, 4, 4, 2>;
 // (3 R slots of 32 KB + 2 L slots of 16 KB = 128 KB) two 32 KB passage chunks are in flight per CU, against 2 x 16 KB with
 // two 128 x 128 workgroups.
 using TileTall = TileCfg<2, 4, 4, 1>;
+// 256 x 128 for the encoder GEMMs (k_gemm: 256 features x 128 tokens): 4 x 2 waves of 64 x 64, i.e. 2 x 2 MFMA tiles per
+// wave -- 4 fragment reads per 4 MFMAs where TileTall's 128 x 32 wave needs 5 -- on the same R3 K step.  Serves problems
+// whose 256 x 256 tiling leaves the 256 CUs a bad last round (or none at all: N = 768 at ~9 k training rows is 108 tiles):
+// half the tile, so twice the tiles, at 1.5 x the L2 -> LDS bytes per FLOP of 256 x 256 instead of the 2 x of the
+// 128 x 128 engine, and one 8-wave workgroup per CU whose K step is long enough to hide its own barrier.
+using TileWide = TileCfg<4, 2, 2, 2>;
 
 template <class T>
 struct GemmAcc {

@@ -36,12 +36,20 @@ struct TrainBufs {
   float *G0, *G1, *Drow, *slab, *part, *dcls_y, *dcls_f, *dhead_y;
   bf16_t *dctx, *dhead_yb, *dclsb;
   bf16_t *dXb1, *dXb2;   // dgrad outputs of FFN1 / the QKV projection (added to the fp32 stream by the next LayerNorm backward)
+  // Last layer, CLS pooling: only the B CLS rows are live after the attention (models.py:43), so the output projection,
+  // LayerNorm and FFN of that layer -- forward and backward -- run on compact [B, .] copies of those rows (c_*).
+  bf16_t *c_ctx, *c_xin, *c_X1, *c_Hpre, *c_Hm;          // forward, kept for the backward
+  float* c_Y1;
+  bf16_t *c_dYb, *c_dHpre, *c_dYb2, *c_dctx;             // backward
+  float *c_dX1f, *c_dY1, *c_slab;
+  size_t c_slab_elems;
   int64_t ldt, Tp;
   size_t slab_elems;
   size_t total;
 };
 
 constexpr int TRAIN_MAX_LAYERS = 48;
+constexpr int CLS_MAX_SPLIT = 16;   // contraction slices of the compact (CLS-row) projections of the last layer
 constexpr int LN_BWD_BLOCKS = 512;
 constexpr int COLSUM_CHUNKS = 64;
 constexpr size_t SLAB_ELEMS = (size_t)16 * 3072 * 768;  // >= splits * N * K for every weight of a base-size model
@@ -70,10 +78,15 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
     s.Xin = (bf16_t*)take(rs * H * 2);
     s.QKV = (bf16_t*)take(rs * 3 * H * 2);
     s.ctx = (bf16_t*)take(rs * H * 2);
+    s.LSE = (float*)take((size_t)c->heads * p.ldt * 4);
+    if (l + 1 == c->layers && !c->pool_mean) {   // CLS-only tail: these live in the compact c_* buffers
+      s.X1 = s.Hpre = s.Hm = nullptr;
+      s.Y1 = s.Y2 = nullptr;
+      continue;
+    }
     s.X1 = (bf16_t*)take(rs * H * 2);
     s.Hpre = (bf16_t*)take(rs * I * 2);
     s.Hm = (bf16_t*)take(rs * I * 2);
-    s.LSE = (float*)take((size_t)c->heads * p.ldt * 4);
     s.Y1 = (float*)take(rs * H * 4);
     s.Y2 = (float*)take(rs * H * 4);
   }
@@ -106,6 +119,20 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
   }
   p.dXb1 = (bf16_t*)take(rs * H * 2);
   p.dXb2 = (bf16_t*)take(rs * H * 2);
+  p.c_ctx = (bf16_t*)take(Bp * H * 2);
+  p.c_xin = (bf16_t*)take(Bp * H * 2);
+  p.c_X1 = (bf16_t*)take(Bp * H * 2);
+  p.c_Hpre = (bf16_t*)take(Bp * I * 2);
+  p.c_Hm = (bf16_t*)take(Bp * I * 2);
+  p.c_Y1 = (float*)take(Bp * H * 4);
+  p.c_dYb = (bf16_t*)take(Bp * H * 2);
+  p.c_dHpre = (bf16_t*)take(Bp * I * 2);
+  p.c_dYb2 = (bf16_t*)take(Bp * H * 2);
+  p.c_dctx = (bf16_t*)take(Bp * H * 2);
+  p.c_dX1f = (float*)take(Bp * H * 4);
+  p.c_dY1 = (float*)take(Bp * H * 4);
+  p.c_slab_elems = (size_t)CLS_MAX_SPLIT * Bp * H;
+  p.c_slab = (float*)take(p.c_slab_elems * 4);
   p.dctx = (bf16_t*)take(rs * H * 2);
   p.dhead_yb = (bf16_t*)take(Bp * E * 2);
   p.dclsb = (bf16_t*)take(Bp * H * 2);
@@ -307,13 +334,28 @@ static int colsum_chunks(int64_t rows) { return rows >= 2048 ? COLSUM_CHUNKS : 8
 // (dense bias = column sums of dX, dgamma, dbeta) go to part[blocks][3][H]; returns the number of blocks.
 static int ln_bwd_kernel(const float* dY, const bf16_t* dYadd, const float* Yin, int64_t rows, int H, const float* g, float eps,
                          float* dXf, bf16_t* dXb, float* part, int* blocks_out, hipStream_t st,
-                         const DropSite drop = DropSite{0u, 0u, 1.f}) {
+                         const DropSite drop = DropSite{0u, 0u, 1.f}, const int32_t* row_map = nullptr) {
   const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
   ProfScope prof("layernorm_bwd", st);
-  hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, dYadd, Yin, rows, H, g, eps, dXf, dXb, part, drop);
+  hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, dYadd, Yin, rows, H, g, eps, dXf, dXb, part, drop, row_map);
   CONVDR_CHECK_LAUNCH("k_layernorm_bwd");
   *blocks_out = blocks;
   return 0;
+}
+
+// Projection of the B compact CLS rows of the last layer, A[B, K] W[N, K]^T -> c_slab[slices][B][N]: the contraction is cut
+// into slices of 3 K steps so that the launch has N / 128 x slices tiles -- as one whole-contraction tile per 128 features it
+// would be a 12- (K = 768) or 48-step (K = 3072) latency chain on 6 compute units, as long as the full-size GEMM it replaces.
+static int cls_projection(const bf16_t* W, const bf16_t* A, int B, int N, int K, const TrainBufs& p, hipStream_t st, int* nsplit) {
+  const int nk = K / GEMM_BK;
+  int ns = nk / 3 < CLS_MAX_SPLIT ? nk / 3 : CLS_MAX_SPLIT;
+  while (ns > 1 && nk % ns) --ns;
+  if (ns < 1) ns = 1;
+  CONVDR_REQUIRE((size_t)ns * B * N <= p.c_slab_elems, "train: CLS-row slab too small (%d x %d x %d)", ns, B, N);
+  GemmArgs g{};
+  g.rows = B; g.W = W; g.X = A; g.N = N; g.K = K; g.k_split_len = K / ns; g.Cf = p.c_slab;
+  *nsplit = ns;
+  return launch_gemm<EPI_SLAB_F32>(g, st, "gemm_cls");
 }
 
 struct ReduceList {
@@ -398,11 +440,39 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
     GemmArgs g{};
     g.rows = rows; g.W = (const bf16_t*)lw->wqkv; g.X = s.Xin; g.N = 3 * H; g.K = H; g.bias = lw->bqkv; g.Cb = s.QKV;
     if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_qkv")) return e;
+    // Last layer with CLS pooling: only the B CLS rows are live from here on (models.py:43).  The attention runs its first
+    // query tile only (it holds row 0 of every sequence), and output projection, LayerNorm and FFN run on compact [B, .]
+    // copies of those rows (TrainBufs::c_*; dropout masks indexed by the packed row, so the result is the full layer's).
+    const bool cls_tail = l + 1 == cfg->layers && !cfg->pool_mean;
     {
       AttnTrainArgs a{s.QKV, rows, cu_seqlens, seq_lens, H, s.ctx, drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att), s.LSE, p.ldt, 0.125f};
       ProfScope prof("attention", st);
-      hipLaunchKernelGGL(k_attention_train_fwd, dim3((max_len + 127) / 128, cfg->heads, B), dim3(256), 4 * ATT_TILE, st, a);
+      hipLaunchKernelGGL(k_attention_train_fwd, dim3(cls_tail ? 1 : (max_len + 127) / 128, cfg->heads, B), dim3(256), 4 * ATT_TILE, st, a);
       CONVDR_CHECK_LAUNCH("k_attention_train_fwd");
+    }
+    if (cls_tail) {
+      hipLaunchKernelGGL(k_gather_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, s.ctx, (const float*)nullptr, p.c_ctx, (float*)nullptr);
+      hipLaunchKernelGGL(k_gather_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, s.Xin, (const float*)nullptr, p.c_xin, (float*)nullptr);
+      CONVDR_CHECK_LAUNCH("k_gather_cls");
+      const unsigned fin_blocks = (unsigned)ceil_div64((int64_t)B * H / 4, 256);
+      int ns = 1;
+      if (int e = cls_projection((const bf16_t*)lw->wo, p.c_ctx, B, H, H, p, st, &ns)) return e;
+      hipLaunchKernelGGL(k_slab_finish, dim3(fin_blocks), dim3(256), 0, st, p.c_slab, ns, B, H, lw->bo, p.c_xin, cu_seqlens,
+                         drop_site(dseed, DROP_SITE_ATTN_OUT, l, p_hid), p.c_Y1);
+      hipLaunchKernelGGL(k_layernorm, dim3((B + 3) / 4), dim3(256), 0, st, p.c_Y1, (int64_t)B, H, lw->ln1_g, lw->ln1_b, cfg->ln_eps, p.c_X1,
+                         (float*)nullptr);
+      g = GemmArgs{};
+      g.rows = B; g.W = (const bf16_t*)lw->w1; g.X = p.c_X1; g.N = I; g.K = H; g.bias = lw->b1; g.Cb = p.c_Hm; g.Cb2 = p.c_Hpre;
+      if (int e = launch_gemm<EPI_GELU_SAVE>(g, st, "gemm_cls")) return e;
+      if (int e = cls_projection((const bf16_t*)lw->w2, p.c_Hm, B, H, I, p, st, &ns)) return e;
+      hipLaunchKernelGGL(k_slab_finish, dim3(fin_blocks), dim3(256), 0, st, p.c_slab, ns, B, H, lw->b2, p.c_X1, cu_seqlens,
+                         drop_site(dseed, DROP_SITE_FFN_OUT, l, p_hid), p.cls_y);   // = the CLS rows of the pre-LayerNorm2 sums
+      CONVDR_CHECK_LAUNCH("cls tail");
+      float* cls_out = cfg->out_dim > 0 ? p.cls_f : out;
+      hipLaunchKernelGGL(k_layernorm, dim3((B + 3) / 4), dim3(256), 0, st, p.cls_y, (int64_t)B, H, lw->ln2_g, lw->ln2_b,
+                         cfg->ln_eps, p.cls_b, cls_out);
+      CONVDR_CHECK_LAUNCH("k_layernorm(cls)");
+      continue;
     }
     g = GemmArgs{};
     g.rows = rows; g.W = (const bf16_t*)lw->wo; g.X = s.ctx; g.N = H; g.K = H; g.bias = lw->bo; g.Cf = s.Y1; g.R = s.Xin;
@@ -428,14 +498,7 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
       hipLaunchKernelGGL(k_masked_mean, dim3(B), dim3(256), 0, st, p.Xout, cu_seqlens, seq_lens, H, p.cls_b,
                          cfg->out_dim > 0 ? p.cls_f : out);
       CONVDR_CHECK_LAUNCH("k_masked_mean");
-    } else {
-      hipLaunchKernelGGL(k_gather_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, (const bf16_t*)nullptr, s.Y2,
-                         (bf16_t*)nullptr, p.cls_y);
-      float* cls_out = cfg->out_dim > 0 ? p.cls_f : out;
-      hipLaunchKernelGGL(k_layernorm, dim3((B + 3) / 4), dim3(256), 0, st, p.cls_y, (int64_t)B, H, lw->ln2_g, lw->ln2_b,
-                         cfg->ln_eps, p.cls_b, cls_out);
-      CONVDR_CHECK_LAUNCH("k_layernorm(cls)");
-    }
+    }   // (CLS pooling: the last layer took the cls_tail branch above)
   }
   if (cfg->out_dim > 0) {
     GemmArgs g{};
@@ -492,9 +555,7 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     if (int e = ln_bwd(dcls, nullptr, p.cls_y, B, H, w->layers[NL - 1].ln2_g, cfg->ln_eps, p.dcls_y, (bf16_t*)nullptr, p,
                        p_hid > 0.f ? nullptr : lg_last->b2, lg_last->ln2_g, lg_last->ln2_b, st))
       return e;
-    CONVDR_CHECK_HIP(hipMemsetAsync(p.G0, 0, (size_t)rows * H * 4, st));
-    hipLaunchKernelGGL(k_scatter_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, p.dcls_y, p.G0);
-    CONVDR_CHECK_LAUNCH("k_scatter_cls");
+    // (p.dcls_y [B, H]: the gradient of the CLS rows' pre-LayerNorm2 sums; the last layer's tail stays on those B rows)
   }
 
   WgradFork& wf = WgradFork::get();
@@ -513,59 +574,88 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     const convdr_layer_grads* lg = &gr->layers[l];
     const LayerSave& s = P.layers[l];
     const LayerBwd& d = P.bwd[l];
-    const bool last = l == NL - 1 && !pool_mean;   // "last" = the CLS-only shortcut of the last layer
-    // d(pre-LN2 sum Y2): for the last layer cur_f already is that (CLS rows only), else LayerNorm2 backward
-    float* dY2;
+    const bool last = l == NL - 1 && !pool_mean;   // the CLS-only tail of the last layer (see the forward's cls_tail)
     int blocks_ln2 = 0, blocks_ln1 = 0;
+    const int chunks_c = colsum_chunks(B);         // column-sum chunks of the compact [B, .] matrices
+    GemmArgs g{};
+    float* dY1;
     if (!last) {
-      if (int e = ln_bwd_kernel(cur_f, cur_b, s.Y2, rows, H, lw->ln2_g, cfg->ln_eps, other, d.dYb, d.part_ln2, &blocks_ln2, st,
+      // d(pre-LN2 sum Y2) = LayerNorm2 backward of the incoming gradient
+      float* dY2 = other;
+      if (int e = ln_bwd_kernel(cur_f, cur_b, s.Y2, rows, H, lw->ln2_g, cfg->ln_eps, dY2, d.dYb, d.part_ln2, &blocks_ln2, st,
                                 drop_site(dseed, DROP_SITE_FFN_OUT, l, p_hid)))
         return e;
-      dY2 = other; other = cur_f;
-    } else if (p_hid > 0.f) {
-      // (the CLS-row LayerNorm backward above indexed its rows 0..B-1, not by packed row: with dropout the mask is applied
-      //  here, and the FFN2 bias gradient -- column sums of the MASKED gradient -- comes from a column-sum pass)
-      hipLaunchKernelGGL(k_cast_drop_f32_bf16, dim3(1024), dim3(256), 0, st, cur_f, d.dYb, rows, H,
-                         drop_site(dseed, DROP_SITE_FFN_OUT, l, p_hid));
-      CONVDR_CHECK_LAUNCH("k_cast_drop_f32_bf16");
-      dY2 = cur_f;
+      other = cur_f;
+      // ---- FFN2: Y2 = Hm W2^T + b2 + X1:  dHpre = (dY2 W2) * gelu'(Hpre) ----
+      g.rows = rows; g.W = (const bf16_t*)lt->w2_t; g.X = d.dYb; g.N = I; g.K = H; g.Cb = d.dHpre;
+      if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
+      {
+        ProfScope prof("dgelu_colsum", st);
+        hipLaunchKernelGGL(k_dgelu_colsum, dim3((I + 255) / 256, chunks), dim3(256), 0, st, d.dHpre, s.Hpre, rows, I, d.part_b1);
+        CONVDR_CHECK_LAUNCH("k_dgelu_colsum");
+      }
+      // ---- FFN1: Hpre = X1 W1^T + b1;  dX1 = dHpre W1 (bf16 tile output) + dY2 (residual branch, fp32) ----
+      g = GemmArgs{};
+      g.rows = rows; g.W = (const bf16_t*)lt->w1_t; g.X = d.dHpre; g.N = H; g.K = I; g.Cb = p.dXb1;
+      if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
+      // ---- LayerNorm1: dY1 = LN'(dY2 + dXb1) ----
+      dY1 = other;
+      if (int e = ln_bwd_kernel(dY2, p.dXb1, s.Y1, rows, H, lw->ln1_g, cfg->ln_eps, dY1, d.dYb2, d.part_ln1, &blocks_ln1, st,
+                                drop_site(dseed, DROP_SITE_ATTN_OUT, l, p_hid)))
+        return e;
+      other = dY2;
+      // ---- attention output projection: Y1 = ctx Wo^T + bo + Xin ----
+      g = GemmArgs{};
+      g.rows = rows; g.W = (const bf16_t*)lt->wo_t; g.X = d.dYb2; g.N = H; g.K = H; g.Cb = p.dctx;
+      if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
     } else {
-      hipLaunchKernelGGL(k_cast_f32_bf16, dim3(1024), dim3(256), 0, st, cur_f, d.dYb, (int64_t)rows * H / 4);
-      CONVDR_CHECK_LAUNCH("k_cast_f32_bf16");
-      dY2 = cur_f;
-    }
-    // ---- FFN2: Y2 = Hm W2^T + b2 + X1:  dHpre = (dY2 W2) * gelu'(Hpre) ----
-    GemmArgs g{};
-    g.rows = rows; g.W = (const bf16_t*)lt->w2_t; g.X = d.dYb; g.N = I; g.K = H; g.Cb = d.dHpre;
-    if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
-    {
-      ProfScope prof("dgelu_colsum", st);
-      hipLaunchKernelGGL(k_dgelu_colsum, dim3((I + 255) / 256, chunks), dim3(256), 0, st, d.dHpre, s.Hpre, rows, I, d.part_b1);
+      // ---- the same chain on the B CLS rows: p.dcls_y [B, H] is d(pre-LN2 sum) of those rows, every other row's is zero ----
+      const DropSite dr_ffn = drop_site(dseed, DROP_SITE_FFN_OUT, l, p_hid), dr_att = drop_site(dseed, DROP_SITE_ATTN_OUT, l, p_hid);
+      if (p_hid > 0.f) {
+        // (the CLS-row LayerNorm backward above indexed its rows 0..B-1, not by packed row: with dropout the mask is applied
+        //  here, and the FFN2 bias gradient -- column sums of the MASKED gradient -- comes from a column-sum pass)
+        hipLaunchKernelGGL(k_cast_drop_f32_bf16, dim3(64), dim3(256), 0, st, p.dcls_y, p.c_dYb, (int64_t)B, H, dr_ffn, cu_seqlens);
+        CONVDR_CHECK_LAUNCH("k_cast_drop_f32_bf16");
+      } else {
+        hipLaunchKernelGGL(k_cast_f32_bf16, dim3(64), dim3(256), 0, st, p.dcls_y, p.c_dYb, (int64_t)B * H / 4);
+        CONVDR_CHECK_LAUNCH("k_cast_f32_bf16");
+      }
+      g.rows = B; g.W = (const bf16_t*)lt->w2_t; g.X = p.c_dYb; g.N = I; g.K = H; g.Cb = p.c_dHpre;
+      if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_cls")) return e;
+      hipLaunchKernelGGL(k_dgelu_colsum, dim3((I + 255) / 256, chunks_c), dim3(256), 0, st, p.c_dHpre, p.c_Hpre, (int64_t)B, I, d.part_b1);
       CONVDR_CHECK_LAUNCH("k_dgelu_colsum");
+      // dX1 = dHpre W1 + dY2: the contraction slices are added straight onto the fp32 residual-branch gradient
+      CONVDR_CHECK_HIP(hipMemcpyAsync(p.c_dX1f, p.dcls_y, (size_t)B * H * 4, hipMemcpyDeviceToDevice, st));
+      int ns = 1;
+      if (int e = cls_projection((const bf16_t*)lt->w1_t, p.c_dHpre, B, H, I, p, st, &ns)) return e;
+      hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)ceil_div64((int64_t)B * H / 4, 256)), dim3(256), 0, st, p.c_slab, ns,
+                         (int64_t)B * H, (int64_t)B * H, p.c_dX1f, 1);
+      CONVDR_CHECK_LAUNCH("k_reduce_partials");
+      if (int e = ln_bwd_kernel(p.c_dX1f, nullptr, p.c_Y1, B, H, lw->ln1_g, cfg->ln_eps, p.c_dY1, p.c_dYb2, d.part_ln1, &blocks_ln1, st,
+                                dr_att, cu_seqlens))
+        return e;
+      g = GemmArgs{};
+      g.rows = B; g.W = (const bf16_t*)lt->wo_t; g.X = p.c_dYb2; g.N = H; g.K = H; g.Cb = p.c_dctx;
+      if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_cls")) return e;
+      // d ctx: zero but for the CLS rows; the attention backward below reads the first query tile only.  The Q third of dQKV
+      // beyond that tile is never written: zero.  The residual-branch gradient handed to the layer below: likewise.
+      CONVDR_CHECK_HIP(hipMemsetAsync(p.dctx, 0, (size_t)rows * H * 2, st));
+      hipLaunchKernelGGL(k_scatter_cls_bf16, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, p.c_dctx, p.dctx);
+      CONVDR_CHECK_HIP(hipMemsetAsync(d.dQKV, 0, (size_t)rows * 3 * H * 2, st));
+      dY1 = cur_f;
+      CONVDR_CHECK_HIP(hipMemsetAsync(dY1, 0, (size_t)rows * H * 4, st));
+      hipLaunchKernelGGL(k_scatter_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, p.c_dY1, dY1);
+      CONVDR_CHECK_LAUNCH("k_scatter_cls");
     }
-    // ---- FFN1: Hpre = X1 W1^T + b1;  dX1 = dHpre W1 (bf16 tile output) + dY2 (residual branch, fp32) ----
-    g = GemmArgs{};
-    g.rows = rows; g.W = (const bf16_t*)lt->w1_t; g.X = d.dHpre; g.N = H; g.K = I; g.Cb = p.dXb1;
-    if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
-    // ---- LayerNorm1: dY1 = LN'(dY2 + dXb1) ----
-    float* dY1 = other;
-    if (int e = ln_bwd_kernel(dY2, p.dXb1, s.Y1, rows, H, lw->ln1_g, cfg->ln_eps, dY1, d.dYb2, d.part_ln1, &blocks_ln1, st,
-                              drop_site(dseed, DROP_SITE_ATTN_OUT, l, p_hid)))
-      return e;
-    other = dY2;
-    // ---- attention output projection: Y1 = ctx Wo^T + bo + Xin ----
-    g = GemmArgs{};
-    g.rows = rows; g.W = (const bf16_t*)lt->wo_t; g.X = d.dYb2; g.N = H; g.K = H; g.Cb = p.dctx;
-    if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
     // ---- attention ----
     {
       // (D[h, t] = dO . O per head is computed by the dQ kernel for its own queries and handed to the dK / dV kernel
       //  through p.Drow: no separate row-dot pass)
       AttnBwdArgs a{s.QKV, p.dctx, rows, s.LSE, cfg->heads, p.Drow, s.ctx, p.Drow, p.ldt, cu_seqlens, seq_lens, H, d.dQKV, 0.125f,
-                    drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att)};
+                    drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att), last ? 64 : 0};
       ProfScope prof("attention_bwd", st);
       const dim3 grid((max_len + 127) / 128, cfg->heads, B);
-      hipLaunchKernelGGL(k_attention_bwd_dq, grid, dim3(256), ATTB_DQ_SMEM, st, a);
+      hipLaunchKernelGGL(k_attention_bwd_dq, last ? dim3(1, cfg->heads, B) : grid, dim3(256), ATTB_DQ_SMEM, st, a);
       hipLaunchKernelGGL(k_attention_bwd_dkv, grid, dim3(256), ATTB_DKV_SMEM, st, a);
       CONVDR_CHECK_LAUNCH("k_attention_bwd");
     }
@@ -578,22 +668,29 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       ReduceList r;
       if (!last) r.add_ln(d.part_ln2, blocks_ln2, H, lg->b2, lg->ln2_g, lg->ln2_b);
       if (last && p_hid > 0.f) {   // see the k_cast_drop_f32_bf16 branch above (part_ln2 is free in the last layer)
-        hipLaunchKernelGGL(k_colsum_bf16, dim3((H + 255) / 256, chunks), dim3(256), 0, ss, d.dYb, rows, H, d.part_ln2);
+        hipLaunchKernelGGL(k_colsum_bf16, dim3((H + 255) / 256, chunks_c), dim3(256), 0, ss, p.c_dYb, (int64_t)B, H, d.part_ln2);
         CONVDR_CHECK_LAUNCH("k_colsum_bf16");
-        r.add(d.part_ln2, chunks, H, H, lg->b2);
+        r.add(d.part_ln2, chunks_c, H, H, lg->b2);
       }
       r.add_ln(d.part_ln1, blocks_ln1, H, lg->bo, lg->ln1_g, lg->ln1_b);
-      r.add(d.part_b1, chunks, I, I, lg->b1);
+      r.add(d.part_b1, last ? chunks_c : chunks, I, I, lg->b1);
       r.add(d.part_bqkv, chunks, 3 * H, 3 * H, lg->bqkv);
       if (int e = r.launch(ss)) return e;
     }
-    {
+    if (!last) {
       const WgradItem items[4] = {{d.dHpre, I, I, s.X1, H, H, lg->w1},          // Hpre = X1 W1^T
                                   {d.dYb, H, H, s.Hm, I, I, lg->w2},            // Y2 = Hm W2^T
                                   {d.dQKV, 3 * H, 3 * H, s.Xin, H, H, lg->wqkv},   // QKV = Xin Wqkv^T
                                   {d.dYb2, H, H, s.ctx, H, H, lg->wo}};         // Y1 = ctx Wo^T
       static const int tail_split = getenv("CONVDR_WGRAD_TAIL_SPLIT") ? atoi(getenv("CONVDR_WGRAD_TAIL_SPLIT")) : 2;
       if (int e = wgrad_batch(items, 4, rows, p.slab, p.slab_elems, ss, l == 0 && fork_wgrad ? tail_split : 0)) return e;
+    } else {
+      // three of the four products contract over the B CLS rows only (one 64-token K step); the QKV projection saw every row
+      const WgradItem items_c[3] = {{p.c_dHpre, I, I, p.c_X1, H, H, lg->w1}, {p.c_dYb, H, H, p.c_Hm, I, I, lg->w2},
+                                    {p.c_dYb2, H, H, p.c_ctx, H, H, lg->wo}};
+      if (int e = wgrad_batch(items_c, 3, B, p.slab, p.slab_elems, ss)) return e;
+      const WgradItem item_qkv{d.dQKV, 3 * H, 3 * H, s.Xin, H, H, lg->wqkv};
+      if (int e = wgrad_batch(&item_qkv, 1, rows, p.slab, p.slab_elems, ss)) return e;
     }
     // ---- QKV projection: QKV = Xin Wqkv^T + bqkv;  dXin = dQKV Wqkv (bf16 tile output) + dY1 (residual branch, fp32) ----
     g = GemmArgs{};
@@ -691,7 +788,18 @@ extern "C" int convdr_grad_norm_clip(float* grads, int64_t n, float max_norm, fl
 extern "C" int convdr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                                  double beta2, double eps, double weight_decay, int step, int correct_bias,
                                  const float* grad_scale, convdr_stream_t stream) {
+  return convdr_adamw_step_packed(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, correct_bias, grad_scale, nullptr, 0,
+                                  stream);
+}
+
+extern "C" int convdr_adamw_step_packed(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                                        double beta2, double eps, double weight_decay, int step, int correct_bias,
+                                        const float* grad_scale, void* bf16_copy, int64_t bf16_first,
+                                        convdr_stream_t stream) {
   CONVDR_REQUIRE(n >= 0 && step >= 1, "convdr_adamw_step: bad n/step");
+  CONVDR_REQUIRE(bf16_copy == nullptr || (bf16_first >= 0 && bf16_first % 4 == 0 && ((uintptr_t)bf16_copy & 7) == 0),
+                 "convdr_adamw_step_packed: the bf16 copy must start at a multiple of 4 elements (%lld) and be 8-byte aligned",
+                 (long long)bf16_first);
   if (n == 0) return 0;
   double step_size = lr;
   if (correct_bias) step_size = lr * sqrt(1.0 - pow(beta2, (double)step)) / (1.0 - pow(beta1, (double)step));
@@ -701,7 +809,7 @@ extern "C" int convdr_adamw_step(float* p, const float* g, float* m, float* v, i
   const int maxb = device_cu_count();
   const int blocks = (int)(ceil_div64(n, 1024) < maxb ? ceil_div64(n, 1024) : maxb);
   hipLaunchKernelGGL(k_adamw_hf, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)lr, (float)beta1,
-                     (float)beta2, (float)eps, (float)weight_decay, (float)step_size, grad_scale);
+                     (float)beta2, (float)eps, (float)weight_decay, (float)step_size, grad_scale, (bf16_t*)bf16_copy, bf16_first);
   CONVDR_CHECK_LAUNCH("k_adamw_hf");
   return 0;
 }

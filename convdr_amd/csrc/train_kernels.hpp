@@ -78,7 +78,10 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
                                                        const float* __restrict__ Yin,
                                                        int64_t rows, int H, const float* __restrict__ g, float eps,
                                                        float* __restrict__ dXf, bf16_t* __restrict__ dXb,
-                                                       float* __restrict__ part, const DropSite drop) {
+                                                       float* __restrict__ part, const DropSite drop,
+                                                       const int32_t* __restrict__ row_map) {
+  // row_map (optional): the rows are a compact selection (the CLS rows of the last layer); the dropout mask of row r is
+  // that of packed row row_map[r]
   __shared__ float red[4][3][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 ag[4], ab[4], ax[4];
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
         if (dXf) *(float4*)(dXf + row * H + e0) = o;   // residual branch: not dropped
         if (drop.thresh) {   // the dense output feeding this LayerNorm went through dropout: its gradient (and its bias') is masked
           float k0, k1, k2, k3;
-          drop_hidden4(drop, row, e0, H, k0, k1, k2, k3);
+          drop_hidden4(drop, row_map ? (int64_t)row_map[row] : row, e0, H, k0, k1, k2, k3);
           o.x *= k0; o.y *= k1; o.z *= k2; o.w *= k3;
         }
         ax[j].x += o.x; ax[j].y += o.y; ax[j].z += o.z; ax[j].w += o.w;
@@ -361,14 +364,14 @@ static __global__ void __launch_bounds__(256) k_masked_mean_bwd(const float* __r
 // y = bf16(x * dropout mask) for a [rows, H] matrix: the last layer's FFN-output gradient (only its CLS rows are non-zero)
 // on its way to the FFN2 dgrad / wgrad operands when hidden dropout is on
 static __global__ void __launch_bounds__(256) k_cast_drop_f32_bf16(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t rows,
-                                                                   int H, const DropSite drop) {
+                                                                   int H, const DropSite drop, const int32_t* __restrict__ row_map) {
   const int64_t n4 = rows * H / 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = (4 * i) / H;
     const int col = (int)(4 * i - row * H);
     float4 v = *(const float4*)(x + 4 * i);
     float m0, m1, m2, m3;
-    drop_hidden4(drop, row, col, H, m0, m1, m2, m3);
+    drop_hidden4(drop, row_map ? (int64_t)row_map[row] : row, col, H, m0, m1, m2, m3);
     uint2 o;
     o.x = pack_bf16x2(v.x * m0, v.y * m1);
     o.y = pack_bf16x2(v.z * m2, v.w * m3);
@@ -384,6 +387,45 @@ __global__ void __launch_bounds__(256) k_scatter_cls(const int32_t* __restrict__
   if (b >= B) return;
   const int64_t row = cu[b];
   for (int e0 = 4 * lane; e0 < H; e0 += 256) *(float4*)(dst + row * H + e0) = *(const float4*)(src + (int64_t)b * H + e0);
+}
+
+// bf16 form: dst[cu[b], :] = src[b, :] (dst pre-zeroed)
+__global__ void __launch_bounds__(256) k_scatter_cls_bf16(const int32_t* __restrict__ cu, int B, int H,
+                                                          const bf16_t* __restrict__ src, bf16_t* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int64_t row = cu[b];
+  for (int e0 = 8 * lane; e0 < H; e0 += 512) *(uint4*)(dst + row * H + e0) = *(const uint4*)(src + (int64_t)b * H + e0);
+}
+
+// Finish of a split-K projection on a few compact rows (the CLS rows of the last layer, training forward):
+//   Y[r, f] = dropout(sum_s slab[s][r][f] + bias[f]; packed row row_map[r]) + resid[r, f]
+// i.e. exactly what the EPI_RESID_F32 epilogue computes for a whole-contraction tile.  One thread per 4 features.
+__global__ void __launch_bounds__(256) k_slab_finish(const float* __restrict__ slab, int nsplit, int rows, int N,
+                                                     const float* __restrict__ bias, const bf16_t* __restrict__ resid,
+                                                     const int32_t* __restrict__ row_map, const DropSite drop,
+                                                     float* __restrict__ Y) {
+  const int64_t n4 = (int64_t)rows * N / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)((4 * i) / N), f = (int)(4 * i - (int64_t)r * N);
+    float4 y = bias ? *(const float4*)(bias + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nsplit; ++s) {
+      const float4 v = *(const float4*)(slab + ((int64_t)s * rows + r) * N + f);
+      y.x += v.x; y.y += v.y; y.z += v.z; y.w += v.w;
+    }
+    if (drop.thresh) {
+      float m0, m1, m2, m3;
+      drop_hidden4(drop, row_map ? (int64_t)row_map[r] : (int64_t)r, f, N, m0, m1, m2, m3);
+      y.x *= m0; y.y *= m1; y.z *= m2; y.w *= m3;
+    }
+    if (resid) {
+      const uint2 q = *(const uint2*)(resid + (int64_t)r * N + f);
+      y.x += __uint_as_float(q.x << 16); y.y += __uint_as_float(q.x & 0xffff0000u);
+      y.z += __uint_as_float(q.y << 16); y.w += __uint_as_float(q.y & 0xffff0000u);
+    }
+    *(float4*)(Y + (int64_t)r * N + f) = y;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -676,10 +718,14 @@ __global__ void k_norm_finish(const float* __restrict__ part, int nparts, float 
 // HF transformers==2.3.0 AdamW (not torch.optim.AdamW):
 //   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps);  p -= lr wd p
 // g is multiplied by *gscale (the clip coefficient, device scalar) first.
+// pb (optional): the packed bf16 copy of the weights that the GEMMs read, pb[i - pb_first] = bf16(p[i]) for i >= pb_first
+// (pb_first % 4 == 0): written here, from the registers that hold the new weight, instead of by a cast pass over the arena at
+// the top of the next step (0.5 GB read + 0.17 GB written, 93 us of the configs[2] step's serial tail).
 __global__ void __launch_bounds__(256) k_adamw_hf(float* __restrict__ p, const float* __restrict__ g,
                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                   float b1, float b2, float eps, float wd, float step_size,
-                                                  const float* __restrict__ gscale) {
+                                                  const float* __restrict__ gscale, bf16_t* __restrict__ pb,
+                                                  int64_t pb_first) {
   const float gs = gscale ? gscale[0] : 1.f;
   auto upd = [&](float& pi, const float g0, float& mi, float& vi) {
     const float gi = g0 * gs;
@@ -696,11 +742,18 @@ __global__ void __launch_bounds__(256) k_adamw_hf(float* __restrict__ p, const f
     const float4 gg = ((const float4*)g)[i];
     upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
     ((float4*)m)[i] = mm; ((float4*)v)[i] = vv; ((float4*)p)[i] = pp;
+    if (pb && 4 * i >= pb_first) {
+      uint2 o;
+      o.x = pack_bf16x2(pp.x, pp.y);
+      o.y = pack_bf16x2(pp.z, pp.w);
+      *(uint2*)(pb + (4 * i - pb_first)) = o;
+    }
   }
   for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float pi = p[i], mi = m[i], vi = v[i];
     upd(pi, g[i], mi, vi);
     m[i] = mi; v[i] = vi; p[i] = pi;
+    if (pb && i >= pb_first) pb[i - pb_first] = f32_to_bf16(pi);
   }
 }
 

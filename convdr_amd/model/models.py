@@ -192,6 +192,23 @@ class EncoderTower(nn.Module):
         self._packed_key = None
         self.__dict__.pop("_packed_t", None)
 
+    def fused_update_target(self, P):
+        """(bf16 copy, first arena element it covers) when the packed weights of this tower are views of the flat arena
+        `P` -- then an optimizer that updates all of P may refresh the copy itself (convdr_adamw_step_packed) and call
+        adopt_fused_update() instead of leaving a cast pass to the next forward -- else None."""
+        flat = self.__dict__.get("_flat")
+        if flat is None or self._packed is None or "_packed_extra" not in self.__dict__ or flat.get("Pb") is None:
+            return None
+        if flat["P"].data_ptr() != P.data_ptr() or flat["P"].numel() != P.numel():
+            return None
+        return flat["Pb"], flat["w0"]
+
+    def adopt_fused_update(self):
+        """The optimizer has rewritten the whole bf16 copy next to the fp32 weights: the packed structs (pointers into the
+        two arenas) are valid for the parameters' new versions; the transposed copies for the backward are not."""
+        self._packed_key = self._version_key(self.__dict__["_packed_extra"])
+        self.__dict__.pop("_packed_t", None)
+
     def check_positions(self, max_len):
         """The reference's position-embedding lookup raises IndexError when a sequence needs a position past the table
         (RoBERTa: position = pad_idx + running count of non-pad tokens; BERT: the column index)."""
@@ -221,7 +238,9 @@ class EncoderTower(nn.Module):
         flat = getattr(self, "_flat", None)
         if flat is not None and flat["head"] is (None if head is None else head[0]):
             self._packed, self._packed_key = self._packed_from_flat(flat, head), key
+            self.__dict__["_packed_extra"] = extra
             return self._packed
+        self.__dict__.pop("_packed_extra", None)
         keep = []
 
         def f32(t):

@@ -68,7 +68,19 @@ def flatten_parameters(model):
             off[id(p)] = int(o)
     tower._flat = {"P": P, "off": off, "w0": int(offs[5]), "head": head[0], "params": params}
     tower._packed = None
+    _ARENA_OWNERS[P.data_ptr()] = weakref.ref(tower)
     return tower._flat
+
+
+_ARENA_OWNERS = {}      # flat parameter arena (data_ptr) -> weak reference to the tower whose parameters are its views
+
+
+def _arena_owner(P):
+    ref = _ARENA_OWNERS.get(P.data_ptr())
+    tower = ref() if ref is not None else None
+    if ref is not None and tower is None:
+        del _ARENA_OWNERS[P.data_ptr()]
+    return tower
 
 
 def _packed_t(tower, head):
@@ -666,14 +678,22 @@ class AdamW(torch.optim.Optimizer):
         g0 = self.param_groups[0]
         step = steps.pop() + 1
         b1, b2 = g0["betas"]
+        # When P is a tower's whole arena, the update kernel also rewrites the packed bf16 weights the GEMMs read (every
+        # element of the copy: all of P is updated), so the next forward finds them current instead of re-casting 0.5 GB
+        tower = _arena_owner(P)
+        target = tower.fused_update_target(P) if tower is not None else None
+        Pb, w0 = target if target is not None else (None, 0)
         with torch.cuda.device(P.device):
-            _lib.check(_lib.lib().convdr_adamw_step(_lib.ptr(P), _lib.ptr(G), _lib.ptr(st["m"]), _lib.ptr(st["v"]), P.numel(),
-                                                    g0["lr"], b1, b2, g0["eps"], g0["weight_decay"], step,
-                                                    int(g0["correct_bias"]), _lib.ptr(scale), _lib.stream_ptr()),
-                       "convdr_adamw_step")
+            _lib.check(_lib.lib().convdr_adamw_step_packed(_lib.ptr(P), _lib.ptr(G), _lib.ptr(st["m"]), _lib.ptr(st["v"]),
+                                                           P.numel(), g0["lr"], b1, b2, g0["eps"], g0["weight_decay"], step,
+                                                           int(g0["correct_bias"]), _lib.ptr(scale), _lib.ptr(Pb), w0,
+                                                           _lib.stream_ptr()),
+                       "convdr_adamw_step_packed")
         for p in ps:
             self.state[p]["step"] = step
             _bump_version(p)
+        if target is not None:
+            tower.adopt_fused_update()
         return True
 
     def load_state_dict(self, state_dict):

@@ -311,6 +311,13 @@ int convdr_scale_f32(float* x, int64_t n, const float* scale, convdr_stream_t st
 int convdr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                       double eps, double weight_decay, int step, int correct_bias, const float* grad_scale,
                       convdr_stream_t stream);
+/* The same update, also refreshing the packed bf16 copy of the weights that the encoder GEMMs read (what
+ * convdr_cast_f32_bf16 over p[bf16_first, n) would produce afterwards): bf16_copy[i - bf16_first] = bf16(p[i]) for
+ * i >= bf16_first, written from the registers that hold the new weight -- the training step then has no cast pass over
+ * the parameter arena.  bf16_copy == NULL: exactly convdr_adamw_step.  bf16_first % 4 == 0. */
+int convdr_adamw_step_packed(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                             double eps, double weight_decay, int step, int correct_bias, const float* grad_scale,
+                             void* bf16_copy, int64_t bf16_first, convdr_stream_t stream);
 
 /* Tuning / test knobs: "fused_ln_min_rows" = minimum packed rows for the fused GEMM + residual + LayerNorm kernel
  * (default 24576; tests lower it to exercise that kernel on small inputs); "fused_ln_max_k" = largest contraction

@@ -273,7 +273,7 @@ def test_blocked_ffn_activation_layout_is_result_neutral():
                 out[blk] = model.body_emb(torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda())
     finally:
         L.convdr_set_option(b"fused_ln_min_rows", 128 * 192)
-        L.convdr_set_option(b"hm_blocked", -1)
+        L.convdr_set_option(b"hm_blocked", 1)
     assert torch.equal(out[1], out[0])
     _check(out[1], ref, "blocked ffn layout")
 

@@ -333,6 +333,55 @@ def test_flat_arena_training_matches_per_parameter_path():
             assert d.mean().item() < 1e-5 + 1e-4 * v.abs().mean().item(), (k, d.mean().item())
 
 
+def test_adamw_refreshes_the_packed_bf16_weights_itself():
+    """Flat-arena training: the AdamW launch also rewrites the packed bf16 copy of the weights (convdr_adamw_step_packed), so
+    the next forward neither re-casts the arena nor reads stale weights: after a step the copy is bit-identical to a cast
+    of the fp32 arena, the packed structs are current for the new parameter versions, the transposed copies are rebuilt,
+    and the fused step == the plain step + cast (bit for bit)."""
+    from types import SimpleNamespace
+    from convdr_amd import _lib, train as TR
+    rs = np.random.RandomState(6)
+    ids, mask = _batch(rs, 6, 48, [48, 20, 33, 5, 40, 12])
+    tid, tmask = _batch(rs, 6, 16, [16, 9, 4, 16, 7, 3])
+    batch = tuple(x.cuda() for x in (ids, mask, tid, tmask))
+    args = SimpleNamespace(learning_rate=1e-3, adam_epsilon=1e-8, max_grad_norm=1.0, ranking_task=False, no_mse=False,
+                           num_negatives=0, gradient_accumulation_steps=1)
+    student, teacher = _tiny(seed=3).cuda(), _tiny(seed=4).cuda().eval()
+    flat = TR.flatten_parameters(student)
+    opt = TR.get_optimizer(args, student, weight_decay=0.0)       # one hyper-parameter set: the one-launch path
+    sched = TR.get_linear_schedule_with_warmup(opt, 0, 10)
+    tower = student.roberta
+    for step in range(3):
+        TR.train_step(args, student, teacher, opt, sched, batch)
+        P, Pb, w0 = flat["P"], flat["Pb"], flat["w0"]
+        ref = torch.empty_like(Pb)
+        _lib.check(_lib.lib().convdr_cast_f32_bf16(_lib.ptr(P[w0:]), _lib.ptr(ref), P.numel() - w0, _lib.stream_ptr()), "cast")
+        assert torch.equal(Pb.view(torch.int16), ref.view(torch.int16)), "step %d: stale bf16 weights" % step
+        head = (student.embeddingHead, student.norm)
+        extra = [head[0].weight, head[0].bias, head[1].weight, head[1].bias]
+        assert tower._packed is not None and tower._packed_key == tower._version_key(extra)     # no re-cast pending
+        assert "_packed_t" not in tower.__dict__                                                   # transposes are rebuilt
+    # the plain entry point + a cast gives the same bits as the fused one
+    n = 4096 + 8
+    g = torch.Generator(device="cuda").manual_seed(1)
+    p0, gr = torch.randn(n, device="cuda", generator=g), torch.randn(n, device="cuda", generator=g)
+    outs = []
+    for fused in (False, True):
+        p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        pb = torch.zeros(n - 8, dtype=torch.bfloat16, device="cuda")
+        L = _lib.lib()
+        if fused:
+            _lib.check(L.convdr_adamw_step_packed(_lib.ptr(p), _lib.ptr(gr), _lib.ptr(m), _lib.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0.01,
+                                                  1, 1, None, _lib.ptr(pb), 8, _lib.stream_ptr()), "adamw_packed")
+        else:
+            _lib.check(L.convdr_adamw_step(_lib.ptr(p), _lib.ptr(gr), _lib.ptr(m), _lib.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, 1,
+                                           None, _lib.stream_ptr()), "adamw")
+            _lib.check(L.convdr_cast_f32_bf16(_lib.ptr(p[8:]), _lib.ptr(pb), n - 8, _lib.stream_ptr()), "cast")
+        outs.append((p, m, v, pb))
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32), b.view(torch.int16 if b.dtype == torch.bfloat16 else torch.int32))
+
+
 def test_dpr_tower_backward_matches_autograd():
     """BiEncoder (two BERT towers, raw CLS, no head): gradients of the question tower."""
     from convdr_amd.model.models import MSMarcoConfigDict, BertConfig
@@ -477,10 +526,22 @@ def test_layer_completion_events_and_overlapped_allreduce():
     assert (out - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
 
 
-def test_backward_at_256_tile_scale_matches_autograd():
+@pytest.mark.parametrize("tile_policy", [0, 1, 2, 3])
+def test_backward_at_256_tile_scale_matches_autograd(tile_policy):
     """roberta-base-wide layer (768 / 12 heads / 3072) over ~17 k packed rows: enough for the training step's GEMMs to run as
     256 x 256 tiles on the R3 K step (forward with saved pre-activations, x gelu', data-gradient and split-K
-    weight-gradient epilogues), which the small fixtures never reach.  Gradients vs torch autograd on the fp32 oracle."""
+    weight-gradient epilogues), which the small fixtures never reach.  Gradients vs torch autograd on the fp32 oracle.
+    tile_policy: 0 = the launcher's cost model, 1 / 2 / 3 = every GEMM of the step forced onto 256 x 256 / 256 x 128
+    (TileWide: the parked tile uses the spare LDS behind the operand slots) / 128 x 128 tiles where the shape allows."""
+    from convdr_amd import _lib
+    _lib.check(_lib.lib().convdr_set_option(b"gemm_tile_policy", tile_policy), "set_option")
+    try:
+        _backward_at_256_tile_scale("bwd_256tile_policy%d" % tile_policy)
+    finally:
+        _lib.lib().convdr_set_option(b"gemm_tile_policy", 0)
+
+
+def _backward_at_256_tile_scale(tag):
     from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
     torch.manual_seed(12)
     cfg = RobertaConfig(vocab_size=300, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072,
@@ -508,10 +569,10 @@ def test_backward_at_256_tile_scale_matches_autograd():
     checked = 0
     for n, p in model.named_parameters():
         if n in ref and not n.endswith("attention.self.key.bias"):
-            _compare(n, p.grad, ref[n], cos_tol=1 - 3e-4, norm_tol=2e-3, tag="bwd_256tile")
+            _compare(n, p.grad, ref[n], cos_tol=1 - 3e-4, norm_tol=2e-3, tag=tag)
             checked += 1
     assert checked >= 20
-    _record_worst("bwd_256tile", 3e-4, 2e-3)              # measured 6.7e-5 / 4.6e-4
+    _record_worst(tag, 3e-4, 2e-3)              # measured 6.7e-5 / 4.6e-4
 
 
 @pytest.mark.parametrize("rows,N,K,pad", [(1000, 128, 256, 0), (77, 72, 40, 8), (4100, 768, 384, 0), (64, 8, 8, 0), (1, 136, 264, 16),
@@ -997,18 +1058,19 @@ def test_attention_dropout_backward_on_odd_lengths():
     """The dK / dV kernel shares one mask hash between the two lanes of a key pair (DPP swap).  For an odd-length sequence
     the last key's partner lane lies past the sequence; its role in the swap must come from the lane parity, not from the
     clamped key (round-3 advisor finding: dK / dV of the last token of every odd-length sequence used another mask than
-    the forward).  Short odd sequences make that token a large share of the key / value weight gradients."""
+    the forward).  Short odd sequences make that token a large share of the key / value weight gradients; two layers, because
+    in the last layer only the CLS query (an even register) carries gradient."""
     from convdr_amd import train as TR
     rs = np.random.RandomState(47)
     B, L, lens = 8, 16, [1, 3, 5, 7, 9, 11, 13, 15]
     p_h, p_a = 0.0, 0.4
-    model = _tiny_dropout(p_h, p_a, layers=1)
+    model = _tiny_dropout(p_h, p_a, layers=2)
     model.dropout_seed = 99
     ids, mask = _batch(rs, B, L, lens)
     G = torch.from_numpy(rs.randn(B, 768).astype(np.float32))
     seed = TR.dropout_seed_of(model, 0)
     sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
-    ref_emb = OE.rdot_nll_emb(sd, ids, mask, num_layers=1, num_heads=2, dropout=(p_h, p_a, seed))
+    ref_emb = OE.rdot_nll_emb(sd, ids, mask, num_layers=2, num_heads=2, dropout=(p_h, p_a, seed))
     (ref_emb * G).sum().backward()
     model = model.cuda().train()
     emb = model(ids.cuda(), mask.cuda())
