@@ -785,6 +785,21 @@ extern "C" int convdr_grad_norm_clip(float* grads, int64_t n, float max_norm, fl
   return 0;
 }
 
+extern "C" int convdr_grad_sumsq(const float* x, int64_t n, float* partials, int nblocks, convdr_stream_t stream) {
+  CONVDR_REQUIRE(n >= 0 && nblocks >= 1 && nblocks <= 1024, "convdr_grad_sumsq: bad n / nblocks (%lld, %d)", (long long)n, nblocks);
+  hipLaunchKernelGGL(k_sumsq_partial, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, x, n, partials);
+  CONVDR_CHECK_LAUNCH("k_sumsq_partial");
+  return 0;
+}
+
+extern "C" int convdr_grad_norm_finish(const float* partials, int count, float max_norm, float pre_scale, float* norm_and_coef,
+                                       convdr_stream_t stream) {
+  CONVDR_REQUIRE(count >= 1, "convdr_grad_norm_finish: no partial sums");
+  hipLaunchKernelGGL(k_norm_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, count, max_norm, pre_scale, norm_and_coef);
+  CONVDR_CHECK_LAUNCH("k_norm_finish");
+  return 0;
+}
+
 extern "C" int convdr_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                                  double beta2, double eps, double weight_decay, int step, int correct_bias,
                                  const float* grad_scale, convdr_stream_t stream) {

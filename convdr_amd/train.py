@@ -534,14 +534,62 @@ def _flat_view(tensors):
     return torch.as_strided(base, (n,), (1,), base.storage_offset())
 
 
-def clip_grad_norm_(parameters, max_norm, defer_to=None, extra_scale=1.0):
+def _overlapped_sumsq(flat, tower, scratch, dev):
+    """Sum of squares of a FRESH gradient arena, piece by piece: every encoder layer's slice on a side stream as soon as
+    the backward's completion events say it is final (convdr_backward_wait_layer) -- under the backward of the layers
+    below --, embeddings and head on the current stream after the backward.  Returns the number of partial sums written
+    to `scratch`, or 0 when the arena is not the one the tower's last backward wrote."""
+    info = getattr(tower, "_flat", None)
+    if info is None or getattr(tower, "_last_backward_arena", None) != flat.data_ptr():
+        return 0
+    offs = info.get("offs")
+    if offs is None:
+        offs = info["offs"] = np.concatenate([[0], np.cumsum([p.numel() for p in info["params"]])]).astype(np.int64)
+    nl = len(tower.encoder.layer)
+    if int(offs[-1]) != flat.numel() or len(offs) < 6 + 16 * nl:
+        return 0
+    L = _lib.lib()
+    per, nb_emb, nb_head = 64, 256, 16
+    if scratch.numel() < nl * per + nb_emb + nb_head:
+        return 0
+    main = torch.cuda.current_stream(dev)
+    side = _norm_stream(dev)
+    base, sbase = flat.data_ptr(), scratch.data_ptr()
+    with torch.cuda.stream(side):
+        for l in reversed(range(nl)):
+            b, e = int(offs[5 + 16 * l]), int(offs[5 + 16 * (l + 1)])
+            _lib.check(L.convdr_backward_wait_layer(l, side.cuda_stream), "convdr_backward_wait_layer")
+            _lib.check(L.convdr_grad_sumsq(C.c_void_p(base + 4 * b), e - b, C.c_void_p(sbase + 4 * l * per), per, side.cuda_stream),
+                       "convdr_grad_sumsq")
+    b0, e1 = int(offs[5]), int(offs[5 + 16 * nl])
+    _lib.check(L.convdr_grad_sumsq(C.c_void_p(base), b0, C.c_void_p(sbase + 4 * nl * per), nb_emb, main.cuda_stream), "convdr_grad_sumsq")
+    _lib.check(L.convdr_grad_sumsq(C.c_void_p(base + 4 * e1), flat.numel() - e1, C.c_void_p(sbase + 4 * (nl * per + nb_emb)), nb_head,
+                                   main.cuda_stream), "convdr_grad_sumsq")
+    main.wait_stream(side)
+    return nl * per + nb_emb + nb_head
+
+
+_NORM_STREAMS = {}
+
+
+def _norm_stream(device):
+    key = (device.type, device.index)
+    if key not in _NORM_STREAMS:
+        _NORM_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _NORM_STREAMS[key]
+
+
+def clip_grad_norm_(parameters, max_norm, defer_to=None, extra_scale=1.0, overlap_backward=False):
     """torch.nn.utils.clip_grad_norm_ (run_convdr_train.py:188-189) in one or a few kernels.  Returns the total
     norm as a device scalar (no host sync).
     defer_to: an ``AdamW`` of this module.  When the gradients form one flat arena the clip coefficient is then only
     computed and handed to the optimizer, whose update kernel multiplies it into the gradient on the fly -- one pass over
     the 125 M gradients less; the stored gradients stay unscaled (train_step zeroes them right after the update).
     extra_scale: the gradients are (sum over ranks) and still have to be multiplied by this factor (1 / world size):
-    the norm and the clip coefficient are those of the scaled gradients, the scaling itself rides on the same pass."""
+    the norm and the clip coefficient are those of the scaled gradients, the scaling itself rides on the same pass.
+    overlap_backward: the gradients come straight from a backward that may still be running on the device and nothing has
+    touched them since (no all-reduce): the per-layer slices of the arena are then summed on a side stream behind that
+    backward's per-layer completion events, and only embeddings + head (a third of the arena) after it."""
     parameters = list(parameters)
     grads = [p.grad for p in parameters if p.grad is not None]
     if not grads:
@@ -554,9 +602,20 @@ def clip_grad_norm_(parameters, max_norm, defer_to=None, extra_scale=1.0):
         flat = _flat_view(grads)
         if flat is not None:
             defer = defer_to is not None and defer_to.can_flat_step(flat)
-            _lib.check(L.convdr_grad_norm_clip(_lib.ptr(flat), flat.numel(), float(max_norm), float(extra_scale),
-                                               _lib.ptr(scratch), _lib.ptr(out), 0 if defer else 1, _lib.stream_ptr()),
-                       "convdr_grad_norm_clip")
+            count = 0
+            if defer and overlap_backward:
+                ops = defer_to.__dict__.get("_flat_ops_cache")
+                tower = _arena_owner(ops[1]) if ops is not None else None
+                if tower is not None:
+                    scratch = torch.empty(4096, dtype=torch.float32, device=dev)
+                    count = _overlapped_sumsq(flat, tower, scratch, dev)
+            if count:
+                _lib.check(L.convdr_grad_norm_finish(_lib.ptr(scratch), count, float(max_norm), float(extra_scale), _lib.ptr(out),
+                                                     _lib.stream_ptr()), "convdr_grad_norm_finish")
+            else:
+                _lib.check(L.convdr_grad_norm_clip(_lib.ptr(flat), flat.numel(), float(max_norm), float(extra_scale),
+                                                   _lib.ptr(scratch), _lib.ptr(out), 0 if defer else 1, _lib.stream_ptr()),
+                           "convdr_grad_norm_clip")
             if defer:
                 defer_to._pending_grad_scale = out[1:2]
             return out[0]
@@ -825,7 +884,7 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
             # the 1 / world factor rides on the clip / AdamW pass instead of costing its own pass over 0.5 GB
             scale = ddp.allreduce_grads(force_overlap=force_overlap, average=False)
         clip_grad_norm_(list(model.parameters()), args.max_grad_norm, defer_to=optimizer if isinstance(optimizer, AdamW) else None,
-                        extra_scale=scale)
+                        extra_scale=scale, overlap_backward=ddp is None and gas == 1)
         optimizer.step()
         scheduler.step()
         model.zero_grad()

@@ -302,6 +302,16 @@ int convdr_inbatch_ce_fwd_bwd(const float* embs, const float* docs, int B, int N
 int convdr_grad_norm_clip(float* grads, int64_t n, float max_norm, float pre_scale, float* scratch, float* norm_and_coef,
                           int apply, convdr_stream_t stream);
 
+/* The two halves of convdr_grad_norm_clip, for callers that sum a gradient arena piece by piece -- e.g. every encoder
+ * layer's slice on a side stream as soon as convdr_backward_wait_layer says it is complete, under the backward of the
+ * layers below, so that only the last pieces are summed after the backward:
+ *   convdr_grad_sumsq:       partials[b] = sum of squares of block b's share of x[0, n), b < nblocks (<= 1024)
+ *   convdr_grad_norm_finish: norm_and_coef as convdr_grad_norm_clip, from `count` partial sums (any order of pieces: the
+ *                            finish folds them in index order in fp64 -- deterministic for a fixed layout) */
+int convdr_grad_sumsq(const float* x, int64_t n, float* partials, int nblocks, convdr_stream_t stream);
+int convdr_grad_norm_finish(const float* partials, int count, float max_norm, float pre_scale, float* norm_and_coef,
+                            convdr_stream_t stream);
+
 /* x[i] *= scale[0] (device scalar), e.g. the clip coefficient */
 int convdr_scale_f32(float* x, int64_t n, const float* scale, convdr_stream_t stream);
 

@@ -382,6 +382,37 @@ def test_adamw_refreshes_the_packed_bf16_weights_itself():
         assert torch.equal(a.view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32), b.view(torch.int16 if b.dtype == torch.bfloat16 else torch.int32))
 
 
+def test_gradient_norm_summed_under_the_backward_equals_the_single_pass():
+    """clip_grad_norm_(overlap_backward=True): per-layer slices of the fresh gradient arena are summed on a side stream behind
+    the backward's per-layer completion events, embeddings + head after it; the norm and the clip coefficient must be those
+    of the one-pass form (fp64 fold of fp32 partial sums either way: equal to rounding), and an arena that is NOT the last
+    backward's (accumulated gradients) must take the one-pass route."""
+    from types import SimpleNamespace
+    from convdr_amd import train as TR
+    rs = np.random.RandomState(8)
+    ids, mask = _batch(rs, 6, 48, [48, 20, 33, 5, 40, 12])
+    student = _tiny(seed=3).cuda().train()
+    TR.flatten_parameters(student)
+    args = SimpleNamespace(learning_rate=1e-3, adam_epsilon=1e-8)
+    opt = TR.get_optimizer(args, student, weight_decay=0.0)
+    G = torch.from_numpy(rs.randn(6, 768).astype(np.float32)).cuda()
+    (student(ids.cuda(), mask.cuda()) * G).sum().backward()
+    params = list(student.parameters())
+    n1 = TR.clip_grad_norm_(params, 1.0, defer_to=opt, overlap_backward=True).item()
+    c1 = opt._pending_grad_scale.item()
+    n0 = TR.clip_grad_norm_(params, 1.0, defer_to=opt, overlap_backward=False).item()
+    c0 = opt._pending_grad_scale.item()
+    ref = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params if p.grad is not None)).item()
+    assert abs(n1 - ref) <= 2e-6 * ref and abs(n0 - ref) <= 2e-6 * ref, (n1, n0, ref)
+    assert abs(c1 - c0) <= 2e-6 * c0
+    scratch = torch.empty(4096, device="cuda")
+    flat = TR._flat_view([p.grad for p in params if p.grad is not None])
+    assert TR._overlapped_sumsq(flat, student.roberta, scratch, flat.device) > 0
+    (student(ids.cuda(), mask.cuda()) * G).sum().backward()             # accumulates into the first arena
+    flat2 = TR._flat_view([p.grad for p in params if p.grad is not None])
+    assert TR._overlapped_sumsq(flat2, student.roberta, scratch, flat2.device) == 0
+
+
 def test_dpr_tower_backward_matches_autograd():
     """BiEncoder (two BERT towers, raw CLS, no head): gradients of the question tower."""
     from convdr_amd.model.models import MSMarcoConfigDict, BertConfig
