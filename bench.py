@@ -45,6 +45,20 @@ def _init_group(dev):
         dist.init_process_group(backend)
 
 
+def _power_state():
+    """What rocm-smi shows an ordinary user about the power state of device 0 (None when unreadable)."""
+    import subprocess
+    out = {}
+    for flag, key in (("--showmaxpower", "max_power"), ("--showpower", "power"), ("--showclocks", "clocks")):
+        try:
+            r = subprocess.run(["rocm-smi", "-d", "0", flag, "--json"], capture_output=True, text=True, timeout=20)
+            j = json.loads(r.stdout)
+            out[key] = j.get("card0", j)
+        except Exception:
+            out[key] = None
+    return out
+
+
 def flop_per_passage(L):
     return LINEAR_FLOP_PER_TOKEN * L + 36864 * L * L + 2 * H * D_OUT
 
@@ -449,6 +463,89 @@ def extras_encode_loop(dev, model, n_pass=200_000, L=128):
         shutil.rmtree(td, ignore_errors=True)
 
 
+def extras_registry(dev):
+    """The rest of model.models.MSMarcoConfigDict (models.py:291-311) and the query-encode loop at the reference's own
+    batch size: `dpr` (BiEncoder: two BERT-base towers, raw CLS, no head) and `rdot_nll_multi_chunk` (MaxP documents: one
+    embedding per 512-token chunk) as encode rates, `evaluate` (run_convdr_inference.py:116-154) at per_gpu_eval_batch_size
+    4 with conversational queries of up to 510 tokens as ms per batch -- small-batch latency of the persistent kernels."""
+    import contextlib
+    import logging
+    from types import SimpleNamespace
+    import numpy as np
+    import torch
+    from convdr_amd.inference import evaluate
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    out = {}
+
+    def rate(fn, n_items, reps=5):
+        with torch.no_grad():
+            fn(); fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        return {"ms_per_batch": ms, "items_per_s": n_items / (ms / 1e3)}
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sys.stderr):
+        dpr = MSMarcoConfigDict["dpr"].model_class(SimpleNamespace()).to(dev).eval()
+        mc = MSMarcoConfigDict["rdot_nll_multi_chunk"].model_class(RobertaConfig(max_position_embeddings=514)).to(dev).eval()
+        rdot = random_rdot_model(0).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(11)
+
+    def toks(B, L, vocab):
+        ids = torch.randint(3, vocab, (B, L), generator=g, device=dev)
+        ids[:, 0] = 0
+        return ids
+    ids, mask = toks(2048, 128, 30000), torch.ones(2048, 128, dtype=torch.long, device=dev)
+    out["dpr"] = {"passages_2048x128": dict(rate(lambda: dpr(ids, mask, is_query=False), 2048), unit="passages/s (ctx_model, BERT-base)"),
+                  "queries_64x32": dict(rate(lambda: dpr(ids[:64, :32], mask[:64, :32]), 64), unit="queries/s (question_model)")}
+    ids_r = toks(2048, 128, 50000)
+    out["rdot_nll_multi_chunk"] = {"passages_2048x128": dict(rate(lambda: mc(ids_r, mask, is_query=True), 2048), unit="sequences/s (query_emb path)")}
+    dids, dmask = toks(64, 2048, 50000), torch.ones(64, 2048, dtype=torch.long, device=dev)
+    dmask[:, 1536 + 100:] = 0        # the last chunk is partly padding, as after chunk-wise tokenisation
+    out["rdot_nll_multi_chunk"]["docs_64x4x512"] = dict(rate(lambda: mc.body_emb(dids, dmask), 64, reps=3),
+                                                        unit="documents/s (4 chunks of 512 tokens each, body_emb -> [64, 4, 768])")
+    # evaluate(): CAsT-like sessions, right-padded to the batch maximum by the collate function
+    rs = np.random.RandomState(5)
+    nq, bs, Lq = 64, 4, 510
+    lens = rs.randint(60, Lq + 1, size=nq)
+    qids_np = rs.randint(3, 50000, size=(nq, Lq)).astype(np.int64)
+    qids_np[:, 0] = 0
+    qmask = (np.arange(Lq)[None, :] < lens[:, None]).astype(np.int64)
+    qids_np *= qmask
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return nq
+
+        def __getitem__(self, i):
+            return i
+
+        def get_collate_fn(self, args, mode):
+            def collate(idx):
+                m = int(lens[idx].max())
+                return {"qid": ["q%d" % i for i in idx], "concat_ids": torch.from_numpy(qids_np[idx, :m]),
+                        "concat_id_mask": torch.from_numpy(qmask[idx, :m]), "history_utterances": [[""] for _ in idx]}
+            return collate
+    eargs = SimpleNamespace(per_gpu_eval_batch_size=bs, n_gpu=1, device=dev, seed=42)
+    log = logging.getLogger("bench")
+    evaluate(eargs, DS(), rdot, log)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        emb, _, _ = evaluate(eargs, DS(), rdot, log)
+    el = (time.perf_counter() - t0) / reps
+    out["evaluate"] = {"queries": nq, "batch": bs, "max_tokens": Lq, "mean_tokens": float(lens.mean()),
+                       "ms_per_batch": el / (nq / bs) * 1e3, "queries_per_s": nq / el,
+                       "note": "whole evaluate() call incl. DataLoader, H2D of the batches and the final D2H (rdot_nll, batch 4)"}
+    del dpr, mc, rdot
+    torch.cuda.empty_cache()
+    return out
+
+
 def extras_search_38m(dev, nq, k, d):
     """BASELINE's target corpus on ONE MI355X: 38M x 768 resident (117 GB fp32 + 58 GB fp16 scan copy of 288 GB), built from
     8 slices of 4.75M generated on the device into reserved storage; 1k queries, top-100; and the HBM-bound regime at
@@ -596,12 +693,19 @@ def main():
     for i in range(args.warmup):
         out = step(i)
     sync_all()
+    # workgroup 0 of every FFN1 launch stamps {s_memtime, s_memrealtime} at its start and end: the shader clock the roofline
+    # kernel actually ran at in this run (the part is power-managed; boxes of the pool differ by 4-5 % on identical code)
+    clock_probe = torch.zeros(4, dtype=torch.int64, device=dev)
+    _lib.check(L_.convdr_set_option(b"clock_probe", clock_probe.data_ptr()), "convdr_set_option")
     L_.convdr_prof_enable(1)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i, ev[i])
     sync_all()
     el = time.perf_counter() - t0
+    L_.convdr_set_option(b"clock_probe", 0)
+    cp = clock_probe.cpu().numpy().astype(np.float64)
+    clock_mhz = float((cp[2] - cp[0]) / ((cp[3] - cp[1]) / 100.0)) if cp[3] > cp[1] else None   # s_memrealtime: 100 MHz
     status_bad = int((out[2] != 0).sum().item()) if out[2] is not None else 0    # (after certification: always 0)
     first_pass_retries = retried[0]
     emitted, band = (t.float().mean().item() for t in index.last_counts(nq, k))
@@ -662,6 +766,14 @@ def main():
     # dispatch durations of back-to-back persistent GEMMs run 3-9 % longer, so both are stated.
     roof = line["roofline"]
     roof["achieved_hipevent"] = dom_tf
+    if clock_mhz:
+        # the same fraction against the matrix peak AT THE CLOCK THE KERNEL RAN AT (datasheet peak x delivered / 2400 MHz):
+        # comparable across boxes and power states, where `frac` is not
+        roof["clock_mhz_delivered"] = clock_mhz
+        roof["clock_source"] = "s_memtime / s_memrealtime stamps of workgroup 0 of the last timed FFN1 launch"
+        roof["peak_at_delivered_clock"] = MFMA_BF16_PEAK_TFLOPS * clock_mhz / 2400.0
+        roof["frac_at_delivered_clock"] = dom_tf / roof["peak_at_delivered_clock"]
+    roof["power"] = _power_state()
     try:
         kname = "k_gemm<8, convdr::TileCfg<2, 4, 4, 2>"      # EPI_GELU_BLK on 256 x 256 tiles (k_gemm<1, ..> before round 3)
         rnd = "r03" if os.path.exists(os.path.join(ROOT, "profiles", "r03_bench_default.kernel_stats.txt")) else "r02"
@@ -697,6 +809,7 @@ def main():
             line["train_kd_no_dropout"] = {kk: kd0[kk] for kk in ("value", "unit", "ms_per_step", "config", "final_loss")}
             line["train_rank"] = train_rank_measure(dev)
             line["encode_loop"] = extras_encode_loop(dev, random_rdot_model().to(dev).eval())
+            line["registry"] = extras_registry(dev)
             torch.cuda.empty_cache()
             line["search_38m_1gpu"] = extras_search_38m(dev, nq, k, d)
         except Exception as e:      # the extras must never cost the headline line

@@ -292,6 +292,10 @@ extern "C" int convdr_set_option(const char* name, int64_t value) {
     g_fused_ln_max_k = value;
     return 0;
   }
+  if (strcmp(name, "clock_probe") == 0) {   // measurement: device buffer of 4 uint64 for the FFN1 kernel's clock stamps (0 = off)
+    g_clock_probe = (void*)(uintptr_t)value;
+    return 0;
+  }
   if (strcmp(name, "attn_trace") == 0) {
     g_attn_trace = (void*)(uintptr_t)value;
     return 0;

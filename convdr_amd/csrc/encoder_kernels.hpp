@@ -284,6 +284,10 @@ struct GemmArgs {
   int dbg_same_tile;  // experiment: every workgroup reads tile (0, 0) (all-L2-hit upper bound); results are garbage
   int dbg_skip_epi;   // experiment: 1 no epilogue, 3 no global stores of bf16 tiles, 4 every tile stores to tile 0 (garbage results)
   unsigned long long* trace;   // experiment: [workgroup][64 tiles][16 phases] s_memtime stamps of wave 0 (or null)
+  // measurement (bench.py): workgroup 0 stamps {shader cycles (s_memtime), 100 MHz real time (s_memrealtime)} when it starts
+  // and when it has finished its last tile: [4] -> the shader clock this launch actually ran at (the part is power-managed:
+  // 2.0-2.1 GHz under these kernels, not the 2.4 GHz behind the datasheet peak).  Null: off.
+  unsigned long long* clock_probe;
   DropSite drop;      // EPI_RESID_F32 (training): dropout on the dense output (bias included) before the residual add; thresh 0 = off
 };
 
@@ -473,6 +477,10 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
   const uint32_t stride = (gridDim.x + 7u) >> 3;
   uint32_t idx = blockIdx.x >> 3;
   if (idx >= chunk_len) return;
+  if (a.clock_probe && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    a.clock_probe[0] = __builtin_amdgcn_s_memtime();
+    a.clock_probe[1] = __builtin_amdgcn_s_memrealtime();
+  }
 
   struct Coord { int64_t t0; int n0; int swap; };   // swap: V third of the fused QKV projection (tokens on registers)
   auto decode = [&](uint32_t i) {
@@ -864,6 +872,10 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
     idx = next;
     c = cn;
     buf = idle;
+  }
+  if (a.clock_probe && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    a.clock_probe[2] = __builtin_amdgcn_s_memtime();
+    a.clock_probe[3] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
