@@ -14,14 +14,15 @@ import torch
 import torch.distributed as dist
 
 
-def _world():
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+def _world(group=None):
+    """Size of `group` (default: the whole job); 1 outside a process group."""
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
 def all_gather_rows(x, group=None, force=False):
     """[n_local, d] on every rank (equal n_local) -> [W * n_local, d], rank order.
     (force: run the collective at world size 1 too -- single-GPU tests of the RCCL path.)"""
-    W = _world()
+    W = _world(group)
     if W == 1 and not (force and dist.is_initialized()):
         return x
     parts = [torch.empty_like(x) for _ in range(W)]
@@ -67,7 +68,7 @@ def search_sharded(index, queries, k, embid, group=None):
     ids = np.where(I >= 0, np.asarray(embid)[np.clip(I, 0, None)], -1)
     dev = getattr(index, "device", torch.device("cpu"))
     Dt, It = torch.from_numpy(D).to(dev), torch.from_numpy(ids).to(dev)
-    W = _world()
+    W = _world(group)
     if W == 1:
         return D, ids
     Dl = [torch.empty_like(Dt) for _ in range(W)]
@@ -95,7 +96,7 @@ def search_sharded_device(index, queries, k, embid, group=None, force=False, cer
     else:
         D, I, status = index.search_device(queries, k)[:3]
     ids = torch.where(I >= 0, embid[I.clamp(min=0)], torch.full_like(I, -1))
-    W = _world()
+    W = _world(group)
     if W == 1 and not (force and dist.is_initialized()):
         return D, ids, status
     # one collective for both: [nq, k, 3] int32 = (score bits, offset low word, offset high word)
@@ -161,7 +162,7 @@ class DataParallelStudent:
 
     def __init__(self, model, group=None, broadcast=True):
         self.model, self.group = model, group
-        if broadcast and _world() > 1:   # what the DDP constructor does (gen_passage_embeddings.py:64-69)
+        if broadcast and _world(group) > 1:   # what the DDP constructor does (gen_passage_embeddings.py:64-69)
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, 0, group=group)
             # the writes went through .data (no version bump): drop the packed bf16 copies made before them
@@ -194,7 +195,7 @@ class DataParallelStudent:
         queued on a communication stream behind that layer's completion events (convdr_backward_wait_layer), last
         layer first; embeddings + head follow the whole backward.  The compute stream waits for all of them at the
         end.  (force_overlap: run this path at world size 1 too -- the single-GPU test of the stream logic.)"""
-        W = _world()
+        W = _world(self.group)
         scale = 1.0 / W
 
         def finish(tensors):

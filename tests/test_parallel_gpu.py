@@ -145,3 +145,69 @@ def test_two_ranks_data_parallel_step_equals_one_process_on_the_whole_batch():
     assert abs(0.5 * (out[0][1] + out[1][1]) - out[0][2]) < 2e-5 * max(1.0, abs(out[0][2])), out
     for worst, _, _ in out:
         assert worst < 0.02, out     # mean |difference| per tensor, in units of the step size
+
+
+def _rank_inbatch_job(rank, world):
+    """configs[4]'s step (run_convdr_train.py:118-171 + the north_star all-gather): KD + ranking with in-batch negatives.
+    Each rank owns half of the batch AND that half's documents; the ranks' document embeddings are all-gathered (gloo
+    here, RCCL on real ranks), every local query is scored against all W x B x K documents (convdr_inbatch_ce_fwd_bwd), the
+    gradients are summed over the ranks with 1 / W folded into the clip."""
+    from types import SimpleNamespace
+    from convdr_amd import parallel
+    from convdr_amd import train as TR
+    from oracle import train as OT
+    from tests.test_train_gpu import _batch, _tiny
+    rs = np.random.RandomState(13)
+    B, K = 8, 4
+    ids, mask = _batch(rs, B, 40, [40, 17, 33, 1, 8, 25, 40, 12])
+    tid, tmask = _batch(rs, B, 16, [16, 9, 4, 16, 7, 3, 11, 16])
+    docs = torch.from_numpy(rs.randn(B * K, 768).astype(np.float32) * 0.3)       # the frozen teacher's document embeddings
+    args = SimpleNamespace(learning_rate=1e-3, adam_epsilon=1e-8, max_grad_norm=1.0, ranking_task=True, no_mse=False,
+                           num_negatives=K - 1, gradient_accumulation_steps=1, in_batch_negatives=True)
+    dev = torch.device("cuda", 0)
+
+    # the one-process reference run lives inside the same 2-rank job: its document "gather" must stay on this rank
+    solo = [dist.new_group([r]) for r in range(world)][rank]
+
+    def run(sel, ddp_on):
+        student, teacher = _tiny(seed=3).to(dev).train(), _tiny(seed=4).to(dev).eval()
+        TR.flatten_parameters(student)
+        opt = TR.get_optimizer(args, student, weight_decay=0.0)
+        sched = TR.get_linear_schedule_with_warmup(opt, 0, 10)
+        ddp = parallel.DataParallelStudent(student) if ddp_on else SimpleNamespace(group=solo, allreduce_grads=lambda **kw: 1.0)
+        batch = tuple(x[sel].to(dev) for x in (ids, mask, tid, tmask))
+        dsel = docs.view(B, K, 768)[sel].reshape(-1, 768).to(dev)
+        with torch.no_grad():
+            embs = student.eval()(batch[0], batch[1]).cpu()          # (dropout is 0 in the tiny model: = the step's forward)
+        student.train()
+        loss, l1, l2 = TR.train_step(args, student, teacher, opt, sched, batch, ddp=ddp, doc_embs=dsel)
+        return l1.item(), l2.item(), embs, {k: v.detach().cpu().clone() for k, v in student.state_dict().items()}
+
+    n = B // world
+    half = slice(rank * n, (rank + 1) * n)
+    l1_dp, l2_dp, embs_dp, sd_dp = run(half, True)
+    l1_1, l2_1, embs_1, sd_1 = run(slice(0, B), False)
+    # oracle: the global-batch in-batch loss from the (HIP) embeddings of all queries -- and this rank's share of it
+    pos = torch.arange(B) * K
+    l2_oracle = OT.inbatch_rank_loss(embs_1, docs, pos).item()
+    l2_oracle_rank = OT.inbatch_rank_loss(embs_dp, docs, pos[half]).item()
+    worst = 0.0
+    for k, v in sd_1.items():
+        if v.dtype.is_floating_point and "key.bias" not in k:
+            worst = max(worst, (v - sd_dp[k]).abs().mean().item() / args.learning_rate)
+    return worst, l1_dp, l2_dp, l1_1, l2_1, l2_oracle, l2_oracle_rank
+
+
+def test_two_ranks_ranking_step_with_inbatch_negatives_equals_one_process_on_the_whole_batch():
+    out = _run(_rank_inbatch_job, 2, 29647)
+    l2_1, l2_oracle = out[0][4], out[0][5]
+    # one process, whole batch: the device loss is the oracle's definition on the same embeddings
+    assert abs(l2_1 - l2_oracle) < 1e-4 * max(1.0, abs(l2_oracle)), out
+    # every rank's loss is the oracle's loss of ITS queries against ALL gathered documents ...
+    for o in out:
+        assert abs(o[2] - o[6]) < 1e-4 * max(1.0, abs(o[6])), out
+    # ... and the mean over ranks is the global-batch loss (equal shares), for both terms
+    assert abs(0.5 * (out[0][2] + out[1][2]) - l2_1) < 1e-4 * max(1.0, abs(l2_1)), out
+    assert abs(0.5 * (out[0][1] + out[1][1]) - out[0][3]) < 2e-5 * max(1.0, abs(out[0][3])), out
+    for o in out:
+        assert o[0] < 0.02, out      # weights after the step: mean |difference| per tensor, in units of the step size
