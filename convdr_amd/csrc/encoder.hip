@@ -66,7 +66,11 @@ static int gemm_resid_ln(const bf16_t* W, const bf16_t* Wks, const bf16_t* A, in
       CONVDR_CHECK_HIP(
           hipFuncSetAttribute((const void*)k_gemm_resid_ln, hipFuncAttributeMaxDynamicSharedMemorySize, LN_SMEM_BYTES));
     GemmLnArgs a{W, A, rows, K, bias, R, gamma, beta, eps, X,
-                 K == 768 ? (unsigned long long*)g_gemm_trace_ln : nullptr, Wks, a_blocked ? 1 : 0};
+                 K == 768 ? (unsigned long long*)g_gemm_trace_ln : nullptr, Wks, a_blocked ? 1 : 0, 0};
+#ifdef CONVDR_ENABLE_TRACE   // timing experiment that produces garbage results: only in the `make TRACE=1` library
+    static const int dbg_epi = getenv("CONVDR_DBG_SKIP_EPI") ? atoi(getenv("CONVDR_DBG_SKIP_EPI")) : 0;
+    a.dbg_skip_epi = dbg_epi == 1;
+#endif
     ProfScope prof(name, st);
     hipLaunchKernelGGL(k_gemm_resid_ln, dim3((unsigned)ceil_div64(rows, TileLN::TL)), dim3(512), LN_SMEM_BYTES, st, a);
     CONVDR_CHECK_LAUNCH("k_gemm_resid_ln");

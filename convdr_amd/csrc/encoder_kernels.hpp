@@ -283,6 +283,7 @@ struct GemmArgs {
                       // kernel streams from HBM anyway stays out of L2; a training-size output its consumer finds in L2 does not)
   int dbg_same_tile;  // experiment: every workgroup reads tile (0, 0) (all-L2-hit upper bound); results are garbage
   int dbg_skip_epi;   // experiment: 1 no epilogue, 3 no global stores of bf16 tiles, 4 every tile stores to tile 0 (garbage results)
+  int dbg_prelanded;  // experiment: a tile's first K chunks are not waited for -- the prologue as if perfectly hidden (garbage results)
   unsigned long long* trace;   // experiment: [workgroup][64 tiles][16 phases] s_memtime stamps of wave 0 (or null)
   // measurement (bench.py): workgroup 0 stamps {shader cycles (s_memtime), 100 MHz real time (s_memrealtime)} when it starts
   // and when it has finished its last tile: [4] -> the shader clock this launch actually ran at (the part is power-managed:
@@ -597,7 +598,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
     CONVDR_TRACE(0)
     int idle;   // the stage the last K step did not read
     if constexpr (R3) {
-      st = gemm_nt_mainloop_r3<T>(src3, c.swap ? a.K : klen, smem, acc, w, st, true, true, landed,
+      st = gemm_nt_mainloop_r3<T>(src3, c.swap ? a.K : klen, smem, acc, w, st, true, true, landed || a.dbg_prelanded,
                                   (a.trace && trace_tile == 8) ? a.trace + ((size_t)blockIdx.x * 64 + 56) * 16 : nullptr);
       idle = 0;
       sbias = sbias_of(st);   // free: neither read by the last step nor a prologue target

@@ -26,6 +26,8 @@ inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
   a.dbg_same_tile = dbg;
   static const int dbg_epi = getenv("CONVDR_DBG_SKIP_EPI") ? atoi(getenv("CONVDR_DBG_SKIP_EPI")) : 0;
   a.dbg_skip_epi = dbg_epi;
+  static const int dbg_pre = getenv("CONVDR_DBG_PRELANDED") ? atoi(getenv("CONVDR_DBG_PRELANDED")) : 0;
+  a.dbg_prelanded = dbg_pre;
 #endif
   static const int trace_epi = getenv("CONVDR_TRACE_EPI") ? atoi(getenv("CONVDR_TRACE_EPI")) : (int)EPI_GELU_BF16;
   a.trace = (EPI == trace_epi) ? (unsigned long long*)g_gemm_trace : nullptr;

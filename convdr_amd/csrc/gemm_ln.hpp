@@ -33,6 +33,7 @@ struct GemmLnArgs {
   unsigned long long* trace;   // experiment: [workgroup][16] s_memtime stamps of thread 0 (or null)
   const bf16_t* Wks;    // W in K-slice-major order [K / 32][768][32] (or null: stream the row-major W)
   int a_blocked;        // A is in the blocked layout [rows / 32][K / 8][32][8] the FFN1 epilogue EPI_GELU_BLK writes
+  int dbg_skip_epi;     // timing experiment (TRACE library only): the kernel ends after its main loop (garbage results)
 };
 #ifdef CONVDR_ENABLE_TRACE   // make TRACE=1: phase stamps for tools/gemm_trace_ln.py
 #define CONVDR_LN_TRACE(ph) \
@@ -183,6 +184,17 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
     CONVDR_LN_STEP(4)
   }
 
+  if (a.dbg_skip_epi) {   // (keeps the accumulators alive; never true in the product)
+    float s = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < T::MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < T::NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc.c[mt][nt][r];
+    if (s == 12345.678f) a.X[0] = f32_to_bf16(s);
+    return;
+  }
   // ---------------- epilogue: + bias + residual, LayerNorm over the 768 features of each token ----------------
   // In the accumulator layout a lane holds 4 features of one token, so direct residual loads / output stores touch
   // 32 rows x 16-32 B per instruction (measured: 23 k + 19 k cycles of a 130 k-cycle workgroup at K = 768).  Both

@@ -207,6 +207,7 @@ struct ScanArgs {
   float* cand_s;     // EMIT: [nq, cap]
   int cap;
   float* T;          // FULL: [nPt*128, nq_pad]; TOP2: [nPt*8, nq_pad]
+  int dbg_prelanded; // timing experiment (TRACE library only): a tile's first K chunks are not waited for (garbage results)
 };
 
 template <int MODE, class T>
@@ -539,7 +540,7 @@ __global__ void __launch_bounds__(T::THREADS, 2) k_ip_scan_r3(const ScanArgs a) 
     float tau_lane[T::NT];
 #pragma unroll
     for (int nt = 0; nt < T::NT; ++nt) tau_lane[nt] = tau_next[nt];
-    slots = gemm_nt_mainloop_r3<T, F16, P_AUX>(src, a.d, smem, acc, w, slots, true);
+    slots = gemm_nt_mainloop_r3<T, F16, P_AUX>(src, a.d, smem, acc, w, slots, true, false, a.dbg_prelanded != 0);
 #pragma unroll
     for (int nt = 0; nt < T::NT; ++nt) asm volatile("" : "+v"(tau_lane[nt]));
     int tid_e = threadIdx.x;
@@ -916,6 +917,7 @@ static int launch_scan_x(const ScanArgs& a, hipStream_t st) {
       ScanArgs b = a;
 #ifdef CONVDR_ENABLE_TRACE   // timing only (every threshold = +inf: results are garbage): `make TRACE=1` library only
       if (getenv("CONVDR_DBG_SCAN_NOEMIT")) b.nq = 0;
+      if (getenv("CONVDR_DBG_PRELANDED")) b.dbg_prelanded = 1;
 #endif
       ProfScope prof("ip_scan_emit", st);
       hipLaunchKernelGGL((k_ip_scan_r3<T, F16>), dim3(std::min(tiles, (unsigned)device_cu_count())), dim3(T::THREADS), R3_SMEM, st, b);
