@@ -143,6 +143,7 @@ register("convdr_mse_fwd_bwd", C.c_int, [_p, _p, C.c_int64, C.c_float, _p, _p, _
 register("convdr_rank_ce_fwd_bwd", C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, C.c_int, _p])
 register("convdr_inbatch_ce_fwd_bwd", C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, C.c_float, _p, _p, C.c_int, _p])
 register("convdr_grad_norm_clip", C.c_int, [_p, C.c_int64, C.c_float, C.c_float, _p, _p, C.c_int, _p])
+register("convdr_pair_nll_fwd_bwd", C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, _p, _p, _p])
 register("convdr_grad_sumsq", C.c_int, [_p, C.c_int64, _p, C.c_int, _p])
 register("convdr_grad_norm_finish", C.c_int, [_p, C.c_int, C.c_float, C.c_float, _p, _p])
 register("convdr_scale_f32", C.c_int, [_p, C.c_int64, _p, _p])

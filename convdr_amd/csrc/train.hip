@@ -761,6 +761,16 @@ extern "C" int convdr_rank_ce_fwd_bwd(const float* embs, const float* docs, int 
   return 0;
 }
 
+extern "C" int convdr_pair_nll_fwd_bwd(const float* q, const float* a, const float* b, const float* bias_a, const float* bias_b,
+                                       int B, int C, int E, float grad_scale, float* loss_per_query, float* d_q, float* d_a,
+                                       float* d_b, convdr_stream_t stream) {
+  CONVDR_REQUIRE(B > 0 && C >= 1 && C <= 32 && E > 0, "convdr_pair_nll_fwd_bwd: bad sizes B=%d C=%d E=%d", B, C, E);
+  hipLaunchKernelGGL(k_pair_nll_fwd_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, q, a, b, bias_a, bias_b, B, C, E, grad_scale,
+                     loss_per_query, d_q, d_a, d_b);
+  CONVDR_CHECK_LAUNCH("k_pair_nll_fwd_bwd");
+  return 0;
+}
+
 extern "C" int convdr_inbatch_ce_fwd_bwd(const float* embs, const float* docs, int B, int N, int E, const int32_t* pos,
                                          float grad_scale, float* loss_per_query, float* d_embs, int accumulate,
                                          convdr_stream_t stream) {

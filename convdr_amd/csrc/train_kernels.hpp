@@ -618,6 +618,62 @@ __global__ void __launch_bounds__(256) k_rank_ce_fwd_bwd(const float* __restrict
   }
 }
 
+// Pairwise NLL of the model surface: NLL.forward's triple branch (models.py:66-75) and NLL_MultiChunk's MaxP form
+// (models.py:92-126) in one kernel.  Per query b, with C chunks per document (C = 1 and no bias: the plain pairwise form):
+//   s_x = max_c ( <q[b], x[b, c]> + bias_x[b, c] ),  x in {a, b}        (first maximal chunk, like torch.max)
+//   loss[b] = -log_softmax([s_a, s_b])[0]
+//   dq[b] = g ((p_a - 1) a[b, c*_a] + p_b b[b, c*_b]),  da[b, c*_a] = g (p_a - 1) q[b],  db[b, c*_b] = g p_b q[b],  g = gscale / B,
+//   zero for every other chunk.  One workgroup per query; C <= 32.
+__global__ void __launch_bounds__(256) k_pair_nll_fwd_bwd(const float* __restrict__ q, const float* __restrict__ a,
+                                                          const float* __restrict__ b, const float* __restrict__ bias_a,
+                                                          const float* __restrict__ bias_b, int B, int C, int E, float gscale,
+                                                          float* __restrict__ loss_per_b, float* __restrict__ dq,
+                                                          float* __restrict__ da, float* __restrict__ db) {
+  __shared__ float sc[2][32];
+  __shared__ float pr[2];
+  __shared__ int arg[2];
+  const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* qi = q + (int64_t)i * E;
+  for (int k = wave; k < 2 * C; k += 4) {
+    const int side = k / C, c = k - side * C;
+    const float* d = (side ? b : a) + ((int64_t)i * C + c) * E;
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s += qi[e] * d[e];
+    s = wave_sum(s);
+    const float* bias = side ? bias_b : bias_a;
+    if (lane == 0) sc[side][c] = s + (bias ? bias[(int64_t)i * C + c] : 0.f);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float best[2];
+    for (int side = 0; side < 2; ++side) {
+      int am = 0;
+      for (int c = 1; c < C; ++c)
+        if (sc[side][c] > sc[side][am]) am = c;
+      arg[side] = am;
+      best[side] = sc[side][am];
+    }
+    const float mx = fmaxf(best[0], best[1]);
+    const float lz = logf(expf(best[0] - mx) + expf(best[1] - mx)) + mx;
+    pr[0] = expf(best[0] - lz);
+    pr[1] = expf(best[1] - lz);
+    loss_per_b[i] = lz - best[0];
+  }
+  __syncthreads();
+  const float g = gscale / (float)B;
+  const float ca = g * (pr[0] - 1.f), cb = g * pr[1];
+  const float* as = a + ((int64_t)i * C + arg[0]) * E;
+  const float* bs = b + ((int64_t)i * C + arg[1]) * E;
+  if (dq)
+    for (int e = threadIdx.x; e < E; e += 256) dq[(int64_t)i * E + e] = ca * as[e] + cb * bs[e];
+  for (int k = 0; k < C; ++k) {
+    if (da)
+      for (int e = threadIdx.x; e < E; e += 256) da[((int64_t)i * C + k) * E + e] = k == arg[0] ? ca * qi[e] : 0.f;
+    if (db)
+      for (int e = threadIdx.x; e < E; e += 256) db[((int64_t)i * C + k) * E + e] = k == arg[1] ? cb * qi[e] : 0.f;
+  }
+}
+
 // In-batch-negative ranking loss (BASELINE configs[4]; not in the reference -- oracle/train.py:inbatch_rank_loss is the
 // definition): every query scores ALL N gathered documents, the target is the index of its own positive.
 //   logits[n] = <e_b, docs[n]>,  loss_b = logsumexp(logits) - logits[pos_b],

@@ -471,9 +471,10 @@ def _wants_autograd(module):
 
 
 def _pairwise_nll(q_embs, a_embs, b_embs):
-    logit_matrix = torch.cat([(q_embs * a_embs).sum(-1).unsqueeze(1), (q_embs * b_embs).sum(-1).unsqueeze(1)], dim=1)
-    lsm = torch.nn.functional.log_softmax(logit_matrix, dim=1)
-    return (-1.0 * lsm[:, 0]).mean()
+    """models.py:66-75: logits = [<q, a>, <q, b>], loss = mean(-log_softmax(logits)[:, 0]); one HIP launch for the loss and
+    the gradients of all three embeddings (convdr_pair_nll_fwd_bwd)."""
+    from ..train import pairwise_nll
+    return pairwise_nll(q_embs, a_embs, b_embs)
 
 
 class NLL(EmbeddingMixin):
@@ -570,15 +571,11 @@ class NLL_MultiChunk(EmbeddingMixin):
         batchS, full_length = input_ids_a.size()
         chunk_factor = full_length // self.base_len
 
-        def maxp(embs, mask):
+        def bias(mask):   # chunks whose first position is masked are pure padding: -9999 keeps them out of the max (:100-107)
             first = mask.reshape(batchS, chunk_factor, -1)[:, :, 0]
-            inverted_bias = ((1 - first) * (-9999)).float()
-            a12 = torch.matmul(q_embs.unsqueeze(1), embs.transpose(1, 2))
-            return (a12[:, 0, :] + inverted_bias).max(dim=-1, keepdim=False).values
-        logit_matrix = torch.cat([maxp(a_embs, attention_mask_a).unsqueeze(1), maxp(b_embs, attention_mask_b).unsqueeze(1)],
-                                 dim=1)
-        lsm = torch.nn.functional.log_softmax(logit_matrix, dim=1)
-        return ((-1.0 * lsm[:, 0]).mean(), )
+            return ((1 - first) * (-9999)).float()
+        from ..train import pairwise_nll
+        return (pairwise_nll(q_embs, a_embs, b_embs, bias(attention_mask_a), bias(attention_mask_b)), )
 
 
 class RobertaDot_CLF_ANN_NLL_MultiChunk(NLL_MultiChunk, RobertaDot_NLL_LN):

@@ -472,6 +472,38 @@ def ranking_loss(embs, pos_and_negs_embeddings):
     return _RankCE.apply(embs, pos_and_negs_embeddings.detach())
 
 
+class _PairNLL(torch.autograd.Function):
+    """NLL.forward's triple branch / NLL_MultiChunk's MaxP form (convdr_pair_nll_fwd_bwd): loss and the gradients of all three
+    inputs in one launch."""
+
+    @staticmethod
+    def forward(ctx, q, a, b, bias_a, bias_b):
+        q32, a32, b32 = q.float().contiguous(), a.float().contiguous(), b.float().contiguous()
+        B, E = q32.shape
+        Cn = a32.shape[1] if a32.dim() == 3 else 1
+        ba = None if bias_a is None else bias_a.float().contiguous()
+        bb = None if bias_b is None else bias_b.float().contiguous()
+        per = torch.empty(B, dtype=torch.float32, device=q.device)
+        dq, da, db = torch.empty_like(q32), torch.empty_like(a32), torch.empty_like(b32)
+        with torch.cuda.device(q.device):
+            _lib.check(_lib.lib().convdr_pair_nll_fwd_bwd(_lib.ptr(q32), _lib.ptr(a32), _lib.ptr(b32), _lib.ptr(ba), _lib.ptr(bb), B, Cn,
+                                                          E, 1.0, _lib.ptr(per), _lib.ptr(dq), _lib.ptr(da), _lib.ptr(db),
+                                                          _lib.stream_ptr()), "convdr_pair_nll_fwd_bwd")
+        ctx.save_for_backward(dq, da, db)
+        return per.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        dq, da, db = ctx.saved_tensors
+        return dq * g, da * g, db * g, None, None
+
+
+def pairwise_nll(q_embs, a_embs, b_embs, bias_a=None, bias_b=None):
+    """mean_i -log_softmax([s_a, s_b])[0] with s_x = <q, x> (a / b [B, E]) or max over chunks of <q, x_c> + bias (a / b
+    [B, C, E], MaxP): models.py:66-75 and :92-126."""
+    return _PairNLL.apply(q_embs, a_embs, b_embs, bias_a, bias_b)
+
+
 class _InBatchCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, embs, docs_all, pos):

@@ -290,6 +290,16 @@ int convdr_rank_ce_fwd_bwd(const float* embs, const float* docs, int B, int K, i
  * loss_per_query[b] = -log_softmax(logits[b])[pos[b]] with pos[b] the row of query b's own positive document;
  * d_embs (nullable) (+)= grad_scale / B * sum_n (softmax - onehot(pos[b])) docs[n].  embs [B, E], docs [N, E] fp32,
  * pos device int32 [B], N <= 16384. */
+/* The pairwise NLL of the model surface -- NLL.forward(q, a, b) (/root/reference/model/models.py:66-75; BiEncoder.forward
+ * :254-262) and its MaxP form NLL_MultiChunk.forward (:92-126) -- with gradients for ALL three inputs (a and b are student
+ * outputs here, not frozen teacher embeddings):  s_x[i] = max_c(<q[i], x[i, c]> + bias_x[i, c]) for x in {a, b} (C chunks per
+ * document; C = 1 and NULL biases: the plain pairwise form; the first maximal chunk wins, like torch.max),
+ * loss_per_query[i] = -log_softmax([s_a, s_b])[0]; d_q / d_a / d_b (each nullable) = grad_scale / B * d(sum_i loss_i) / d(.),
+ * overwritten (non-selected chunks get zeros).  q [B, E], a / b [B, C, E], biases [B, C] fp32; C <= 32. */
+int convdr_pair_nll_fwd_bwd(const float* q, const float* a, const float* b, const float* bias_a, const float* bias_b, int B,
+                            int C, int E, float grad_scale, float* loss_per_query, float* d_q, float* d_a, float* d_b,
+                            convdr_stream_t stream);
+
 int convdr_inbatch_ce_fwd_bwd(const float* embs, const float* docs, int B, int N, int E, const int32_t* pos,
                               float grad_scale, float* loss_per_query, float* d_embs, int accumulate,
                               convdr_stream_t stream);

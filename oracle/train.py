@@ -40,17 +40,18 @@ def clip_coef(total_norm, max_norm):
     return min(1.0, max_norm / (total_norm + 1e-6))
 
 
-def kd_losses(sd_student, sd_teacher, batch, *, num_layers, num_heads, docs=None, num_negatives=9):
-    """loss1 = MSE(student(concat), teacher(target)); loss2 = CE(<student, teacher(docs)>, 0) when docs given."""
+def kd_losses(sd_student, sd_teacher, batch, *, num_layers, num_heads, docs=None, num_negatives=9, emulate_bf16=False):
+    """loss1 = MSE(student(concat), teacher(target)); loss2 = CE(<student, teacher(docs)>, 0) when docs given.
+    emulate_bf16: both towers through oracle/encoder.py's bf16-emulating forward."""
     concat_ids, concat_mask, target_ids, target_mask = batch
-    embs = OE.rdot_nll_emb(sd_student, concat_ids, concat_mask, num_layers=num_layers, num_heads=num_heads)
+    embs = OE.rdot_nll_emb(sd_student, concat_ids, concat_mask, num_layers=num_layers, num_heads=num_heads, emulate_bf16=emulate_bf16)
     with torch.no_grad():
-        t = OE.rdot_nll_emb(sd_teacher, target_ids, target_mask, num_layers=num_layers, num_heads=num_heads)
+        t = OE.rdot_nll_emb(sd_teacher, target_ids, target_mask, num_layers=num_layers, num_heads=num_heads, emulate_bf16=emulate_bf16)
     loss1 = F.mse_loss(embs, t)
     loss2 = None
     if docs is not None:
         with torch.no_grad():
-            d = OE.rdot_nll_emb(sd_teacher, docs[0], docs[1], num_layers=num_layers, num_heads=num_heads)
+            d = OE.rdot_nll_emb(sd_teacher, docs[0], docs[1], num_layers=num_layers, num_heads=num_heads, emulate_bf16=emulate_bf16)
         d = d.view(embs.shape[0], num_negatives + 1, -1)
         logits = (embs.unsqueeze(1) * d).sum(-1)
         loss2 = F.cross_entropy(logits, torch.zeros(embs.shape[0], dtype=torch.long))
