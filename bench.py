@@ -328,7 +328,8 @@ def extras(dev, index, model, tower, head, building, filled_rows, nq, k, d, Q):
                     same = bool((Ic == Im).all().item() and (Dc == Dm).all().item())
                 del fresh
         # the ceiling of this box: pinned host memory -> HBM, nothing else (boxes of the pool differ: 44-57 GB/s)
-        pin = torch.empty((1 << 28,), dtype=torch.uint8).pin_memory()
+        from convdr_amd.search import gpu_numa_cpus, pinned_near
+        pin = pinned_near(dev, (1 << 28,), torch.uint8)     # on the GPU's NUMA node, like the loader's staging buffers
         dst = torch.empty_like(pin, device=dev)
         dst.copy_(pin, non_blocking=True)
         torch.cuda.synchronize()
@@ -342,9 +343,48 @@ def extras(dev, index, model, tower, head, building, filled_rows, nq, k, d, Q):
                              "chunk_MB": 64, "pinned_h2d_ceiling_GB_per_s_this_box": h2d, "frac_of_h2d_ceiling": max(rates[1:]) / h2d,
                              "pcie_gen5_x16_GB_per_s": 63.0, "results_identical_to_resident_block": same,
                              "host_threads": len(os.sched_getaffinity(0)),
+                             "gpu_numa_node_cpus": len(gpu_numa_cpus(dev) or ()) or None,
                              "path": "blocks.BlockView (payload offset of the pickle; page cache warm) -> positioned reads, 16 slices "
                                      "per chunk and 3 chunks in flight, into 4 process-wide pinned staging buffers -> H2D on a copy "
                                      "stream, convdr_ip_prepare_block_f16 of chunk i under the copy of chunk i + 1"}
+        # ---- (1b) a-11 the way the reference runs it (run_convdr_inference.py:157-242): search_one_by_one over block FILES --
+        # load -> add -> search -> merge -> reset per block, end to end, two blocks of 1M passages
+        from convdr_amd.search import search_one_by_one
+        host = index._p32.cpu().numpy()
+        half = host.shape[0]
+        for b in range(2):
+            rows = host if b == 0 else np.ascontiguousarray(host[::-1])            # (second block: the same rows, reversed)
+            blocks.dump_block(os.path.join(td, "passage__emb_p__data_obj_%d.pb" % b), rows)
+            blocks.dump_block(os.path.join(td, "passage__embid_p__data_obj_%d.pb" % b), np.arange(b * half, (b + 1) * half, dtype=np.int64))
+        del host
+        Qh = Q.cpu().numpy()
+        runs = []
+        for rep in range(3):
+            tmg = {}
+            gi = FlatIPIndex(d, device=dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mD, mI = search_one_by_one(td, gi, Qh, k, timings=tmg)
+            dt = time.perf_counter() - t0
+            runs.append((dt, tmg))
+            del gi
+        dt, tmg = min(runs, key=lambda r: r[0])
+        Dm, Im = index.search_tensors(Q, k)
+        # every passage exists twice (row i of block 0 = row n - 1 - i of block 1), so the merged scores are the resident
+        # block's top scores, each twice, and every returned offset folds back onto a row with exactly that score
+        # (bit-exact ids against the oracle's search_one_by_one: tests/test_ip_search_gpu.py, tools/dbg/sobo_probe.py)
+        want = Dm.double().cpu().numpy().repeat(2, axis=1)                    # the 2k merged entries: the resident top-k, twice
+        fold = np.sort(np.where(mI < half, mI, 2 * half - 1 - mI), axis=1)
+        rows_ok = bool((fold[:, 0::2] == fold[:, 1::2]).all() and (fold[:, 0::2] == np.sort(Im.cpu().numpy(), axis=1)).all())
+        pair_ok = bool(mD.shape[1] == 2 * k and np.array_equal(mD, want) and rows_ok)
+        out["search_one_by_one_files"] = {
+            "blocks": 2, "passages_per_block": half, "queries": nq, "topk": k, "seconds_end_to_end": dt,
+            "seconds_all_reps": [r[0] for r in runs], "file_GB_per_s_end_to_end": tmg["bytes"] / dt / 1e9,
+            "breakdown_s": {"load_add (host: file -> pinned -> H2D enqueue, previous block's search running on the GPU)": tmg["load_add_s"],
+                            "certify + merge + first pass enqueue": tmg["search_finish_merge_s"],
+                            "queries H2D / result D2H / rest": dt - tmg["load_add_s"] - tmg["search_finish_merge_s"]},
+            "merged_list_consistent_with_resident_search": pair_ok,
+            "flow": "blocks.BlockView -> FlatIPIndex.add (streamed) -> search_begin; next block's add; search_finish -> convdr_topk_merge -> reset"}
     finally:
         shutil.rmtree(td, ignore_errors=True)
     out.update(extras_search(dev, index, tower, head, building, filled_rows, nq, k, d))
@@ -634,6 +674,9 @@ def main():
     from convdr_amd import _lib
     from convdr_amd.search import FlatIPIndex
     L_ = _lib.lib()
+    if world == 1 and not dist_on and not args.no_extras:
+        from convdr_amd import train as _TR
+        _TR.reserve_streams(dev)      # (the train_kd / train_rank legs below: see train.reserve_streams)
 
     n, nq, k, d, EB, SL = args.passages, args.queries, args.topk, D_OUT, args.enc_batch, args.seq_len
     model = random_rdot_model().to(dev).eval()

@@ -12,6 +12,7 @@ _p = C.c_void_p
 _SIGNATURES = {
     "convdr_version": (C.c_int, []),
     "convdr_last_error": (C.c_char_p, []),
+    "convdr_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "convdr_prof_enable": (C.c_int, [C.c_int]),
     "convdr_prof_collect": (C.c_int, [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "convdr_ip_column_mean": (C.c_int, [_p, C.c_int64, C.c_int, _p, _p, _p]),
@@ -144,6 +145,7 @@ register("convdr_rank_ce_fwd_bwd", C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, 
 register("convdr_inbatch_ce_fwd_bwd", C.c_int, [_p, _p, C.c_int, C.c_int, C.c_int, _p, C.c_float, _p, _p, C.c_int, _p])
 register("convdr_grad_norm_clip", C.c_int, [_p, C.c_int64, C.c_float, C.c_float, _p, _p, C.c_int, _p])
 register("convdr_pair_nll_fwd_bwd", C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, _p, _p, _p])
+register("convdr_train_set_side_stream", C.c_int, [_p])
 register("convdr_grad_sumsq", C.c_int, [_p, C.c_int64, _p, C.c_int, _p])
 register("convdr_grad_norm_finish", C.c_int, [_p, C.c_int, C.c_float, C.c_float, _p, _p])
 register("convdr_scale_f32", C.c_int, [_p, C.c_int64, _p, _p])

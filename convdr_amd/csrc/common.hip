@@ -81,4 +81,10 @@ extern "C" int convdr_prof_collect(const char* name, float* total_ms, int* launc
 }
 
 extern "C" int convdr_version(void) { return 100; }
+
+extern "C" int convdr_device_pci_bus_id(int device, char* out, int len) {
+  CONVDR_REQUIRE(out != nullptr && len >= 16, "convdr_device_pci_bus_id: buffer of %d bytes", len);
+  CONVDR_CHECK_HIP(hipDeviceGetPCIBusId(out, len, device));
+  return 0;
+}
 extern "C" const char* convdr_last_error(void) { return convdr::g_err; }

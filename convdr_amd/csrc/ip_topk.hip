@@ -1116,7 +1116,7 @@ static int ip_search(int kind, float p_scale, const float* q_f32, int nq, const 
   if (n == 0) {
     hipLaunchKernelGGL(k_fill_f32, dim3((p.nq_pad + 255) / 256), dim3(256), 0, st, tau, p.nq_pad, -INFINITY);
   } else {
-    ScanArgs a;
+    ScanArgs a{};
     a.P = (const bf16_t*)p_bf16; a.Qb = qb; a.Plo = (const bf16_t*)p_bf16_lo; a.Qlo = qlo; a.n = n; a.nq = nq; a.nq_pad = p.nq_pad; a.d = d;
     a.nQt = p.nQt; a.tau = tau; a.counts = counts; a.cand_id = cand_id; a.cand_s = cand_s; a.cap = cap; a.T = T;
     if (tau_in) {

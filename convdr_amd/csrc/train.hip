@@ -144,6 +144,8 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
 // fork() makes the side stream wait for what the main stream has enqueued so far (the layer's activation gradients);
 // nothing on the main stream ever waits for the side stream before the final join, because every operand the branch
 // reads lives in a per-layer buffer (LayerBwd / LayerSave) and its scratch (slab, the bias part of `part`) is its own.
+static hipStream_t g_ext_side = nullptr;   // convdr_train_set_side_stream (before the first backward of the process)
+
 struct WgradFork {
   hipStream_t main, side;
   hipEvent_t prod, fin;
@@ -161,8 +163,15 @@ struct WgradFork {
     main = st;
     if (!ok) {
       // (a lowest-priority side stream -- so that this branch would only take the compute units the critical chain leaves
-      //  idle -- measured no different on MI355X, round 3: 11.63 vs 11.66 ms per configs[2] step)
-      CONVDR_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      //  idle -- measured no different on MI355X, round 3: 11.63 vs 11.66 ms per configs[2] step; round 4: streams of
+      //  other priorities bring their own hardware queues, and with more than GPU_MAX_HW_QUEUES = 4 queues alive the step
+      //  takes 17-19 ms.)  Which hardware queue a stream shares with which other stream is decided by HIP in order of first
+      // use, and a branch that shares the MAIN stream's queue runs serialised with the chain it is meant to run beside
+      // (10.7 -> 12.4 ms per step depending on nothing but how many streams the process had used before,
+      // tools/dbg/stream_queue_probe.py): the host may hand in a stream it has verified to run concurrently with the main
+      // one (convdr_train_set_side_stream; train.py:_aux_streams does that once per process).
+      if (g_ext_side) side = g_ext_side;
+      else CONVDR_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
       CONVDR_CHECK_HIP(hipEventCreateWithFlags(&prod, hipEventDisableTiming));
       CONVDR_CHECK_HIP(hipEventCreateWithFlags(&fin, hipEventDisableTiming));
       for (int i = 0; i < TRAIN_MAX_LAYERS; ++i) {
@@ -724,6 +733,13 @@ extern "C" int convdr_wgrad(const void* dy, int N, int64_t ld_dy, const void* x,
                  "convdr_wgrad: bad sizes N=%d K=%d rows=%lld", N, K, (long long)rows);
   const WgradItem it{(const bf16_t*)dy, N, ld_dy, (const bf16_t*)x, K, ld_x, dW};
   return wgrad_batch(&it, 1, rows, slab, slab_elems, (hipStream_t)stream);
+}
+
+extern "C" int convdr_train_set_side_stream(convdr_stream_t stream) {
+  WgradFork& wf = WgradFork::get();
+  CONVDR_REQUIRE(!wf.ok || wf.side == (hipStream_t)stream, "convdr_train_set_side_stream: the weight-gradient stream of this device is already in use");
+  g_ext_side = (hipStream_t)stream;
+  return 0;
 }
 
 extern "C" int convdr_backward_wait_layer(int layer, convdr_stream_t stream) {

@@ -66,6 +66,14 @@ class FlatIPIndex:
         self._s32 = self._s16 = self._slo = None
         self.reset()
 
+    def twin(self):
+        """An empty index with this one's parameters (search_one_by_one keeps two blocks in flight: one being searched, one
+        being loaded)."""
+        t = FlatIPIndex(self.d_in, device=self.device, cap=self.cap, rank_target=self.rank_target, precision=self.precision,
+                        center=self.center)
+        t.host_chunk_bytes, t.host_copy_threads, t.host_stage_buffers = self.host_chunk_bytes, self.host_copy_threads, self.host_stage_buffers
+        return t
+
     # -- faiss-like surface ---------------------------------------------------
     @property
     def ntotal(self):
@@ -243,7 +251,7 @@ class FlatIPIndex:
             cs.wait_stream(main)                    # (allocation order / the copy of the old rows in _grow_for)
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             threads = max(1, min(int(self.host_copy_threads), avail))
-            pool = _copy_pool(threads * (nbuf - 1))
+            pool = _copy_pool(threads * (nbuf - 1), self.device)
             chunks = [(s, min(n, s + rows_per)) for s in range(0, n, rows_per)]
 
             def fill(ci):
@@ -398,6 +406,12 @@ class FlatIPIndex:
         error band still fits the candidate list, with the split scan (4x tighter band) once the band has swallowed
         the whole list.  The index remembers when most queries of a block ended on the split scan and starts there next
         time (`x3_first`)."""
+        return self.search_finish(self.search_begin(q, k))
+
+    def search_begin(self, q, k):
+        """First half of search_tensors: the first scan pass is ENQUEUED (no host round trip) and a handle returned;
+        search_finish(handle) reads the certificates and walks the ladder for whatever the first pass left open.  Between the
+        two the host is free -- search_one_by_one loads the next block file meanwhile."""
         import torch
         qt = torch.as_tensor(q)
         if qt.dtype != torch.float32:
@@ -405,9 +419,13 @@ class FlatIPIndex:
         qt = (self._pad_columns(qt) if self.d != self.d_in else qt.to(self.device)).contiguous()
         assert qt.dim() == 2 and qt.shape[1] == self.d
         k = int(k)
-        nq = int(qt.shape[0])
         x3 = self.precision in ("bf16x3", "fp16x3") or (self.precision == "auto" and getattr(self, "_x3_first", False) and self.ntotal > 0)
-        D, I, status, tau_retry = self.search_device(qt, k, x3=x3)
+        return (qt, k, x3) + tuple(self.search_device(qt, k, x3=x3))
+
+    def search_finish(self, handle):
+        import torch
+        qt, k, x3, D, I, status, tau_retry = handle
+        nq = int(qt.shape[0])
         rescaled = 0
         n_range, n_bad = torch.stack([(status == STATUS_RANGE).sum(), (status != 0).sum()]).tolist()   # one host round trip
         if self.kind == "f16" and n_range:
@@ -510,6 +528,67 @@ class FlatIPIndex:
 # fresh set per index would cost as much as loading a 3 GB block through them.
 _STAGING = {}
 _POOLS = {}
+_NUMA = {}
+
+
+def gpu_numa_cpus(device):
+    """CPUs of the NUMA node the GPU hangs off (None when the topology cannot be read, or on a one-node host).
+    A pinned buffer is placed where its allocating thread runs; across the socket link the same H2D copy runs at 29 GB/s
+    instead of 57 (measured on a 2-socket MI355X host, tools/dbg/loader_probe.py) -- which is why the loader's rate, and the
+    'pinned H2D ceiling' beside it, used to differ by a factor of two between boxes of one pool."""
+    import torch
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx in _NUMA:
+        return _NUMA[idx]
+    cpus = None
+    try:
+        import ctypes
+        buf = ctypes.create_string_buffer(64)
+        # (through libconvdr_hip.so, which is bound to the HIP runtime torch loaded: dlopen-ing "libamdhip64.so" by name
+        #  brings a SECOND runtime into the process, which slowed every later launch -- the training step went host-bound)
+        if _lib.lib().convdr_device_pci_bus_id(int(idx), buf, 64) == 0:
+            bdf = buf.value.decode().lower()
+            node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+            import glob
+            if node >= 0 and len(glob.glob("/sys/devices/system/node/node[0-9]*")) > 1:
+                got = set()
+                for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+                    lo, _, hi = part.partition("-")
+                    got.update(range(int(lo), int(hi or lo) + 1))
+                got &= os.sched_getaffinity(0)
+                cpus = got or None
+    except Exception:
+        cpus = None
+    _NUMA[idx] = cpus
+    return cpus
+
+
+class _on_cpus:
+    """Confine the calling thread to `cpus` for the duration of the block (no-op for None)."""
+
+    def __init__(self, cpus):
+        self.cpus, self.old = cpus, None
+
+    def __enter__(self):
+        if self.cpus:
+            try:
+                self.old = os.sched_getaffinity(0)
+                os.sched_setaffinity(0, self.cpus)
+            except OSError:
+                self.old = None
+
+    def __exit__(self, *exc):
+        if self.old is not None:
+            os.sched_setaffinity(0, self.old)
+
+
+def pinned_near(device, shape, dtype):
+    """A pinned host tensor allocated (first-touched and locked) on the GPU's NUMA node."""
+    import torch
+    with _on_cpus(gpu_numa_cpus(device)):
+        t = torch.empty(shape, dtype=dtype).pin_memory()
+    return t
 
 
 def _staging(device, rows, d, nbuf):
@@ -517,15 +596,25 @@ def _staging(device, rows, d, nbuf):
     key = (str(device), int(d), int(nbuf))
     ent = _STAGING.get(key)
     if ent is None or ent[0][0].shape[0] < rows:
-        ent = _STAGING[key] = ([torch.empty((rows, d), dtype=torch.float32).pin_memory() for _ in range(nbuf)], [None] * nbuf)
+        ent = _STAGING[key] = ([pinned_near(device, (rows, d), torch.float32) for _ in range(nbuf)], [None] * nbuf)
     return ent
 
 
-def _copy_pool(threads):
-    pool = _POOLS.get(threads)
+def _copy_pool(threads, device=None):
+    """Reader threads of the block loader; confined to the GPU's NUMA node (their destination is the pinned staging there)."""
+    cpus = gpu_numa_cpus(device) if device is not None else None
+    key = (threads, None if cpus is None else min(cpus))
+    pool = _POOLS.get(key)
     if pool is None:
         from concurrent.futures import ThreadPoolExecutor
-        pool = _POOLS[threads] = ThreadPoolExecutor(max_workers=threads)
+
+        def init():
+            if cpus:
+                try:
+                    os.sched_setaffinity(0, cpus)
+                except OSError:
+                    pass
+        pool = _POOLS[key] = ThreadPoolExecutor(max_workers=threads, initializer=init)
     return pool
 
 
@@ -564,54 +653,89 @@ def merge_topk_device(merged, cand, topN):
     return Do, Io
 
 
-def search_one_by_one(ann_data_dir, gpu_index, query_embedding, topN, max_blocks=8):
+def search_one_by_one(ann_data_dir, gpu_index, query_embedding, topN, max_blocks=8, timings=None):
     """Block-by-block search + merge; same contract as the reference function (float64 scores, int64 offsets,
     2 * topN columns once two blocks have been merged).  With a FlatIPIndex the embedding block is memory-mapped
     (blocks.BlockView: no pickle.load copy) and streamed to HBM in pinned chunks (FlatIPIndex.add), and the per-block
     results, the offset lookup ``embid[I]`` and the running merge stay on the device; any other index object
-    (``.add/.search/.reset``) takes the reference's host path."""
+    (``.add/.search/.reset``) takes the reference's host path.
+    Device path, pipelined: TWO blocks are in flight -- the first scan pass of block i is enqueued (search_begin, no host
+    round trip), then the host reads block i + 1 into the twin index (file -> pinned staging -> HBM on the copy stream)
+    while the GPU searches block i; block i's certificates are read (search_finish), its result merged and its storage
+    dropped only after that.  The reference's load -> add -> search -> merge -> reset is strictly serial (:157-242).
+    timings (optional dict): filled with the wall seconds spent per stage."""
+    import time
     from . import blocks
-    on_device = hasattr(gpu_index, "search_tensors")
+    on_device = hasattr(gpu_index, "search_begin")
     merged = None
-    for block_id in range(max_blocks):
-        emb_path = os.path.join(ann_data_dir, "passage__emb_p__data_obj_%d.pb" % block_id)
-        view = None
-        try:
-            if on_device:
+    tm = {"load_add_s": 0.0, "search_finish_merge_s": 0.0, "blocks": 0, "bytes": 0}
+
+    def paths(block_id):
+        return (os.path.join(ann_data_dir, "passage__emb_p__data_obj_%d.pb" % block_id),
+                os.path.join(ann_data_dir, "passage__embid_p__data_obj_%d.pb" % block_id))
+    if on_device:
+        import torch
+        twins = [gpu_index, None]
+        pending = None                       # (handle, index, embid) of the block whose first pass is in flight
+
+        def finish(p):
+            nonlocal merged
+            handle, idx, ids = p
+            D, I = idx.search_finish(handle)
+            embid = torch.as_tensor(np.asarray(ids, dtype=np.int64), device=D.device)
+            found = torch.where(I >= 0, embid[I.clamp_min(0)], I) if embid.numel() else I   # -1 padding when n < topN
+            cand = (D, found)
+            merged = cand if merged is None else merge_topk_device(merged, cand, topN)
+            idx.reset()
+        for block_id in range(max_blocks):
+            emb_path, id_path = paths(block_id)
+            try:
                 view = blocks.BlockView(emb_path)
-                passage_embedding = view
-            else:
-                passage_embedding = load_block(emb_path)
-            passage_embedding2id = load_block(os.path.join(ann_data_dir, "passage__embid_p__data_obj_%d.pb" % block_id))
-        except Exception:
-            if view is not None:
-                view.close()
-            break
+            except Exception:
+                break
+            try:
+                try:
+                    ids = load_block(id_path)
+                except Exception:
+                    break
+                idx = twins[block_id & 1]
+                if idx is None:
+                    idx = twins[block_id & 1] = gpu_index.twin()
+                t0 = time.perf_counter()
+                idx.add(view)                # the host reads; the GPU meanwhile searches the previous block
+                t1 = time.perf_counter()
+                tm["load_add_s"] += t1 - t0
+                tm["bytes"] += int(view.array.nbytes)
+                tm["blocks"] += 1
+                if pending is not None:
+                    finish(pending)
+                pending = (idx.search_begin(query_embedding, topN), idx, ids)
+                tm["search_finish_merge_s"] += time.perf_counter() - t1
+            finally:
+                view.close()                 # (the file is read by host threads only, and add() has joined them)
+        if pending is not None:
+            t1 = time.perf_counter()
+            finish(pending)
+            tm["search_finish_merge_s"] += time.perf_counter() - t1
+        if timings is not None:
+            timings.update(tm)
+        if merged is None:
+            raise FileNotFoundError("no passage blocks under %s" % ann_data_dir)
+        return merged[0].double().cpu().numpy(), merged[1].cpu().numpy()
+    for block_id in range(max_blocks):
+        emb_path, id_path = paths(block_id)
         try:
-            gpu_index.add(passage_embedding)
-            if on_device:
-                import torch
-                D, I = gpu_index.search_tensors(query_embedding, topN)
-                embid = torch.as_tensor(np.asarray(passage_embedding2id, dtype=np.int64), device=D.device)
-                ids = torch.where(I >= 0, embid[I.clamp_min(0)], I) if embid.numel() else I   # -1 padding when n < topN
-                cand = (D, ids)
-                merged = cand if merged is None else merge_topk_device(merged, cand, topN)
-            else:
-                D, I = gpu_index.search(query_embedding, topN)
-                cand = (D.astype(np.float64), np.asarray(passage_embedding2id)[I])
-                merged = cand if merged is None else merge_topk(merged, cand, topN)
-            gpu_index.reset()
-        finally:
-            if view is not None:
-                if on_device:
-                    import torch
-                    torch.cuda.synchronize(gpu_index.device)    # the streamed copy reads the mapping until it completes
-                passage_embedding = None
-                view.close()
+            passage_embedding = load_block(emb_path)
+            passage_embedding2id = load_block(id_path)
+        except Exception:
+            break
+        gpu_index.add(passage_embedding)
+        D, I = gpu_index.search(query_embedding, topN)
+        cand = (D.astype(np.float64), np.asarray(passage_embedding2id)[I])
+        merged = cand if merged is None else merge_topk(merged, cand, topN)
+        gpu_index.reset()
     if merged is None:
         raise FileNotFoundError("no passage blocks under %s" % ann_data_dir)
-    if on_device:
-        return merged[0].double().cpu().numpy(), merged[1].cpu().numpy()
     return merged
 
 

@@ -601,14 +601,8 @@ def _overlapped_sumsq(flat, tower, scratch, dev):
     return nl * per + nb_emb + nb_head
 
 
-_NORM_STREAMS = {}
-
-
 def _norm_stream(device):
-    key = (device.type, device.index)
-    if key not in _NORM_STREAMS:
-        _NORM_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _NORM_STREAMS[key]
+    return _side_stream(device)      # (idle during the backward: the teacher's forward and the weight packing are long done)
 
 
 def clip_grad_norm_(parameters, max_norm, defer_to=None, extra_scale=1.0, overlap_backward=False):
@@ -844,11 +838,77 @@ def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_st
 _SIDE_STREAMS = {}
 
 
-def _side_stream(device):
+def _runs_beside(main, cand, big, small):
+    """Do `main` and `cand` run concurrently -- in BOTH directions: a short kernel on one stream, enqueued after a long one
+    on the other, must finish while the long one is still running?  Two streams that share a hardware queue fail at least
+    one direction (a kernel with the barrier bit waits for everything queued before it, whichever stream it came from)."""
+    def one(long_s, short_s):
+        e0, el, es = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record(long_s)
+        with torch.cuda.stream(long_s):
+            for _ in range(4):
+                big.mul_(1.0)
+            el.record(long_s)
+        with torch.cuda.stream(short_s):
+            short_s.wait_event(e0)
+            small.add_(1.0)
+            small.add_(1.0)          # (a dependent pair: the second one carries the in-stream ordering)
+            es.record(short_s)
+        el.synchronize()
+        es.synchronize()
+        return e0.elapsed_time(es) < 0.5 * e0.elapsed_time(el)
+    return one(main, cand) and one(cand, main)
+
+
+def _aux_streams(device):
+    """(A, B): the stream of the frozen teacher's forward / weight packing / per-layer gradient norms, and the stream of the
+    backward's weight-gradient branches -- both VERIFIED to run beside the current stream.  HIP multiplexes all streams of
+    a process onto GPU_MAX_HW_QUEUES = 4 hardware queues in order of first use; a side stream that lands on the main
+    stream's queue serialises with it, and the configs[2] step measured 10.7 .. 12.4 ms depending on nothing but how many
+    streams the process had used before (tools/dbg/stream_queue_probe.py; extra priorities or more queues are worse:
+    17-19 ms).  So the first training step of a process tries streams of torch's pool until two pass the test."""
     key = (device.type, device.index)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    if key in _SIDE_STREAMS:
+        return _SIDE_STREAMS[key]
+    main = torch.cuda.current_stream(device)
+    picked, tried = [], []
+    try:
+        big = torch.empty(64 << 20, dtype=torch.float32, device=device).zero_()       # 4 x 0.5 GB of traffic: ~0.4 ms
+        small = torch.zeros(256, dtype=torch.float32, device=device)
+        import os
+        for _ in range(int(os.environ.get("CONVDR_AUX_SKIP", "0"))):
+            tried.append(torch.cuda.Stream(device=device))
+        for _ in range(12):
+            cand = torch.cuda.Stream(device=device)
+            tried.append(cand)
+            if _runs_beside(main, cand, big, small) and all(cand.cuda_stream != p.cuda_stream for p in picked):
+                picked.append(cand)
+                if len(picked) == 2:
+                    break
+        del big, small
+    except Exception:
+        pass
+    while len(picked) < 2:
+        picked.append(tried[len(picked)] if len(tried) > len(picked) else torch.cuda.Stream(device=device))
+    with torch.cuda.device(device):
+        try:
+            _lib.check(_lib.lib().convdr_train_set_side_stream(C.c_void_p(picked[1].cuda_stream)), "convdr_train_set_side_stream")
+        except _lib.ConvdrError:
+            pass      # (a backward has already run in this process: its own side stream stays)
+    _SIDE_STREAMS[key] = tuple(picked)
     return _SIDE_STREAMS[key]
+
+
+def reserve_streams(device=None):
+    """Pick the training step's two auxiliary streams NOW.  Worth calling at the start of a process that will train later
+    (bench.py does): HIP's stream -> hardware-queue assignment follows the order of first use, and the configuration in
+    which the step's streams are the first ones of the process is the one that was measured."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    return _aux_streams(dev)
+
+
+def _side_stream(device):
+    return _aux_streams(device)[0]
 
 
 def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=None, doc_mask=None, ddp=None, doc_embs=None,

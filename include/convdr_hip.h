@@ -26,6 +26,9 @@ extern "C" {
 typedef void* convdr_stream_t;
 
 int convdr_version(void);
+/* "domain:bus:device.function" of HIP device `device` (hipDeviceGetPCIBusId through the runtime this library is bound
+ * to): the host side looks up the GPU's NUMA node with it and places its pinned staging buffers there. */
+int convdr_device_pci_bus_id(int device, char* out, int len);
 const char* convdr_last_error(void);
 
 /* Optional per-kernel timing with hipEvents recorded on the launch stream (bench.py's roofline
@@ -321,6 +324,11 @@ int convdr_grad_norm_clip(float* grads, int64_t n, float max_norm, float pre_sca
 int convdr_grad_sumsq(const float* x, int64_t n, float* partials, int nblocks, convdr_stream_t stream);
 int convdr_grad_norm_finish(const float* partials, int count, float max_norm, float pre_scale, float* norm_and_coef,
                             convdr_stream_t stream);
+
+/* The stream convdr_encoder_backward runs its weight-gradient branches on (default: one it creates itself).  HIP multiplexes
+ * streams onto GPU_MAX_HW_QUEUES hardware queues in order of first use; a caller that has verified that `stream` runs
+ * concurrently with its compute stream hands it in here, once, before the first backward of the process. */
+int convdr_train_set_side_stream(convdr_stream_t stream);
 
 /* x[i] *= scale[0] (device scalar), e.g. the clip coefficient */
 int convdr_scale_f32(float* x, int64_t n, const float* scale, convdr_stream_t stream);

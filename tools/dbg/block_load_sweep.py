@@ -21,10 +21,14 @@ try:
                     rates.append(bv.array.nbytes / (time.perf_counter() - t0) / 1e9)
                     del idx
             print("chunk %3d MB threads/chunk %2d buffers %d: %.1f GB/s (best of 3: %.1f)" % (chunk, th, nb, rates[-1], max(rates)), flush=True)
-    # pure H2D ceiling from pinned memory
-    pin = torch.empty((n // 4, d)).pin_memory(); dev = torch.empty((n // 4, d), device="cuda")
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(4): dev.copy_(pin, non_blocking=True)
-    torch.cuda.synchronize(); print("pinned H2D: %.1f GB/s" % (4 * pin.numel() * 4 / (time.perf_counter() - t0) / 1e9))
+    # pure H2D ceiling from pinned memory: wherever the allocating thread happened to run, and on the GPU's NUMA node
+    from convdr_amd.search import gpu_numa_cpus, pinned_near
+    print("gpu numa cpus:", len(gpu_numa_cpus("cuda:0") or ()))
+    dev = torch.empty((n // 4, d), device="cuda")
+    for name, pin in (("default placement", torch.empty((n // 4, d)).pin_memory()), ("near the GPU", pinned_near("cuda:0", (n // 4, d), torch.float32))):
+        dev.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(4): dev.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize(); print("pinned H2D (%s): %.1f GB/s" % (name, 4 * pin.numel() * 4 / (time.perf_counter() - t0) / 1e9))
 finally:
     shutil.rmtree(td, ignore_errors=True)
