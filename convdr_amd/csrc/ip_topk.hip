@@ -91,9 +91,18 @@ template <int KIND, bool PER_ROW_SCALE>
 __global__ void __launch_bounds__(256) k_rows_to_half(const float* __restrict__ X, int64_t n, int d,
                                                       const float* __restrict__ centre, float scale, bf16_t* __restrict__ Y,
                                                       bf16_t* __restrict__ Ylo, float* __restrict__ row_norm,
-                                                      float* __restrict__ max_norm) {
+                                                      float* __restrict__ max_norm, int64_t n_pad = 0,
+                                                      uint32_t* __restrict__ zero_u32 = nullptr, int64_t zero_count = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float wmax = 0.f;
+  // query preparation of a search: the padding rows [n, n_pad) of Y / Ylo and the candidate counters are zeroed here
+  // instead of by three memsets in front of this kernel (a search of <= 128 queries is a chain of short launches)
+  for (int64_t row = n + (int64_t)blockIdx.x * 4 + wave; row < n_pad; row += (int64_t)gridDim.x * 4)
+    for (int e = lane * 4; e < d; e += 256) {
+      *(uint2*)(Y + row * d + e) = make_uint2(0u, 0u);
+      if (Ylo) *(uint2*)(Ylo + row * d + e) = make_uint2(0u, 0u);
+    }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < zero_count; i += (int64_t)gridDim.x * 256) zero_u32[i] = 0u;
   // Norms are summed in fp64: eps is proportional to them, and in fp32 the squares of elements below ~1e-19 underflow
   // (a block of tiny-magnitude embeddings would get norm 0 = "no rounding error").  The pass is HBM-bound either way.
   auto sq4 = [](const float4& v) {
@@ -737,7 +746,9 @@ __global__ void __launch_bounds__(1024) k_ip_cut(int64_t n, int k, int cap, cons
       st = CONVDR_IP_UNCERTAIN;  // band reaches below tau: list incomplete in [cut, tau)
       retry = nextafterf(cut, -INFINITY);
     }
-    if (pm > norm_limit) {   // fp16 scan copy built with a scale too large for this block's norms: elements may be inf
+    // fp16 scan copy built with a scale too large for this block's norms -- or a query so long that its per-row power-of-two
+    // scale hit the clamp (norm > ~8e34) --: elements of an operand may be inf
+    if (pm > norm_limit || qnorm[q] > norm_limit) {
       st = CONVDR_IP_RANGE;
       retry = -INFINITY;
     }
@@ -1100,17 +1111,15 @@ static int ip_search(int kind, float p_scale, const float* q_f32, int nq, const 
   double* cand_x = (double*)(ws + p.o_x);
   uint32_t* band = (uint32_t*)(ws + p.o_m);
 
-  // queries -> bf16 (+ norms); padded rows stay zero
-  CONVDR_CHECK_HIP(hipMemsetAsync(qb, 0, (size_t)p.nq_pad * d * 2, st));
-  CONVDR_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)p.nq_pad * IP_COUNT_STRIDE * 4, st));
+  // queries -> 16-bit operands (+ norms); the kernel also zeroes the padding rows and the candidate counters
   bf16_t* qlo = p_bf16_lo ? (bf16_t*)(ws + p.o_qlo) : nullptr;
-  if (qlo) CONVDR_CHECK_HIP(hipMemsetAsync(qlo, 0, (size_t)p.nq_pad * d * 2, st));
+  const int64_t n_count = (int64_t)p.nq_pad * IP_COUNT_STRIDE;
   if (kind == IP_KIND_F16)
-    hipLaunchKernelGGL((k_rows_to_half<IP_KIND_F16, true>), dim3((nq + 3) / 4), dim3(256), 0, st, q_f32, (int64_t)nq, d,
-                       (const float*)nullptr, 1.f, qb, qlo, qnorm, (float*)nullptr);
+    hipLaunchKernelGGL((k_rows_to_half<IP_KIND_F16, true>), dim3((p.nq_pad + 3) / 4), dim3(256), 0, st, q_f32, (int64_t)nq, d,
+                       (const float*)nullptr, 1.f, qb, qlo, qnorm, (float*)nullptr, (int64_t)p.nq_pad, counts, n_count);
   else
-    hipLaunchKernelGGL((k_rows_to_half<IP_KIND_BF16, false>), dim3((nq + 3) / 4), dim3(256), 0, st, q_f32, (int64_t)nq, d,
-                       (const float*)nullptr, 1.f, qb, qlo, qnorm, (float*)nullptr);
+    hipLaunchKernelGGL((k_rows_to_half<IP_KIND_BF16, false>), dim3((p.nq_pad + 3) / 4), dim3(256), 0, st, q_f32, (int64_t)nq, d,
+                       (const float*)nullptr, 1.f, qb, qlo, qnorm, (float*)nullptr, (int64_t)p.nq_pad, counts, n_count);
   CONVDR_CHECK_LAUNCH("k_rows_to_half(Q)");
 
   if (n == 0) {

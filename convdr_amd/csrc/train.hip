@@ -282,13 +282,19 @@ static int wgrad_launch(const WgradItem* it, int count, int64_t rows, float* sla
     ordered = nsplit > 1;
     if (!ordered) nsplit = 1;
   }
+  // the operand windows are addressed with 32-bit byte offsets (buffer descriptors): a contraction slice must stay below
+  // 2 GiB -- very long row counts are cut into more slab slices by themselves (when there is a slab to hold them)
+  int64_t max_ld = 0;
+  for (int i = 0; i < count; ++i) max_ld = std::max(max_ld, std::max(it[i].ld_x, it[i].ld_dy));
+  const int64_t window_steps = (((int64_t)1 << 31) - 1) / (64 * max_ld * 2);
+  if (window_steps >= 1 && steps > window_steps * nsplit && slab) {
+    const int need = (int)ceil_div64(steps, window_steps);
+    if ((size_t)need * elems <= slab_elems) { nsplit = need; ordered = false; }
+  }
   g.steps_per_split = (steps + nsplit - 1) / nsplit;
   if (g.steps_per_split < 1) g.steps_per_split = 1;
   nsplit = steps > 0 ? (steps + g.steps_per_split - 1) / g.steps_per_split : 1;
   g.nsplit = nsplit;
-  // the operand windows are addressed with 32-bit byte offsets (buffer descriptors): a slice must stay below 2 GiB
-  int64_t max_ld = 0;
-  for (int i = 0; i < count; ++i) max_ld = std::max(max_ld, std::max(it[i].ld_x, it[i].ld_dy));
   CONVDR_REQUIRE((int64_t)g.steps_per_split * 64 * max_ld * 2 < ((int64_t)1 << 31),
                  "wgrad: a contraction slice of %d x 64 rows x %lld columns exceeds the 2 GiB operand window (pass a slab so "
                  "that it can be split)", g.steps_per_split, (long long)max_ld);

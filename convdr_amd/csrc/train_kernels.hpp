@@ -441,7 +441,9 @@ __global__ void __launch_bounds__(256) k_embed_bwd(const float* __restrict__ dX,
                                                    float eps, float* __restrict__ d_word, float* __restrict__ d_pos,
                                                    float* __restrict__ part, const DropSite drop) {
   __shared__ float red[4][3][1024];
-  __shared__ float stage[4][1024];
+  // the wave-private staging strip of the atomics lives in the wave's own slice of `red`, which is written only after the
+  // row loop (the two arrays together were exactly the 64 KB static-LDS limit)
+  float* const stage_w = &red[threadIdx.x >> 6][0][0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 ag[4], ab[4], at[4];
 #pragma unroll
@@ -503,7 +505,7 @@ __global__ void __launch_bounds__(256) k_embed_bwd(const float* __restrict__ dX,
         o.z = rstd * (d[j].z - m1 - y[j].z * m2);
         o.w = rstd * (d[j].w - m1 - y[j].w * m2);
         at[j].x += o.x; at[j].y += o.y; at[j].z += o.z; at[j].w += o.w;
-        *(float4*)&stage[wave][e0] = o;
+        *(float4*)&stage_w[e0] = o;
       }
     }
     // one atomic instruction = 64 consecutive floats (two whole 128-byte lines), not 64 floats 16 bytes apart (eight
@@ -512,7 +514,7 @@ __global__ void __launch_bounds__(256) k_embed_bwd(const float* __restrict__ dX,
     float* dw = d_word + (int64_t)id * H;
     float* dp = d_pos + (int64_t)pp * H;
     for (int e = lane; e < H; e += 64) {
-      const float o = stage[wave][e];
+      const float o = stage_w[e];
       atomicAdd(dw + e, o);
       atomicAdd(dp + e, o);
     }

@@ -171,7 +171,12 @@ class EncoderTower(nn.Module):
         cache = self.__dict__.get("_plist")
         if cache is not None:
             ps, owners = cache
-            if not all(d.get(k) is p for p, (d, k) in zip(ps, owners)) or sum(len(m._parameters) for m in self.__dict__["_pmods"]) != len(ps):
+            # (non-None entries only: nn.Linear(bias=False) or register_parameter(name, None) leave None entries behind, which
+            #  the list never contained -- counting them rebuilt the list on every call.  A sub-MODULE added after the list was
+            #  built is not seen here -- re-walking the tree per forward is the 0.2 ms this cache exists to save; code that
+            #  grafts modules onto a tower calls invalidate_packed(), like resize_token_embeddings does)
+            live = sum(1 for m in self.__dict__["_pmods"] for p in m._parameters.values() if p is not None)
+            if not all(d.get(k) is p for p, (d, k) in zip(ps, owners)) or live != len(ps):
                 cache = None
         if cache is None:
             ps, owners, mods = [], [], []
@@ -191,6 +196,7 @@ class EncoderTower(nn.Module):
         self._packed = None
         self._packed_key = None
         self.__dict__.pop("_packed_t", None)
+        self.__dict__.pop("_plist", None)
 
     def fused_update_target(self, P):
         """(bf16 copy, first arena element it covers) when the packed weights of this tower are views of the flat arena

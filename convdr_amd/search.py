@@ -337,7 +337,12 @@ class FlatIPIndex:
 
     def search_device(self, q, k, tau_in=None, cap=None, x3=None):
         """One enqueue of the kernel pipeline; q is a device fp32 [nq, d] tensor.
-        Returns device tensors (D, I, status, tau_retry); no sync."""
+        Returns device tensors (D, I, status, tau_retry); no sync.
+        status (per query): 0 = certified exact; 1 / 2 / 3 = not certified, re-run with tau_retry (search_tensors walks that
+        ladder); 4 = CONVDR_IP_RANGE, fp16 rungs only: the scan copy was built with a scale that later, longer rows (or an
+        astronomically long query) overflow -- D / I of such a query are NOT usable, and no retry with another threshold
+        helps: call ``_rebuild_scaled()`` (search_tensors / search_finish do) and search again.  Callers that take one
+        uncertified pass (search_sharded_device(certify=False), the C ABI) must treat any non-zero status as "no result"."""
         import torch
         L = _lib.lib()
         cap = cap or self.cap

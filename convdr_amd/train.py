@@ -18,6 +18,7 @@ regenerates the masks from it; parity tests replay the same seed through the ora
 """
 import ctypes as C
 import math
+import os
 import weakref
 
 import numpy as np
@@ -182,6 +183,7 @@ def _take_workspace(tower, need, dev):
 
 
 _PIN_RINGS = {}
+_PIN_CAPTURED = []     # pinned sources of copies recorded into a hipGraph (see _pinned_upload)
 _PIN_SLOTS = 32
 
 
@@ -195,20 +197,28 @@ def _pinned_upload(arr, dev):
     ring = _PIN_RINGS.get(cls)
     if ring is None:
         ring = _PIN_RINGS[cls] = {"buf": torch.empty((_PIN_SLOTS, cls), dtype=torch.uint8).pin_memory(), "ev": [None] * _PIN_SLOTS, "next": 0}
+    dev = torch.device(dev)
+    if torch.cuda.is_current_stream_capturing():
+        # A captured copy node reads its pinned source at every REPLAY: it must not be a ring slot that later uploads
+        # overwrite.  The capture gets a buffer of its own, kept alive for the life of the process (graphs are few).
+        host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()[:nbytes].view(torch.from_numpy(arr).dtype).view(arr.shape)
+        _PIN_CAPTURED.append(host)
+        host.copy_(torch.from_numpy(arr))
+        with torch.cuda.device(dev):
+            return host.to(dev, non_blocking=True)
     i = ring["next"]
     ring["next"] = (i + 1) % _PIN_SLOTS
-    capturing = torch.cuda.is_current_stream_capturing()
-    if ring["ev"][i] is not None and not capturing:
+    if ring["ev"][i] is not None:
         ring["ev"][i].synchronize()
     host = ring["buf"][i, :nbytes].view(torch.from_numpy(arr).dtype).view(arr.shape)
     host.copy_(torch.from_numpy(arr))
-    out = host.to(dev, non_blocking=True)
-    if not capturing:
+    # the slot's guard event is recorded on the stream the copy was issued on: the current stream OF THE TARGET DEVICE (not
+    # of whatever device happens to be current in the calling thread)
+    with torch.cuda.device(dev):
+        out = host.to(dev, non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record()
-        ring["ev"][i] = ev
-    else:
-        ring["ev"][i] = None
+        ev.record(torch.cuda.current_stream(dev))
+    ring["ev"][i] = ev
     return out
 
 
@@ -875,9 +885,6 @@ def _aux_streams(device):
     try:
         big = torch.empty(64 << 20, dtype=torch.float32, device=device).zero_()       # 4 x 0.5 GB of traffic: ~0.4 ms
         small = torch.zeros(256, dtype=torch.float32, device=device)
-        import os
-        for _ in range(int(os.environ.get("CONVDR_AUX_SKIP", "0"))):
-            tried.append(torch.cuda.Stream(device=device))
         for _ in range(12):
             cand = torch.cuda.Stream(device=device)
             tried.append(cand)

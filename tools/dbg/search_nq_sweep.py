@@ -8,7 +8,7 @@ n, d, k = 1_000_000, 768, 100
 dev = torch.device("cuda")
 P = torch.randn(n, d, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
 idx = FlatIPIndex(d, device=dev); idx.add(P); del P
-for nq in (1, 16, 64, 100, 128, 250, 500, 1000, 2000):
+for nq in [int(x) for x in os.environ.get('NQS', '1,16,64,100,128,250,500,1000,2000').split(',')]:
     Q = torch.randn(nq, d, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
     for _ in range(3):
         out = idx.search_device(Q, k)
@@ -22,7 +22,8 @@ for nq in (1, 16, 64, 100, 128, 250, 500, 1000, 2000):
     ms = t0.elapsed_time(t1) / 10
     scan = _lib.prof_collect("ip_scan_emit")
     resc = _lib.prof_collect("ip_rescore")
+    other = {nm: _lib.prof_collect(nm) for nm in ("ip_scan_sample", "ip_cut", "ip_select")}
     bad = int((out[2] != 0).sum())
     print("nq=%5d  search %.3f ms  scan %.3f ms (%.2f TB/s bf16 stream, %.0f TFLOP/s)  rescore %.3f  uncertified %d" % (
         nq, ms, scan[0] / max(scan[1], 1), n * d * 2 / (scan[0] / max(scan[1], 1)) / 1e9, 2.0 * nq * n * d / (scan[0] / max(scan[1], 1)) / 1e9,
-        resc[0] / max(resc[1], 1), bad), flush=True)
+        resc[0] / max(resc[1], 1), bad) + "  " + " ".join("%s %.3f" % (nm.replace("ip_", ""), v[0] / max(v[1], 1)) for nm, v in other.items()), flush=True)
