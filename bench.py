@@ -819,7 +819,7 @@ def main():
     roof["power"] = _power_state()
     try:
         kname = "k_gemm<8, convdr::TileCfg<2, 4, 4, 2>"      # EPI_GELU_BLK on 256 x 256 tiles (k_gemm<1, ..> before round 3)
-        rnd = "r03" if os.path.exists(os.path.join(ROOT, "profiles", "r03_bench_default.kernel_stats.txt")) else "r02"
+        rnd = next((r for r in ("r04", "r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r + "_bench_default.kernel_stats.txt"))), "r02")
         if EB * SL == 262144:
             for ln in open(os.path.join(ROOT, "profiles", rnd + "_bench_default.kernel_stats.txt")):
                 if kname in ln:
