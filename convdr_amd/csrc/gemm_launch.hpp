@@ -79,10 +79,10 @@ inline int launch_gemm(GemmArgs a, hipStream_t st, const char* prof_name) {
   static const int min256 = getenv("CONVDR_TILE256_MIN_TILES") ? atoi(getenv("CONVDR_TILE256_MIN_TILES")) : 192;   // A/B knob
   constexpr bool WIDE_OK = EPI == EPI_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU_SAVE || EPI == EPI_GELU_BF16 || EPI == EPI_F32;
   int choice = (fits && tiles256 >= min256) ? 256 : 128;
-  if (fits && WIDE_OK && !force128) {
-    if (g_gemm_tile_policy == 1) choice = 256;
-    else if (g_gemm_tile_policy == 2) choice = 192;
-    else if (g_gemm_tile_policy == 3) choice = 128;
+  if (fits && !force128 && g_gemm_tile_policy == 1) choice = 256;
+  else if (fits && !force128 && g_gemm_tile_policy == 3) choice = 128;
+  else if (fits && WIDE_OK && !force128) {
+    if (g_gemm_tile_policy == 2) choice = 192;
     else {
       const int nk = (EPI == EPI_SLAB_F32 && a.k_split_len ? a.k_split_len : a.K) / GEMM_BK;
       const int64_t tilesW = (int64_t)(a.N / 256) * ceil_div64(a.rows, 128) * splits;
