@@ -944,12 +944,7 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
     kw_t = {} if target_lens is None else {"seq_lens": target_lens}
     kw_s = {} if concat_lens is None else {"seq_lens": concat_lens}
     with torch.cuda.stream(side), torch.no_grad():
-        big = os.environ.get("CONVDR_TEACHER_BIG_TILES")
-        if big:
-            _lib.lib().convdr_set_option(b"gemm_tile_policy", 1)
         teacher_embs = teacher_model(target_ids, target_id_mask, **kw_t).detach()
-        if big:
-            _lib.lib().convdr_set_option(b"gemm_tile_policy", 0)
     embs = model(concat_ids, concat_id_mask, **kw_s)
     main.wait_stream(side)
     teacher_embs.record_stream(main)
