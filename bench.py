@@ -45,6 +45,43 @@ def _init_group(dev):
         dist.init_process_group(backend)
 
 
+def live_traffic(kname, timeout=240):
+    """HBM-side bytes per launch of the roofline kernel measured IN THIS RUN: two child passes of this script (one step, no
+    extras) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only: MI355X_MICROARCH.md,
+    HBM section), averaged over the kernel's dispatches.  None when rocprofv3 is not there or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        td = tempfile.mkdtemp(prefix="convdr_pmc_")
+        try:
+            subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", td, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                            "--steps", "1", "--warmup", "0", "--passages", "65536", "--queries", "64", "--no-cpu-baseline", "--no-extras"],
+                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=timeout, check=True)
+            tot, cnt = 0.0, 0
+            for path in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if kname in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                            tot += float(row["Counter_Value"])
+                            cnt += 1
+            if not cnt:
+                return None
+            got[ctr] = (tot / cnt, cnt)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    return got
+
+
 def _power_state():
     """What rocm-smi shows an ordinary user about the power state of device 0 (None when unreadable)."""
     import subprocess
@@ -816,7 +853,7 @@ def main():
         roof["clock_source"] = "s_memtime / s_memrealtime stamps of workgroup 0 of the last timed FFN1 launch"
         roof["peak_at_delivered_clock"] = MFMA_BF16_PEAK_TFLOPS * clock_mhz / 2400.0
         roof["frac_at_delivered_clock"] = dom_tf / roof["peak_at_delivered_clock"]
-    roof["power"] = _power_state()
+    roof["power"] = _power_state() if not args.no_extras else None     # (not in the profiler's child passes: rocm-smi is an exec)
     try:
         kname = "k_gemm<8, convdr::TileCfg<2, 4, 4, 2>"      # EPI_GELU_BLK on 256 x 256 tiles (k_gemm<1, ..> before round 3)
         rnd = next((r for r in ("r04", "r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r + "_bench_default.kernel_stats.txt"))), "r02")
@@ -839,6 +876,16 @@ def main():
                                             % (rnd, rows * H * 2 + rows * I * 2 + H * I * 2))
     except Exception:
         pass
+    if world == 1 and not dist_on and not args.no_extras and EB * SL == 262144:
+        # the roofline kernel's traffic, measured in this run (the committed PMC figure above stays beside it)
+        lt = live_traffic("k_gemm<8, convdr::TileCfg<2, 4, 4, 2>")
+        if lt is not None:
+            if roof.get("traffic") is not None:
+                roof["traffic_committed_run"] = roof["traffic"]
+            roof["traffic"] = (2.0 * lt["FETCH_SIZE"][0] + lt["WRITE_SIZE"][0]) * 1024.0
+            roof["traffic_source"] = ("measured in this run: child passes of this script under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                                      "(separate passes, %d dispatches each); FETCH_SIZE doubled and both in KB per MI355X_MICROARCH.md" % lt["FETCH_SIZE"][1])
+            roof["traffic_over_algorithmic"] = roof["traffic"] / float(rows * H * 2 + rows * I * 2 + H * I * 2)
     if world == 1 and not dist_on and not args.no_extras:
         try:
             line.update(extras(dev, index, model, tower, head, building, min(slots, args.steps + args.warmup) * EB, nq, k, d, Q))
