@@ -775,7 +775,9 @@ def main():
     sync_all()
     # workgroup 0 of every FFN1 launch stamps {s_memtime, s_memrealtime} at its start and end: the shader clock the roofline
     # kernel actually ran at in this run (the part is power-managed; boxes of the pool differ by 4-5 % on identical code)
-    clock_probe = torch.zeros(4, dtype=torch.int64, device=dev)
+    n_probe = 512
+    clock_probe = torch.zeros((n_probe, 4), dtype=torch.int64, device=dev)
+    _lib.check(L_.convdr_set_option(b"clock_probe_slots", n_probe), "convdr_set_option")
     _lib.check(L_.convdr_set_option(b"clock_probe", clock_probe.data_ptr()), "convdr_set_option")
     L_.convdr_prof_enable(1)
     t0 = time.perf_counter()
@@ -785,7 +787,9 @@ def main():
     el = time.perf_counter() - t0
     L_.convdr_set_option(b"clock_probe", 0)
     cp = clock_probe.cpu().numpy().astype(np.float64)
-    clock_mhz = float((cp[2] - cp[0]) / ((cp[3] - cp[1]) / 100.0)) if cp[3] > cp[1] else None   # s_memrealtime: 100 MHz
+    cp = cp[cp[:, 3] > cp[:, 1]]                                 # the slots that were written (one per timed FFN1 launch)
+    mhz = (cp[:, 2] - cp[:, 0]) / ((cp[:, 3] - cp[:, 1]) / 100.0) if len(cp) else np.zeros(0)      # s_memrealtime: 100 MHz
+    clock_mhz = float(np.median(mhz)) if len(mhz) else None
     status_bad = int((out[2] != 0).sum().item()) if out[2] is not None else 0    # (after certification: always 0)
     first_pass_retries = retried[0]
     emitted, band = (t.float().mean().item() for t in index.last_counts(nq, k))
@@ -850,7 +854,8 @@ def main():
         # the same fraction against the matrix peak AT THE CLOCK THE KERNEL RAN AT (datasheet peak x delivered / 2400 MHz):
         # comparable across boxes and power states, where `frac` is not
         roof["clock_mhz_delivered"] = clock_mhz
-        roof["clock_source"] = "s_memtime / s_memrealtime stamps of workgroup 0 of the last timed FFN1 launch"
+        roof["clock_source"] = "s_memtime / s_memrealtime stamps of workgroup 0 of every timed FFN1 launch: median of %d" % len(mhz)
+        roof["clock_mhz_min_max"] = [float(mhz.min()), float(mhz.max())]
         roof["peak_at_delivered_clock"] = MFMA_BF16_PEAK_TFLOPS * clock_mhz / 2400.0
         roof["frac_at_delivered_clock"] = dom_tf / roof["peak_at_delivered_clock"]
     roof["power"] = _power_state() if not args.no_extras else None     # (not in the profiler's child passes: rocm-smi is an exec)

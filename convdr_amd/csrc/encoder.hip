@@ -298,6 +298,11 @@ extern "C" int convdr_set_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "clock_probe") == 0) {   // measurement: device buffer of 4 uint64 for the FFN1 kernel's clock stamps (0 = off)
     g_clock_probe = (void*)(uintptr_t)value;
+    g_clock_probe_next = 0;
+    return 0;
+  }
+  if (strcmp(name, "clock_probe_slots") == 0) {   // number of 4 x uint64 slots behind "clock_probe" (set it first)
+    g_clock_probe_slots = value > 0 ? value : 1;
     return 0;
   }
   if (strcmp(name, "attn_trace") == 0) {

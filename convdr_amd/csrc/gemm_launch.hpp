@@ -10,7 +10,8 @@ namespace convdr {
 inline void* g_gemm_trace = nullptr;
 inline void* g_gemm_trace_ln = nullptr;
 inline void* g_attn_trace = nullptr;
-inline void* g_clock_probe = nullptr;   // convdr_set_option "clock_probe": 4 x uint64 written by workgroup 0 of every FFN1 launch
+inline void* g_clock_probe = nullptr;   // convdr_set_option "clock_probe": [slots][4] uint64, one slot per FFN1 launch (round robin)
+inline int64_t g_clock_probe_slots = 1, g_clock_probe_next = 0;
 
 template <int EPI, class T>
 inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
@@ -31,7 +32,11 @@ inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
 #endif
   static const int trace_epi = getenv("CONVDR_TRACE_EPI") ? atoi(getenv("CONVDR_TRACE_EPI")) : (int)EPI_GELU_BF16;
   a.trace = (EPI == trace_epi) ? (unsigned long long*)g_gemm_trace : nullptr;
-  a.clock_probe = (g_clock_probe && strcmp(prof_name, "gemm_ffn1") == 0) ? (unsigned long long*)g_clock_probe : nullptr;
+  a.clock_probe = nullptr;
+  if (g_clock_probe && strcmp(prof_name, "gemm_ffn1") == 0) {
+    a.clock_probe = (unsigned long long*)g_clock_probe + 4 * (g_clock_probe_next % g_clock_probe_slots);
+    ++g_clock_probe_next;
+  }
   a.nt_out = NT_CTILE && (int64_t)a.rows * a.N * 2 >= ((int64_t)128 << 20);
   a.tilesN = (a.N + T::TR - 1) / T::TR;
   a.tilesT = (int)ceil_div64(a.rows, T::TL);

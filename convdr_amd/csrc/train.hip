@@ -466,9 +466,8 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
       CONVDR_CHECK_LAUNCH("k_attention_train_fwd");
     }
     if (cls_tail) {
-      hipLaunchKernelGGL(k_gather_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, s.ctx, (const float*)nullptr, p.c_ctx, (float*)nullptr);
-      hipLaunchKernelGGL(k_gather_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, s.Xin, (const float*)nullptr, p.c_xin, (float*)nullptr);
-      CONVDR_CHECK_LAUNCH("k_gather_cls");
+      hipLaunchKernelGGL(k_gather_cls2, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, s.ctx, s.Xin, p.c_ctx, p.c_xin);
+      CONVDR_CHECK_LAUNCH("k_gather_cls2");
       const unsigned fin_blocks = (unsigned)ceil_div64((int64_t)B * H / 4, 256);
       int ns = 1;
       if (int e = cls_projection((const bf16_t*)lw->wo, p.c_ctx, B, H, H, p, st, &ns)) return e;
@@ -640,11 +639,10 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       hipLaunchKernelGGL(k_dgelu_colsum, dim3((I + 255) / 256, chunks_c), dim3(256), 0, st, p.c_dHpre, p.c_Hpre, (int64_t)B, I, d.part_b1);
       CONVDR_CHECK_LAUNCH("k_dgelu_colsum");
       // dX1 = dHpre W1 + dY2: the contraction slices are added straight onto the fp32 residual-branch gradient
-      CONVDR_CHECK_HIP(hipMemcpyAsync(p.c_dX1f, p.dcls_y, (size_t)B * H * 4, hipMemcpyDeviceToDevice, st));
       int ns = 1;
       if (int e = cls_projection((const bf16_t*)lt->w1_t, p.c_dHpre, B, H, I, p, st, &ns)) return e;
       hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)ceil_div64((int64_t)B * H / 4, 256)), dim3(256), 0, st, p.c_slab, ns,
-                         (int64_t)B * H, (int64_t)B * H, p.c_dX1f, 1);
+                         (int64_t)B * H, (int64_t)B * H, p.c_dX1f, 0, (const float*)p.dcls_y);
       CONVDR_CHECK_LAUNCH("k_reduce_partials");
       if (int e = ln_bwd_kernel(p.c_dX1f, nullptr, p.c_Y1, B, H, lw->ln1_g, cfg->ln_eps, p.c_dY1, p.c_dYb2, d.part_ln1, &blocks_ln1, st,
                                 dr_att, cu_seqlens))
@@ -654,13 +652,9 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_cls")) return e;
       // d ctx: zero but for the CLS rows; the attention backward below reads the first query tile only.  The Q third of dQKV
       // beyond that tile is never written: zero.  The residual-branch gradient handed to the layer below: likewise.
-      CONVDR_CHECK_HIP(hipMemsetAsync(p.dctx, 0, (size_t)rows * H * 2, st));
-      hipLaunchKernelGGL(k_scatter_cls_bf16, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, p.c_dctx, p.dctx);
-      CONVDR_CHECK_HIP(hipMemsetAsync(d.dQKV, 0, (size_t)rows * 3 * H * 2, st));
       dY1 = cur_f;
-      CONVDR_CHECK_HIP(hipMemsetAsync(dY1, 0, (size_t)rows * H * 4, st));
-      hipLaunchKernelGGL(k_scatter_cls, dim3((B + 3) / 4), dim3(256), 0, st, cu_seqlens, B, H, p.c_dY1, dY1);
-      CONVDR_CHECK_LAUNCH("k_scatter_cls");
+      hipLaunchKernelGGL(k_cls_tail_scatter, dim3(B, 8), dim3(256), 0, st, cu_seqlens, B, H, p.c_dctx, p.dctx, d.dQKV, p.c_dY1, dY1);
+      CONVDR_CHECK_LAUNCH("k_cls_tail_scatter");
     }
     // ---- attention ----
     {

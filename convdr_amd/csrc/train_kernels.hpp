@@ -186,7 +186,9 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
 // out[e] (+)= sum_p part[p * stride + e], p in fixed order (deterministic).  16 bytes per thread, four partials in
 // flight per accumulator chain (the one-load-at-a-time form of round 1 spent its time in dependent L2 round trips).
 __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, int nparts, int64_t stride,
-                                                         int64_t n, float* __restrict__ out, int accumulate) {
+                                                         int64_t n, float* __restrict__ out, int accumulate,
+                                                         const float* __restrict__ addend = nullptr) {
+  // addend (optional, with accumulate = 0): out = addend + sum of the partials
   const int64_t n4 = n >> 2;   // n % 4 == 0 (weight matrices)
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -205,8 +207,8 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict
       const float4 a = *(const float4*)(part + (int64_t)p * stride + 4 * i);
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
-    if (accumulate) {
-      const float4 o = *(const float4*)(out + 4 * i);
+    if (accumulate || addend) {
+      const float4 o = *(const float4*)((accumulate ? out : addend) + 4 * i);
       s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
     }
     *(float4*)(out + 4 * i) = s;
@@ -379,24 +381,41 @@ static __global__ void __launch_bounds__(256) k_cast_drop_f32_bf16(const float* 
   }
 }
 
-// dst[cu[b], :] = src[b, :] for b < B (dst pre-zeroed): scatter CLS-row gradients into a [rows, H] matrix
-__global__ void __launch_bounds__(256) k_scatter_cls(const int32_t* __restrict__ cu, int B, int H,
-                                                     const float* __restrict__ src, float* __restrict__ dst) {
+// Both gathers of the last layer's CLS tail in one launch: ctx_c[b] = ctx[cu[b]], xin_c[b] = xin[cu[b]] (bf16 rows).
+__global__ void __launch_bounds__(256) k_gather_cls2(const int32_t* __restrict__ cu, int B, int H, const bf16_t* __restrict__ a,
+                                                     const bf16_t* __restrict__ b, bf16_t* __restrict__ oa, bf16_t* __restrict__ ob) {
   const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= B) return;
-  const int64_t row = cu[b];
-  for (int e0 = 4 * lane; e0 < H; e0 += 256) *(float4*)(dst + row * H + e0) = *(const float4*)(src + (int64_t)b * H + e0);
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B) return;
+  const int64_t row = cu[i];
+  for (int e0 = 8 * lane; e0 < H; e0 += 512) {
+    *(uint4*)(oa + (int64_t)i * H + e0) = *(const uint4*)(a + row * H + e0);
+    *(uint4*)(ob + (int64_t)i * H + e0) = *(const uint4*)(b + row * H + e0);
+  }
 }
 
-// bf16 form: dst[cu[b], :] = src[b, :] (dst pre-zeroed)
-__global__ void __launch_bounds__(256) k_scatter_cls_bf16(const int32_t* __restrict__ cu, int B, int H,
-                                                          const bf16_t* __restrict__ src, bf16_t* __restrict__ dst) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= B) return;
-  const int64_t row = cu[b];
-  for (int e0 = 8 * lane; e0 < H; e0 += 512) *(uint4*)(dst + row * H + e0) = *(const uint4*)(src + (int64_t)b * H + e0);
+// The hand-over from the last layer's CLS-row backward to the full-size kernels, one launch instead of three memsets and two
+// scatters.  For sequence b (rows [cu[b], cu[b + 1])):
+//   dctx  [rows, H]  bf16: row cu[b] = dctx_c[b]; the other rows the attention backward reads (its first query tile: 128) = 0
+//   dQKV  [rows, 3H] bf16: the Q third of the rows beyond that tile = 0 (the dQ kernel writes only its tile's rows)
+//   G     [rows, H]  fp32: row cu[b] = dY1_c[b], every other row of the sequence = 0 (the residual-branch gradient below)
+// grid (B, 8): the rows of a sequence are dealt to 8 blocks, one wave per row.
+__global__ void __launch_bounds__(256) k_cls_tail_scatter(const int32_t* __restrict__ cu, int B, int H, const bf16_t* __restrict__ dctx_c,
+                                                          bf16_t* __restrict__ dctx, bf16_t* __restrict__ dQKV,
+                                                          const float* __restrict__ dY1_c, float* __restrict__ G) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63;
+  const int64_t base = cu[b], end = cu[b + 1];
+  for (int64_t row = base + blockIdx.y * 4 + (threadIdx.x >> 6); row < end; row += 4 * gridDim.y) {
+    const bool cls = row == base;
+    for (int e0 = 4 * lane; e0 < H; e0 += 256)
+      *(float4*)(G + row * H + e0) = cls ? *(const float4*)(dY1_c + (int64_t)b * H + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < base + 128) {
+      for (int e0 = 8 * lane; e0 < H; e0 += 512)
+        *(uint4*)(dctx + row * H + e0) = cls ? *(const uint4*)(dctx_c + (int64_t)b * H + e0) : make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      for (int e0 = 8 * lane; e0 < H; e0 += 512) *(uint4*)(dQKV + row * 3 * H + e0) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
 }
 
 // Finish of a split-K projection on a few compact rows (the CLS rows of the last layer, training forward):
