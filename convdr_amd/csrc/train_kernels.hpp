@@ -585,7 +585,18 @@ __global__ void __launch_bounds__(1024) k_mse_fwd_bwd(const float* __restrict__ 
   __shared__ float red[16];
   float acc = 0.f;
   const float k = 2.f / (float)n * gscale;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+  // one workgroup (the loss is one scalar): 16-byte accesses, four of them in flight per thread -- the scalar loop was a
+  // 48-deep chain of dependent round trips at the configs[2] size (27 us on the step's critical path)
+  const bool vec = ((((uintptr_t)s) | ((uintptr_t)t) | ((uintptr_t)ds)) & 15) == 0;
+  const int64_t n4 = vec ? (n >> 2) : 0;
+#pragma unroll 4
+  for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+    const float4 a = ((const float4*)s)[i], b = ((const float4*)t)[i];
+    const float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    acc += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    if (ds) ((float4*)ds)[i] = make_float4(k * d.x, k * d.y, k * d.z, k * d.w);
+  }
+  for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += 1024) {
     const float d = s[i] - t[i];
     acc += d * d;
     if (ds) ds[i] = k * d;

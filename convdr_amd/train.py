@@ -848,55 +848,59 @@ def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_st
 _SIDE_STREAMS = {}
 
 
-def _runs_beside(main, cand, big, small):
-    """Do `main` and `cand` run concurrently -- in BOTH directions: a short kernel on one stream, enqueued after a long one
-    on the other, must finish while the long one is still running?  Two streams that share a hardware queue fail at least
-    one direction (a kernel with the barrier bit waits for everything queued before it, whichever stream it came from)."""
-    def one(long_s, short_s):
-        e0, el, es = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        e0.record(long_s)
-        with torch.cuda.stream(long_s):
-            for _ in range(4):
+def _fork_join_time(main, side, big, small):
+    """Wall time (us) of a miniature of the backward's stream pattern: four times { the main stream forks `side` off with an
+    event, `side` runs one long kernel, the main stream five short dependent ones }, then a join.  Streams that HIP has put
+    on hardware queues that serialise against each other take ~16 % longer (1.15 vs 0.98 ms) -- and this, unlike a plain
+    "does a short kernel overtake a long one" test, separates exactly the stream choices with which the real step loses its
+    overlap (tools/dbg/stream_proxy_probe.py)."""
+    import time
+    best = None
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for blk in range(4):
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
                 big.mul_(1.0)
-            el.record(long_s)
-        with torch.cuda.stream(short_s):
-            short_s.wait_event(e0)
-            small.add_(1.0)
-            small.add_(1.0)          # (a dependent pair: the second one carries the in-stream ordering)
-            es.record(short_s)
-        el.synchronize()
-        es.synchronize()
-        return e0.elapsed_time(es) < 0.5 * e0.elapsed_time(el)
-    return one(main, cand) and one(cand, main)
+            for _ in range(5):
+                small.mul_(1.0)
+        fin = torch.cuda.Event()
+        fin.record(side)
+        main.wait_event(fin)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) * 1e6
+        if rep and (best is None or dt < best):
+            best = dt
+    return best
 
 
 def _aux_streams(device):
     """(A, B): the stream of the frozen teacher's forward / weight packing / per-layer gradient norms, and the stream of the
-    backward's weight-gradient branches -- both VERIFIED to run beside the current stream.  HIP multiplexes all streams of
-    a process onto GPU_MAX_HW_QUEUES = 4 hardware queues in order of first use; a side stream that lands on the main
-    stream's queue serialises with it, and the configs[2] step measured 10.7 .. 12.4 ms depending on nothing but how many
-    streams the process had used before (tools/dbg/stream_queue_probe.py; extra priorities or more queues are worse:
-    17-19 ms).  So the first training step of a process tries streams of torch's pool until two pass the test."""
+    backward's weight-gradient branches.  HIP multiplexes all streams of a process onto GPU_MAX_HW_QUEUES = 4 hardware
+    queues in order of first use, and some pairs of queues serialise against each other: the configs[2] step measured
+    10.3 .. 12.4 ms depending on nothing but how many streams the process had used before, and 1 stand-alone run in ~6 drew
+    a bad pair (tools/dbg/stream_queue_probe.py; extra priorities, CU masks or more queues are far worse: 17-31 ms).  So
+    the first training step of a process times a miniature of the backward's fork / join pattern on six streams of torch's
+    pool (~25 ms, once) and keeps the two fastest."""
     key = (device.type, device.index)
     if key in _SIDE_STREAMS:
         return _SIDE_STREAMS[key]
     main = torch.cuda.current_stream(device)
-    picked, tried = [], []
+    cands = [torch.cuda.Stream(device=device) for _ in range(6)]
+    picked = cands[:2]
     try:
-        big = torch.empty(64 << 20, dtype=torch.float32, device=device).zero_()       # 4 x 0.5 GB of traffic: ~0.4 ms
-        small = torch.zeros(256, dtype=torch.float32, device=device)
-        for _ in range(12):
-            cand = torch.cuda.Stream(device=device)
-            tried.append(cand)
-            if _runs_beside(main, cand, big, small) and all(cand.cuda_stream != p.cuda_stream for p in picked):
-                picked.append(cand)
-                if len(picked) == 2:
-                    break
-        del big, small
+        with torch.cuda.device(device):
+            big = torch.zeros(128 << 20, dtype=torch.float32, device=device)       # one pass: ~250 us
+            small = torch.zeros(16 << 20, dtype=torch.float32, device=device)      # one pass: ~30 us
+            scored = sorted(((_fork_join_time(main, c, big, small), i) for i, c in enumerate(cands)))
+            picked = [cands[i] for _, i in scored[:2]]
+            _SIDE_STREAMS[(key, "scores")] = [round(t) for t, _ in scored]
+            del big, small
     except Exception:
         pass
-    while len(picked) < 2:
-        picked.append(tried[len(picked)] if len(tried) > len(picked) else torch.cuda.Stream(device=device))
     with torch.cuda.device(device):
         try:
             _lib.check(_lib.lib().convdr_train_set_side_stream(C.c_void_p(picked[1].cuda_stream)), "convdr_train_set_side_stream")

@@ -20,7 +20,7 @@ if len(sys.argv) > 1:
     from convdr_amd import train as TR
     aux = TR._aux_streams(dev)
     print("streams used before: %d -> %.3f ms/step | " % (k, d["ms_per_step"]) + " ".join("%s %.2f" % (n.replace("gemm_", ""), kk[n]["ms_per_step"]) for n in kk)
-          + " | aux streams %x %x" % (aux[0].cuda_stream, aux[1].cuda_stream), flush=True)
+          + " | aux scores %s" % TR._SIDE_STREAMS.get((("cuda", 0), "scores")), flush=True)
 else:
-    for k in [int(x) for x in os.environ.get('KS', '0,4,5,6,7').split(',')]:
+    for k in [int(x) for x in os.environ.get('KS', '0,4,5,6,7,5,6,0').split(',')]:
         subprocess.run([sys.executable, os.path.abspath(__file__), str(k)], stderr=subprocess.DEVNULL)
