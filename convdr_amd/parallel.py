@@ -219,7 +219,10 @@ class DataParallelStudent:
             L = _lib.lib()
             cur = torch.cuda.current_stream(flat.device)
             if getattr(self, "_comm", None) is None:
-                self._comm = torch.cuda.Stream(device=flat.device)
+                # a stream that has been seen to run beside the compute stream (train._aux_streams: HIP's stream -> hardware
+                # queue multiplexing decides whether the collectives overlap the backward or serialise with it)
+                from .train import _aux_streams
+                self._comm = _aux_streams(flat.device)[2]
             comm, works = self._comm, []
             with torch.cuda.device(flat.device), torch.cuda.stream(comm):
                 for l in reversed(range(len(buckets))):

@@ -890,13 +890,13 @@ def _aux_streams(device):
         return _SIDE_STREAMS[key]
     main = torch.cuda.current_stream(device)
     cands = [torch.cuda.Stream(device=device) for _ in range(6)]
-    picked = cands[:2]
+    picked = cands[:3]
     try:
         with torch.cuda.device(device):
             big = torch.zeros(128 << 20, dtype=torch.float32, device=device)       # one pass: ~250 us
             small = torch.zeros(16 << 20, dtype=torch.float32, device=device)      # one pass: ~30 us
             scored = sorted(((_fork_join_time(main, c, big, small), i) for i, c in enumerate(cands)))
-            picked = [cands[i] for _, i in scored[:2]]
+            picked = [cands[i] for _, i in scored[:3]]     # (the third: the gradient all-reduce stream of parallel.py)
             _SIDE_STREAMS[(key, "scores")] = [round(t) for t, _ in scored]
             del big, small
     except Exception:
