@@ -183,8 +183,9 @@ def _take_workspace(tower, need, dev):
 
 
 _PIN_RINGS = {}
-_PIN_CAPTURED = []     # pinned sources of copies recorded into a hipGraph (see _pinned_upload)
+_PIN_CAPTURED = object()     # marks a ring slot that a captured copy node reads at every replay (see _pinned_upload)
 _PIN_SLOTS = 32
+_PIN_RETIRED = []
 
 
 def _pinned_upload(arr, dev):
@@ -198,16 +199,27 @@ def _pinned_upload(arr, dev):
     if ring is None:
         ring = _PIN_RINGS[cls] = {"buf": torch.empty((_PIN_SLOTS, cls), dtype=torch.uint8).pin_memory(), "ev": [None] * _PIN_SLOTS, "next": 0}
     dev = torch.device(dev)
-    if torch.cuda.is_current_stream_capturing():
-        # A captured copy node reads its pinned source at every REPLAY: it must not be a ring slot that later uploads
-        # overwrite.  The capture gets a buffer of its own, kept alive for the life of the process (graphs are few).
-        host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()[:nbytes].view(torch.from_numpy(arr).dtype).view(arr.shape)
-        _PIN_CAPTURED.append(host)
+    capturing = torch.cuda.is_current_stream_capturing()
+    # A captured copy node reads its pinned source at every REPLAY: the slot it took must never be handed out again.  It is
+    # marked as owned by the capture (pinning a fresh buffer here is not an option: host allocations are illegal while a
+    # stream captures); a ring whose slots have all gone that way is replaced -- outside a capture -- by a fresh one.
+    for _ in range(_PIN_SLOTS):
+        i = ring["next"]
+        ring["next"] = (i + 1) % _PIN_SLOTS
+        if ring["ev"][i] is not _PIN_CAPTURED:
+            break
+    else:
+        if capturing:
+            raise RuntimeError("_pinned_upload: every staging slot of this size belongs to a captured graph")
+        _PIN_RETIRED.append(ring)       # (its slots are still read by the graphs that captured them)
+        ring = _PIN_RINGS[cls] = {"buf": torch.empty((_PIN_SLOTS, cls), dtype=torch.uint8).pin_memory(), "ev": [None] * _PIN_SLOTS, "next": 1}
+        i = 0
+    if capturing:
+        ring["ev"][i] = _PIN_CAPTURED
+        host = ring["buf"][i, :nbytes].view(torch.from_numpy(arr).dtype).view(arr.shape)
         host.copy_(torch.from_numpy(arr))
         with torch.cuda.device(dev):
             return host.to(dev, non_blocking=True)
-    i = ring["next"]
-    ring["next"] = (i + 1) % _PIN_SLOTS
     if ring["ev"][i] is not None:
         ring["ev"][i].synchronize()
     host = ring["buf"][i, :nbytes].view(torch.from_numpy(arr).dtype).view(arr.shape)
