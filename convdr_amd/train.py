@@ -335,19 +335,21 @@ class _EncoderFn(torch.autograd.Function):
             ent, token = _take_workspace(tower, need, dev)
             ws = ent.ws
             drop = None if dropout is None else C.byref(_lib.Dropout(float(dropout[0]), float(dropout[1]), int(dropout[2]) & 0xffffffff))
+            # the transposed weight copies are needed by the backward only: pack them on the side stream, under this
+            # forward (0.6 ms of small transposes per step that would otherwise sit in front of the backward).  The side
+            # stream forks off BEFORE the forward is enqueued -- the weights are final in stream order here; forking after it
+            # (rounds 2-4) made the packing wait for the whole forward and the loss wait for the packing: 0.08 ms per step
+            main = torch.cuda.current_stream()
+            side = _side_stream(dev)
+            side.wait_event(main.record_event())
             _lib.check(L_.convdr_encoder_train_forward(C.byref(c), C.byref(w), _lib.ptr(ids), 0, _lib.ptr(mask), B, L,
                                                        _lib.ptr(cu), _lib.ptr(seq_lens_dev), rows, max_len, _lib.ptr(ws),
                                                        ws.numel(), _lib.ptr(out), drop, _lib.stream_ptr()),
                        "convdr_encoder_train_forward")
             _status_post(tower, ws)
-            # the transposed weight copies are needed by the backward only: pack them on the side stream, under this
-            # forward (0.6 ms of small transposes per step that would otherwise sit in front of the backward)
-            main = torch.cuda.current_stream()
-            side = _side_stream(dev)
             # the zeroed gradient arena of this forward's backward (0.5 GB for roberta-base: a 64 us fill that used to be the
             # first thing on the backward's critical path): allocated here, zeroed on the side stream under the forward
             ctx.grad_arena = torch.empty(sum(int(np.prod(p.shape)) for p in params), dtype=torch.float32, device=dev)
-            side.wait_stream(main)
             with torch.cuda.stream(side):
                 ctx.packed_t = _packed_t(tower, head)
                 ctx.grad_arena.zero_()
