@@ -917,7 +917,7 @@ def _aux_streams(device):
             small = torch.zeros(16 << 20, dtype=torch.float32, device=device)      # one pass: ~30 us
             scored = sorted(((_fork_join_time(main, c, big, small), i) for i, c in enumerate(cands)))
             picked = [cands[i] for _, i in scored[:3]]     # (the third: the gradient all-reduce stream of parallel.py)
-            _SIDE_STREAMS[(key, "scores")] = [round(t) for t, _ in scored]
+            _SIDE_STREAMS[(key, "scores")] = [(round(t), i) for t, i in scored]     # (us, candidate): diagnostics
             del big, small
     except Exception:
         pass
