@@ -120,11 +120,29 @@ struct AttnTrainArgs {
   float* lse;          // [heads, ldt]: log2 of the softmax denominator, log2(sum_k exp(s_k * scale)) (base 2: the backward's exp2 argument)
   int64_t ldt;
   float scale;
+  const int32_t* order;   // [B] or null: workgroup z works on sequence order[z] (k_len_order: longest first)
 };
+
+// Dispatch order of the attention kernels of a training step: sequences in descending length (ties: ascending index).
+// A ragged batch (configs[2]: 32 .. 256 tokens) gives these kernels workgroups of 1 .. 4 tiles x 1 .. 8 waves of work, three
+// rounds of them per CU; in batch order the last round is whatever the collate function put last, and the kernel ends
+// with a few CUs finishing 256-token sequences while the rest idle: heaviest first measured -18 % on the backward and
+// -8 % on the forward kernel (timing experiment with a sorted batch, round 4).  One thread per sequence, O(B) each.
+static __global__ void __launch_bounds__(256) k_len_order(const int32_t* __restrict__ lens, int B, int32_t* __restrict__ order) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const int mine = lens[b];
+  int rank = 0;
+  for (int j = 0; j < B; ++j) {
+    const int o = lens[j];
+    rank += (o > mine) | ((o == mine) & (j < b));
+  }
+  order[rank] = b;
+}
 
 static __global__ void __launch_bounds__(256, 3) k_attention_train_fwd(const AttnTrainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K tile | V tile)
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
   const int len = a.lens[b];
   const int q0 = blockIdx.x * 128;
   if (q0 >= len) return;
@@ -273,6 +291,7 @@ struct AttnBwdArgs {
   DropSite drop;       // attention-probability dropout of the forward (thresh 0 = off)
   int q_limit;         // dK / dV kernel: > 0 = only the first q_limit queries of a sequence carry gradient (last layer: the
                        // CLS query; a multiple of 64): the query loop stops there
+  const int32_t* order;   // [B] or null: workgroup z works on sequence order[z] (k_len_order: longest first)
 };
 
 constexpr int ATTB_DQ_SMEM = 2 * 2 * ATT_TILE;            // two sets of (K tile | V tile)
@@ -287,7 +306,7 @@ constexpr int ATTB_DKV_SMEM = 2 * (2 * ATT_TILE + 512);   // two sets of (Q tile
 // spills cost.
 static __global__ void __launch_bounds__(256, 2) k_attention_bwd_dq(const AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
   const int len = a.lens[b];
   const int q0 = blockIdx.x * 128;
   if (q0 >= len) return;
@@ -423,7 +442,7 @@ static __global__ void __launch_bounds__(256, 2) k_attention_bwd_dq(const AttnBw
 static __global__ void __launch_bounds__(256, 2) k_attention_bwd_dkv(const AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int SET = 2 * ATT_TILE + 512;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
   const int len = a.lens[b];
   const int k0 = blockIdx.x * 128;
   if (k0 >= len) return;
@@ -577,6 +596,267 @@ static __global__ void __launch_bounds__(256, 2) k_attention_bwd_dkv(const AttnB
   {
     const float keep = key < len ? 1.f : 0.f;
     const int r0 = key - (lane & 31);
+    attn_park_store(smem + wave * 4096, dk, keep, lane, a.dQKV + (base + r0) * H3 + H + h * 64, H3, plen - r0);
+    attn_park_store(smem + wave * 4096, dv, keep, lane, a.dQKV + (base + r0) * H3 + 2 * H + h * 64, H3, plen - r0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dQ, dK and dV of one (sequence, head) in ONE workgroup, for sequences of at most 256 tokens (round 4).
+// The two kernels above each recompute S, P, the dropout mask and dS for every (query, key) pair -- exp2 + hash + the
+// dS arithmetic are what these latency- and VALU-bound kernels spend their time on -- and each pays its own prologue
+// (operand fragments, first tiles) and launch.  Here eight waves own 32 keys each (lane = key, exactly the dK / dV kernel's
+// scheme and arithmetic), loop over 64-query tiles, and additionally park dS (bf16, [key][query], the engine's tile
+// image) in LDS; after a barrier two waves contract it with K^T read from the sequence's K tiles:
+//   dQ^T[d, q] = sum_key K^T[d, key] dS^T[key, q]      (both operands through ds_read_b64_tr_b16)
+// so dQ needs neither a second pass over the scores nor a cross-workgroup reduction (one workgroup sees every key).
+// D[q] = dO[q] . O[q] is computed in the prologue for the whole sequence (two threads per query).
+// The attention backward is ON the step's critical path: a timing-only cut of its work by 0.49 ms shortened the configs[2]
+// step by 0.8 ms (10.30 -> 9.49).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int ATTF_MAX_LEN = 256;
+constexpr int ATTF_SET = 2 * ATT_TILE + 512;          // Q tile | dO tile | 64 LSE (+ pad)
+constexpr int ATTF_K = 2 * ATTF_SET;                  // four K tiles (the sequence's keys)
+constexpr int ATTF_DS = ATTF_K + 4 * ATT_TILE;        // two sets of four dS^T tiles: rows = keys, columns = the 64 queries of a step
+constexpr int ATTF_D = ATTF_DS + 8 * ATT_TILE;        // D of the sequence's queries (256 floats)
+constexpr int ATTF_PARK = ATTF_D + 1024;              // park regions of the two dQ waves
+constexpr int ATTB_FUSED_SMEM = ATTF_PARK + 2 * 4096;
+
+// one 8-row round of a 64-row tile per wave (eight waves: the whole tile)
+__device__ __forceinline__ void attn_stage_rows8(const AttnTileSrc& s, int64_t first_row, uint32_t col_bytes, char* lds, int wave,
+                                                 int lane) {
+  const int r0 = wave * 8;
+  const int row = r0 + (lane >> 3);
+  const uint32_t gch = (uint32_t)((lane & 7) ^ ((row >> 1) & 7));
+  const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)((first_row + r0) * s.rowb) + col_bytes);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds + r0 * 128), 16, s.voff + gch * 16, soff, 0, 0);
+}
+
+static __global__ void __launch_bounds__(512, 1) k_attention_bwd_fused(const AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = a.order ? a.order[blockIdx.y] : (int)blockIdx.y, h = blockIdx.x;
+  const int len = a.lens[b];
+  const int64_t base = a.cu[b];
+  const int plen = a.cu[b + 1] - (int)base;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, li = lane & 31;
+  const int key = wave * 32 + li;
+  const int kc = key < len ? key : len - 1;
+  const bool key_ok = key < len;
+  const int H = a.H, H3 = 3 * a.H;
+  bf16x8 kf[4], vf[4];
+  {
+    const bf16_t* kp = a.QKV + (base + kc) * H3 + H + h * 64 + 8 * hi;
+    const bf16_t* vp = a.QKV + (base + kc) * H3 + 2 * H + h * 64 + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { kf[s] = *(const bf16x8*)(kp + 16 * s); vf[s] = *(const bf16x8*)(vp + 16 * s); }
+  }
+  // D: thread (query = t >> 1, half of the head dimensions = t & 1); the loads are issued here, ahead of the tile DMA, and
+  // consumed behind it
+  bf16x8 dox[4], ox[4];
+  const int qd = threadIdx.x >> 1, dhalf = threadIdx.x & 1;
+  {
+    const int qdc = qd < len ? qd : len - 1;
+    const bf16_t* dp_ = a.dO + (base + qdc) * H + h * 64 + 32 * dhalf;
+    const bf16_t* op_ = a.O + (base + qdc) * H + h * 64 + 32 * dhalf;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { dox[s] = *(const bf16x8*)(dp_ + 8 * s); ox[s] = *(const bf16x8*)(op_ + 8 * s); }
+  }
+  const float c = a.scale * 1.44269504088896341f;
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+  const int qrow = (li & ~12) | ((li & 4) << 1) | ((li & 8) >> 1);
+  const int qsw = (qrow >> 1) & 7;
+  const AttnTileSrc srcQ = attn_tile_src(a.QKV, H3, a.rows, lane);
+  const AttnTileSrc srcO = attn_tile_src(a.dO, H, a.rows, lane);
+  const AttnTileSrc srcL = attn_tile_src((const bf16_t*)a.LSE, 2 * a.ldt, a.heads, lane);
+  const TrLane trl = tr_lane(lane);
+  const uint32_t s0 = lds_off(smem);
+  auto stage = [&](int q0, int buf) {
+    char* set = smem + buf * ATTF_SET;
+    attn_stage_rows8(srcQ, base + q0, (uint32_t)(h * 64 * 2), set, wave, lane);
+    attn_stage_rows8(srcO, base + q0, (uint32_t)(h * 64 * 2), set + ATT_TILE, wave, lane);
+    if (wave == 0) {
+      const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)(((int64_t)h * a.ldt + base + q0) * 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srcL.rsrc, (lptr_t)(set + 2 * ATT_TILE), 4, (uint32_t)lane * 4, soff, 0, 0);
+    }
+  };
+  const int qlen = len;
+  stage(0, 0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (t * 64 < len) attn_stage_rows8(srcQ, base + t * 64, (uint32_t)((H + h * 64) * 2), smem + ATTF_K + t * ATT_TILE, wave, lane);
+  if (qlen > 64) stage(64, 1);
+  const bool active = wave * 32 < len;
+  float* sDall = (float*)(smem + ATTF_D);
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      union { bf16x8 v; uint32_t u[4]; } x, y;
+      x.v = dox[s];
+      y.v = ox[s];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc += __uint_as_float(x.u[j] << 16) * __uint_as_float(y.u[j] << 16) +
+               __uint_as_float(x.u[j] & 0xffff0000u) * __uint_as_float(y.u[j] & 0xffff0000u);
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    if (dhalf == 0) sDall[qd] = acc;
+  }
+  // this wave's 32 rows of the dS^T tiles: written every step by a wave that owns keys, zero for good otherwise (the dQ
+  // contraction runs over whole 64-key tiles)
+  const int ds_row = (wave & 1) * 32 + li;
+  char* ds_rowp = smem + ATTF_DS + (wave >> 1) * ATT_TILE + ds_row * 128;
+  const int ds_sw = (ds_row >> 1) & 7;
+  if (!active) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(uint4*)(ds_rowp + (hi * 4 + i) * 16) = make_uint4(0u, 0u, 0u, 0u);
+      *(uint4*)(ds_rowp + 4 * ATT_TILE + (hi * 4 + i) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  // The dQ contraction of step i runs one step late, on waves 6 and 7, from the other dS^T set: beside step i + 1 of the waves
+  // that own keys (for sequences of at most 192 tokens waves 6 and 7 own none) -- one barrier per step, not two.
+  const bool dq_wave = wave >= 6;
+  const int qb = wave - 6;
+  TrLane trq = trl;   // dS^T fragments of this dQ wave's 32-query block (selected here: a run-time index would put the table in scratch)
+  trq.a[0][0] = qb ? trl.a[1][0] : trl.a[0][0];
+  trq.a[0][1] = qb ? trl.a[1][1] : trl.a[0][1];
+  auto dq_phase = [&](int qs, int set) {
+    f32x16 dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+    for (int t = 0; t * 64 < len; ++t) {
+      const uint32_t tK = s0 + ATTF_K + t * ATT_TILE, tS = s0 + ATTF_DS + (set * 4 + t) * ATT_TILE;
+      TrFrag ka[4][2], sf[4];
+      tr_frag<0>(tK, trl, 0, ka[0][0]);  tr_frag<0>(tK, trl, 1, ka[0][1]);  tr_frag<0>(tS, trq, 0, sf[0]);
+      tr_frag<16>(tK, trl, 0, ka[1][0]); tr_frag<16>(tK, trl, 1, ka[1][1]); tr_frag<16>(tS, trq, 0, sf[1]);
+      tr_frag<32>(tK, trl, 0, ka[2][0]); tr_frag<32>(tK, trl, 1, ka[2][1]); tr_frag<32>(tS, trq, 0, sf[2]);
+      tr_frag<48>(tK, trl, 0, ka[3][0]); tr_frag<48>(tK, trl, 1, ka[3][1]); tr_frag<48>(tS, trq, 0, sf[3]);
+      tr_wait4<0>(ka[0][0], ka[0][1], ka[1][0], ka[1][1]);
+      tr_wait4<0>(ka[2][0], ka[2][1], ka[3][0], ka[3][1]);
+      tr_wait4<0>(sf[0], sf[1], sf[2], sf[3]);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s4][dt].v, sf[s4].v, dq[dt], 0, 0, 0);
+    }
+    const int r0 = qs + 32 * qb;
+    const float keep = r0 + li < len ? 1.f : 0.f;
+    attn_park_store(smem + ATTF_PARK + qb * 4096, dq, keep, lane, a.dQKV + (base + r0) * H3 + h * 64, H3, plen - r0);
+  };
+  int it = 0;
+  for (int q0 = 0; q0 < qlen; q0 += 64, ++it) {
+    const int buf = it & 1;
+    lds_dma_wait_all();
+    __syncthreads();   // tile `it` has landed; dS^T of step it - 1 is complete; the set of step it - 2 is free
+    if (it >= 1 && q0 + 64 < qlen) stage(q0 + 64, buf ^ 1);
+    if (dq_wave && it >= 1) dq_phase(q0 - 64, buf ^ 1);
+    char* const ds_cur = ds_rowp + buf * 4 * ATT_TILE;
+    if (active) {
+      const char* sQ = smem + buf * ATTF_SET;
+      const char* sdO = sQ + ATT_TILE;
+      const float* sLse = (const float*)(sQ + 2 * ATT_TILE);
+      const float* sD = sDall + q0;
+      const uint32_t tQ = s0 + buf * ATTF_SET, tO = tQ + ATT_TILE;
+      const bool ragged = q0 + 64 > len;
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        const char* qp = sQ + (qt * 32 + qrow) * 128;
+        const char* op = sdO + (qt * 32 + qrow) * 128;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int ch = ((2 * s4 + hi) ^ qsw) * 16;
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qp + ch), kf[s4], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(op + ch), vf[s4], dp, 0, 0, 0);
+        }
+        TrFrag of[2][2], qf[2][2];
+        if (qt == 0) {
+          tr_frag<0>(tO, trl, 0, of[0][0]); tr_frag<0>(tO, trl, 1, of[0][1]);
+          tr_frag<0>(tQ, trl, 0, qf[0][0]); tr_frag<0>(tQ, trl, 1, qf[0][1]);
+        } else {
+          tr_frag<32>(tO, trl, 0, of[0][0]); tr_frag<32>(tO, trl, 1, of[0][1]);
+          tr_frag<32>(tQ, trl, 0, qf[0][0]); tr_frag<32>(tQ, trl, 1, qf[0][1]);
+        }
+        float dmask[16];
+        if (a.drop.thresh) {   // (see k_attention_bwd_dkv: one hash per two elements, swapped between the lanes of a key pair)
+          const int odd = key & 1;
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int qi_mine = 32 * qt + 16 * (r >> 3) + 8 * hi + (r & 7) + odd;
+            const uint32_t h_mine = drop_mix32((drop_att_base(base + q0 + qi_mine, a.heads, h) + (uint32_t)(kc >> 1)) ^ a.drop.key);
+            const uint32_t h_other = (uint32_t)__builtin_amdgcn_mov_dpp((int)h_mine, 0xB1, 0xF, 0xF, true);
+            const uint32_t h0 = odd ? h_other : h_mine, h1 = odd ? h_mine : h_other;
+            const uint32_t t0 = odd ? (h0 >> 16) : (h0 & 0xffffu), t1 = odd ? (h1 >> 16) : (h1 & 0xffffu);
+            dmask[r] = t0 >= a.drop.thresh ? a.drop.scale : 0.f;
+            dmask[r + 1] = t1 >= a.drop.thresh ? a.drop.scale : 0.f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qi = 32 * qt + 16 * (r >> 3) + 8 * hi + (r & 7);
+          float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -sLse[qi]));
+          float dpr = dp[r], pd = p;
+          if (a.drop.thresh) {
+            const float m = dmask[r];
+            dpr *= m;
+            pd *= m;
+          }
+          float ds = p * (dpr - sD[qi]) * a.scale;
+          if (ragged) {
+            const bool ok = q0 + qi < len;
+            pd = ok ? pd : 0.f;
+            ds = ok ? ds : 0.f;
+          }
+          s[r] = pd;
+          dp[r] = ds;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int r0 = half * 8;
+          if (half == 0) {
+            if (qt == 0) {
+              tr_frag<16>(tO, trl, 0, of[1][0]); tr_frag<16>(tO, trl, 1, of[1][1]);
+              tr_frag<16>(tQ, trl, 0, qf[1][0]); tr_frag<16>(tQ, trl, 1, qf[1][1]);
+            } else {
+              tr_frag<48>(tO, trl, 0, of[1][0]); tr_frag<48>(tO, trl, 1, of[1][1]);
+              tr_frag<48>(tQ, trl, 0, qf[1][0]); tr_frag<48>(tQ, trl, 1, qf[1][1]);
+            }
+          }
+          union { bf16x8 v; uint32_t u[4]; } pb, sb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            pb.u[j] = pack_bf16x2(s[r0 + 2 * j], s[r0 + 2 * j + 1]);
+            sb.u[j] = pack_bf16x2(dp[r0 + 2 * j], dp[r0 + 2 * j + 1]);
+          }
+          if (half == 0) tr_wait4<8>(of[0][0], of[0][1], qf[0][0], qf[0][1]);
+          else tr_wait4<0>(of[1][0], of[1][1], qf[1][0], qf[1][1]);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[half][dt].v, pb.v, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[half][dt].v, sb.v, dk[dt], 0, 0, 0);
+          }
+          // dS of this lane's key for queries 32 qt + 16 half + 8 hi + 0..7: chunk 4 qt + 2 half + hi of the key's row
+          // (a lane whose key lies past the sequence holds a copy of the last key's values: zero)
+          const int chunk = 4 * qt + 2 * half + hi;
+          const uint4 z = key_ok ? make_uint4(sb.u[0], sb.u[1], sb.u[2], sb.u[3]) : make_uint4(0u, 0u, 0u, 0u);
+          *(uint4*)(ds_cur + ((chunk ^ ds_sw) << 4)) = z;
+        }
+      }
+    }
+  }
+  __syncthreads();   // the last step's dS^T is complete; the Q / dO tiles are dead
+  if (dq_wave) dq_phase((it - 1) * 64, (it - 1) & 1);
+  if (active) {
+    const float keep = key_ok ? 1.f : 0.f;
+    const int r0 = wave * 32;
     attn_park_store(smem + wave * 4096, dk, keep, lane, a.dQKV + (base + r0) * H3 + H + h * 64, H3, plen - r0);
     attn_park_store(smem + wave * 4096, dv, keep, lane, a.dQKV + (base + r0) * H3 + 2 * H + h * 64, H3, plen - r0);
   }

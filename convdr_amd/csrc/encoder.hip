@@ -292,6 +292,10 @@ extern "C" int convdr_set_option(const char* name, int64_t value) {
     g_gemm_tile_policy = value;
     return 0;
   }
+  if (strcmp(name, "attn_bwd_fused") == 0) {   // training: 1 = one-workgroup attention backward for sequences <= 256 tokens
+    g_attn_bwd_fused = value;
+    return 0;
+  }
   if (strcmp(name, "fused_ln_max_k") == 0) {
     g_fused_ln_max_k = value;
     return 0;

@@ -65,6 +65,9 @@ inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
 // configs[2] training size (profiles/r04_tile_policy.txt).  g_gemm_tile_policy (convdr_set_option "gemm_tile_policy"):
 // 0 = this model, 1 / 2 / 3 = force 256 x 256 / 256 x 128 / 128 x 128 where the shape allows (A/B runs).
 inline int64_t g_gemm_tile_policy = 0;
+// convdr_set_option "attn_bwd_fused": 1 (default) = sequences of at most 256 tokens take k_attention_bwd_fused (dQ, dK, dV in one
+// workgroup per (sequence, head)); 0 = always the dQ kernel + the dK / dV kernel (tests and A/B runs exercise both)
+inline int64_t g_attn_bwd_fused = 1;
 struct TileCost { double step_us, epi_us; int per_cu; };
 inline double gemm_tile_cost(int64_t tiles, int nk, const TileCost& c) {
   const int64_t slots = (int64_t)device_cu_count() * c.per_cu;

@@ -28,6 +28,7 @@ struct LayerBwd {
 struct TrainBufs {
   int32_t* status;
   int32_t *tok_id, *tok_pos;
+  int32_t* order;   // [B] sequences in descending length: the dispatch order of the attention kernels (k_len_order)
   LayerSave* L;  // host array (inside the plan object)
   LayerBwd* G;   // host array
   bf16_t *Xout, *cls_b;
@@ -73,6 +74,7 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
   p.status = (int32_t*)take(256);   // workspace offset 0, as in the inference plan
   p.tok_id = (int32_t*)take(rs * 4);
   p.tok_pos = (int32_t*)take(rs * 4);
+  p.order = (int32_t*)take((size_t)B * 4);
   for (int l = 0; l < c->layers; ++l) {
     LayerSave& s = P.layers[l];
     s.Xin = (bf16_t*)take(rs * H * 2);
@@ -445,6 +447,8 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
   hipLaunchKernelGGL(k_seq_pack, dim3((B + 3) / 4), dim3(256), 0, st, input_ids, ids_are_int32, attention_mask, seq_lens, B, L,
                      cu_seqlens, cfg->kind, cfg->pad_idx, cfg->max_pos, cfg->vocab, p.tok_id, p.tok_pos, p.status);
   CONVDR_CHECK_LAUNCH("k_seq_pack");
+  hipLaunchKernelGGL(k_len_order, dim3((B + 255) / 256), dim3(256), 0, st, seq_lens, B, p.order);
+  CONVDR_CHECK_LAUNCH("k_len_order");
   hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.tok_id, p.tok_pos, rows, H,
                      w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, cfg->ln_eps, P.layers[0].Xin,
                      drop_site(dseed, DROP_SITE_EMB, 0, p_hid));
@@ -460,7 +464,8 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
     // copies of those rows (TrainBufs::c_*; dropout masks indexed by the packed row, so the result is the full layer's).
     const bool cls_tail = l + 1 == cfg->layers && !cfg->pool_mean;
     {
-      AttnTrainArgs a{s.QKV, rows, cu_seqlens, seq_lens, H, s.ctx, drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att), s.LSE, p.ldt, 0.125f};
+      AttnTrainArgs a{s.QKV, rows, cu_seqlens, seq_lens, H, s.ctx, drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att), s.LSE, p.ldt, 0.125f,
+                      p.order};
       ProfScope prof("attention", st);
       hipLaunchKernelGGL(k_attention_train_fwd, dim3(cls_tail ? 1 : (max_len + 127) / 128, cfg->heads, B), dim3(256), 4 * ATT_TILE, st, a);
       CONVDR_CHECK_LAUNCH("k_attention_train_fwd");
@@ -661,11 +666,19 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       // (D[h, t] = dO . O per head is computed by the dQ kernel for its own queries and handed to the dK / dV kernel
       //  through p.Drow: no separate row-dot pass)
       AttnBwdArgs a{s.QKV, p.dctx, rows, s.LSE, cfg->heads, p.Drow, s.ctx, p.Drow, p.ldt, cu_seqlens, seq_lens, H, d.dQKV, 0.125f,
-                    drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att), last ? 64 : 0};
+                    drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att), last ? 64 : 0, p.order};
       ProfScope prof("attention_bwd", st);
-      const dim3 grid((max_len + 127) / 128, cfg->heads, B);
-      hipLaunchKernelGGL(k_attention_bwd_dq, last ? dim3(1, cfg->heads, B) : grid, dim3(256), ATTB_DQ_SMEM, st, a);
-      hipLaunchKernelGGL(k_attention_bwd_dkv, grid, dim3(256), ATTB_DKV_SMEM, st, a);
+      if (g_attn_bwd_fused && !last && max_len <= ATTF_MAX_LEN) {
+        static DeviceOnce attr_done;
+        if (attr_done.first())
+          CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_attention_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               ATTB_FUSED_SMEM));
+        hipLaunchKernelGGL(k_attention_bwd_fused, dim3(cfg->heads, B), dim3(512), ATTB_FUSED_SMEM, st, a);
+      } else {
+        const dim3 grid((max_len + 127) / 128, cfg->heads, B);
+        hipLaunchKernelGGL(k_attention_bwd_dq, last ? dim3(1, cfg->heads, B) : grid, dim3(256), ATTB_DQ_SMEM, st, a);
+        hipLaunchKernelGGL(k_attention_bwd_dkv, grid, dim3(256), ATTB_DKV_SMEM, st, a);
+      }
       CONVDR_CHECK_LAUNCH("k_attention_bwd");
     }
     // ---- the layer's weight-gradient branch: every operand is complete now; it runs beside the layers below ----

@@ -350,7 +350,9 @@ int convdr_adamw_step_packed(float* p, const float* g, float* m, float* v, int64
 /* Tuning / test knobs: "fused_ln_min_rows" = minimum packed rows for the fused GEMM + residual + LayerNorm kernel
  * (default 24576; tests lower it to exercise that kernel on small inputs); "fused_ln_max_k" = largest contraction
  * length it is used for; "hm_blocked" = 0 / 1: row-major / blocked layout of the FFN activation between FFN1 and the
- * fused FFN2 + LayerNorm kernel (default 1; a workspace-internal choice, results are identical); "gemm_trace" / "gemm_trace_ln" = device buffer for the s_memtime phase stamps of a
+ * fused FFN2 + LayerNorm kernel (default 1; a workspace-internal choice, results are identical); "attn_bwd_fused" = 1 / 0:
+ * training backward of the attention in one workgroup per (sequence, head) for sequences of at most 256 tokens / always the
+ * dQ kernel + the dK, dV kernel (default 1); "gemm_trace" / "gemm_trace_ln" = device buffer for the s_memtime phase stamps of a
  * `make TRACE=1` build (tools/gemm_trace*.py; 0 = off). */
 int convdr_set_option(const char* name, int64_t value);
 
