@@ -1267,6 +1267,67 @@ def test_attention_dropout_backward_on_odd_lengths():
     _record_worst(tag, 3e-4, 0.01)
 
 
+def _tiny_long(layers=3, seed=0, max_pos=330):
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    torch.manual_seed(seed)
+    cfg = RobertaConfig(vocab_size=200, hidden_size=128, num_hidden_layers=layers, num_attention_heads=2,
+                        intermediate_size=256, max_position_embeddings=max_pos, hidden_dropout_prob=0.0,
+                        attention_probs_dropout_prob=0.0)
+    return MSMarcoConfigDict["rdot_nll"].model_class(cfg)
+
+
+@pytest.mark.parametrize("p_att", [0.0, 0.2])
+def test_attention_backward_one_workgroup_form_against_autograd_and_the_two_kernel_form(p_att):
+    """Sequences of at most 256 tokens take k_attention_bwd_fused (one workgroup per (sequence, head): dS parked in LDS, dQ
+    contracted by two of its waves); longer ones, the last layer's CLS-only tail and `attn_bwd_fused = 0` take the dQ kernel
+    + the dK / dV kernel.  Every length at which a wave, a key tile or a query tile starts or stops being used (1, 31..33,
+    63..65, 127..129, 191..193, 255, 256), in a batch whose order is not the dispatch order (k_len_order: longest first):
+    gradients against autograd on the oracle (with the replayed attention-dropout mask when p > 0), and the two forms
+    against each other; then a batch with sequences past 256 tokens (the fallback inside the default mode)."""
+    from convdr_amd import _lib, train as TR
+    from oracle import dropout as OD
+    L_ = _lib.lib()
+    rs = np.random.RandomState(77)
+    lens = [33, 256, 1, 191, 64, 129, 255, 31, 192, 65, 128, 193, 63, 32, 127, 200]
+    for L, lens in ((256, lens), (320, [320, 257, 40, 256, 300])):
+        B = len(lens)
+        ids, mask = _batch(rs, B, L, lens)
+        G = torch.from_numpy(rs.randn(B, 768).astype(np.float32))
+        model = _tiny_long()
+        model.config.attention_probs_dropout_prob = p_att
+        model.dropout_seed = 4321
+        sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+        seed = TR.dropout_seed_of(model, 0)
+        ref_emb = OE.rdot_nll_emb(sd, ids, mask, num_layers=3, num_heads=2, dropout=(0.0, p_att, seed) if p_att else None)
+        (ref_emb * G).sum().backward()
+        grads = {}
+        for fused in (1, 0):
+            _lib.check(L_.convdr_set_option(b"attn_bwd_fused", fused), "set_option")
+            try:
+                m = _tiny_long()
+                m.load_state_dict(model.state_dict())
+                m.config.attention_probs_dropout_prob = p_att
+                m.dropout_seed = 4321
+                m = m.cuda().train()
+                emb = m(ids.cuda(), mask.cuda())
+                (emb * G.cuda()).sum().backward()
+                grads[fused] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+            finally:
+                _lib.check(L_.convdr_set_option(b"attn_bwd_fused", 1), "set_option")
+            assert cosine(emb.detach().cpu().numpy(), ref_emb.detach().numpy()).min() > 1 - 1e-3
+            tag = "attn_bwd_%s_L%d_p%g" % ("fused" if fused else "split", L, p_att)
+            for n, g in grads[fused].items():
+                if n in sd and sd[n].grad is not None and not n.endswith("key.bias") and float(sd[n].grad.abs().max()) > 0:
+                    _compare(n, g, sd[n].grad, cos_tol=1 - 4e-4, norm_tol=8e-3, tag=tag)
+            _record_worst(tag, 4e-4, 8e-3)
+        for n in grads[1]:
+            if n.endswith("key.bias"):
+                continue
+            a, b = grads[1][n].double().reshape(-1), grads[0][n].double().reshape(-1)
+            if float(b.norm()) > 0:
+                assert float((a - b).norm() / b.norm()) < 2e-3, (n, float((a - b).norm() / b.norm()))
+
+
 def test_dropout_statistics():
     """Keep rate, inverted scaling and independence of the device masks, read back through a model whose activations make
     the mask observable: with all-ones LayerNorm-free probes this would need kernel hooks, so the check goes through the
