@@ -51,7 +51,12 @@ struct TrainBufs {
 
 constexpr int TRAIN_MAX_LAYERS = 48;
 constexpr int CLS_MAX_SPLIT = 16;   // contraction slices of the compact (CLS-row) projections of the last layer
-constexpr int LN_BWD_BLOCKS = 512;
+#ifndef CONVDR_LN_BWD_BLOCKS
+#define CONVDR_LN_BWD_BLOCKS 768
+#endif
+constexpr int LN_BWD_BLOCKS = CONVDR_LN_BWD_BLOCKS;
+constexpr int EMB_BWD_BLOCKS = 512;   // (k_embed_bwd keeps a 48 KB staging image per workgroup: three per CU)
+static_assert(EMB_BWD_BLOCKS <= LN_BWD_BLOCKS, "p.part is sized by LN_BWD_BLOCKS");
 constexpr int COLSUM_CHUNKS = 64;
 constexpr size_t SLAB_ELEMS = (size_t)16 * 3072 * 768;  // >= splits * N * K for every weight of a base-size model
 
@@ -724,7 +729,7 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
   wf.layers_recorded = NL;
   // ---- embeddings ----
   {
-    const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
+    const int blocks = (int)(ceil_div64(rows, 4) < EMB_BWD_BLOCKS ? ceil_div64(rows, 4) : EMB_BWD_BLOCKS);
     ProfScope prof("embed_bwd", st);
     hipLaunchKernelGGL(k_embed_bwd, dim3(blocks), dim3(256), 0, st, cur_f, cur_b, p.tok_id, p.tok_pos, rows, H, w->word_emb, w->pos_emb,
                        w->type_emb, w->emb_ln_g, cfg->ln_eps, gr->word_emb, gr->pos_emb, p.part,

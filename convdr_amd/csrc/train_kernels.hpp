@@ -82,7 +82,10 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
                                                        const int32_t* __restrict__ row_map) {
   // row_map (optional): the rows are a compact selection (the CLS rows of the last layer); the dropout mask of row r is
   // that of packed row row_map[r]
-  __shared__ float red[4][3][1024];
+  // (cross-wave sums of the three column partials: one [3][1024] image that the four waves add into in turn.  The round-2
+  //  form kept one image per wave, 48 KB: three workgroups per CU for a kernel that is bound by loads in flight -- 512
+  //  workgroups measured 1.11 ms per configs[2] step, 768 0.94, and with 12 KB the launch below takes 1024.)
+  __shared__ float red[3][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 ag[4], ab[4], ax[4];
 #pragma unroll
@@ -167,19 +170,32 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
       }
     }
   }
+  auto f4add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int e0 = 256 * j + 4 * lane;
-    if (e0 < H) {
-      *(float4*)&red[wave][0][e0] = ax[j];
-      *(float4*)&red[wave][1][e0] = ag[j];
-      *(float4*)&red[wave][2][e0] = ab[j];
+  for (int w = 0; w < 4; ++w) {   // fixed order (wave 0 + 1 + 2 + 3): deterministic
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e0 = 256 * j + 4 * lane;
+        if (e0 < H) {
+          if (w > 0) {
+            f4add(ax[j], *(const float4*)&red[0][e0]);
+            f4add(ag[j], *(const float4*)&red[1][e0]);
+            f4add(ab[j], *(const float4*)&red[2][e0]);
+          }
+          if (w < 3) {
+            *(float4*)&red[0][e0] = ax[j];
+            *(float4*)&red[1][e0] = ag[j];
+            *(float4*)&red[2][e0] = ab[j];
+          } else {
+            *(float4*)(part + ((int64_t)blockIdx.x * 3 + 0) * H + e0) = ax[j];
+            *(float4*)(part + ((int64_t)blockIdx.x * 3 + 1) * H + e0) = ag[j];
+            *(float4*)(part + ((int64_t)blockIdx.x * 3 + 2) * H + e0) = ab[j];
+          }
+        }
+      }
     }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 3 * H; i += 256) {
-    const int k = i / H, e = i - k * H;
-    part[((int64_t)blockIdx.x * 3 + k) * H + e] = red[0][k][e] + red[1][k][e] + red[2][k][e] + red[3][k][e];
+    if (w < 3) __syncthreads();
   }
 }
 
