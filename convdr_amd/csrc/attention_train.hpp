@@ -683,7 +683,7 @@ static __global__ void __launch_bounds__(512, 1) k_attention_bwd_fused(const Att
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srcL.rsrc, (lptr_t)(set + 2 * ATT_TILE), 4, (uint32_t)lane * 4, soff, 0, 0);
     }
   };
-  const int qlen = len;
+  const int qlen = (a.q_limit > 0 && a.q_limit < len) ? a.q_limit : len;   // queries that carry gradient (last layer: the CLS tile)
   stage(0, 0);
 #pragma unroll
   for (int t = 0; t < 4; ++t)

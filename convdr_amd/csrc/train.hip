@@ -663,7 +663,8 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       // d ctx: zero but for the CLS rows; the attention backward below reads the first query tile only.  The Q third of dQKV
       // beyond that tile is never written: zero.  The residual-branch gradient handed to the layer below: likewise.
       dY1 = cur_f;
-      hipLaunchKernelGGL(k_cls_tail_scatter, dim3(B, 8), dim3(256), 0, st, cu_seqlens, B, H, p.c_dctx, p.dctx, d.dQKV, p.c_dY1, dY1);
+      hipLaunchKernelGGL(k_cls_tail_scatter, dim3(B, 8), dim3(256), 0, st, cu_seqlens, B, H, p.c_dctx, p.dctx, d.dQKV, p.c_dY1, dY1,
+                         (g_attn_bwd_fused && max_len <= ATTF_MAX_LEN) ? 64 : 128);
       CONVDR_CHECK_LAUNCH("k_cls_tail_scatter");
     }
     // ---- attention ----
@@ -673,7 +674,7 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       AttnBwdArgs a{s.QKV, p.dctx, rows, s.LSE, cfg->heads, p.Drow, s.ctx, p.Drow, p.ldt, cu_seqlens, seq_lens, H, d.dQKV, 0.125f,
                     drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att), last ? 64 : 0, p.order};
       ProfScope prof("attention_bwd", st);
-      if (g_attn_bwd_fused && !last && max_len <= ATTF_MAX_LEN) {
+      if (g_attn_bwd_fused && max_len <= ATTF_MAX_LEN) {   // (last layer: q_limit = 64, one query step)
         static DeviceOnce attr_done;
         if (attr_done.first())
           CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_attention_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -418,19 +418,21 @@ __global__ void __launch_bounds__(256) k_gather_cls2(const int32_t* __restrict__
 // grid (B, 8): the rows of a sequence are dealt to 8 blocks, one wave per row.
 __global__ void __launch_bounds__(256) k_cls_tail_scatter(const int32_t* __restrict__ cu, int B, int H, const bf16_t* __restrict__ dctx_c,
                                                           bf16_t* __restrict__ dctx, bf16_t* __restrict__ dQKV,
-                                                          const float* __restrict__ dY1_c, float* __restrict__ G) {
+                                                          const float* __restrict__ dY1_c, float* __restrict__ G,
+                                                          int dq_rows) {
+  // dq_rows: rows of a sequence whose dQ the attention backward that follows writes itself (its first query tile: 128 for the
+  // dQ kernel, 64 for the one-workgroup form)
   const int b = blockIdx.x, lane = threadIdx.x & 63;
   const int64_t base = cu[b], end = cu[b + 1];
   for (int64_t row = base + blockIdx.y * 4 + (threadIdx.x >> 6); row < end; row += 4 * gridDim.y) {
     const bool cls = row == base;
     for (int e0 = 4 * lane; e0 < H; e0 += 256)
       *(float4*)(G + row * H + e0) = cls ? *(const float4*)(dY1_c + (int64_t)b * H + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < base + 128) {
+    if (row < base + 128)
       for (int e0 = 8 * lane; e0 < H; e0 += 512)
         *(uint4*)(dctx + row * H + e0) = cls ? *(const uint4*)(dctx_c + (int64_t)b * H + e0) : make_uint4(0u, 0u, 0u, 0u);
-    } else {
+    if (row >= base + dq_rows)
       for (int e0 = 8 * lane; e0 < H; e0 += 512) *(uint4*)(dQKV + row * 3 * H + e0) = make_uint4(0u, 0u, 0u, 0u);
-    }
   }
 }
 
