@@ -349,7 +349,7 @@ class _EncoderFn(torch.autograd.Function):
             _status_post(tower, ws)
             # the zeroed gradient arena of this forward's backward (0.5 GB for roberta-base: a 64 us fill that used to be the
             # first thing on the backward's critical path): allocated here, zeroed on the side stream under the forward
-            ctx.grad_arena = torch.empty(sum(int(np.prod(p.shape)) for p in params), dtype=torch.float32, device=dev)
+            ctx.grad_arena = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
             with torch.cuda.stream(side):
                 ctx.packed_t = _packed_t(tower, head)
                 ctx.grad_arena.zero_()
@@ -958,8 +958,10 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
     if gas > 1 and step is None:
         raise ValueError("train_step: gradient_accumulation_steps = %d needs the micro-batch index `step`" % gas)
     do_step = gas == 1 or (step + 1) % gas == 0
-    model.train()
-    teacher_model.eval()
+    if not model.training:           # (nn.Module.train() walks and re-flags ~190 modules: 0.7 ms of host time per call)
+        model.train()
+    if teacher_model.training:
+        teacher_model.eval()
     # The frozen teacher's forward is independent of the student's and, at 64 x 64 tokens, fills barely a third of the
     # CUs: it runs on a side stream under the student's forward and is joined before the loss needs it.
     main = torch.cuda.current_stream()

@@ -1,0 +1,30 @@
+"""cProfile of the host side of the KD training loop (20 steps enqueued without synchronisation)."""
+import os, sys, time, cProfile, pstats
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import numpy as np, torch
+import bench
+from types import SimpleNamespace
+from convdr_amd import train as TR
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+TR.reserve_streams(dev)
+student = bench.random_rdot_model(0).to(dev); teacher = bench.random_rdot_model(0).to(dev).eval()
+student.config.hidden_dropout_prob = student.config.attention_probs_dropout_prob = 0.1
+TR.flatten_parameters(student)
+targs = SimpleNamespace(learning_rate=1e-5, adam_epsilon=1e-8, max_grad_norm=1.0, ranking_task=False, no_mse=False, num_negatives=9, gradient_accumulation_steps=1)
+opt = TR.get_optimizer(targs, student, weight_decay=0.0); sched = TR.get_linear_schedule_with_warmup(opt, 0, 10000)
+g = torch.Generator(device=dev).manual_seed(0)
+def turns(L, lo):
+    i = torch.randint(3, 50000, (64, L), generator=g, device=dev); i[:, 0] = 0
+    ln = torch.randint(lo, L + 1, (64,), generator=g, device=dev)
+    m = (torch.arange(L, device=dev)[None, :] < ln[:, None]).long()
+    return i * m, m, ln.cpu().numpy().astype(np.int32)
+(ci, cm, cl), (ti, tm, tl) = turns(256, 32), turns(64, 8)
+batch = (ci, cm, ti, tm, cl, tl)
+for _ in range(8): TR.train_step(targs, student, teacher, opt, sched, batch)
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(20): TR.train_step(targs, student, teacher, opt, sched, batch)
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(45)
