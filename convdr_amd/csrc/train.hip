@@ -151,7 +151,16 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
 // fork() makes the side stream wait for what the main stream has enqueued so far (the layer's activation gradients);
 // nothing on the main stream ever waits for the side stream before the final join, because every operand the branch
 // reads lives in a per-layer buffer (LayerBwd / LayerSave) and its scratch (slab, the bias part of `part`) is its own.
-static hipStream_t g_ext_side = nullptr;   // convdr_train_set_side_stream (before the first backward of the process)
+static hipStream_t g_ext_side = nullptr;
+
+// Timing-only experiments (`make TRACE=1` library only: the results are garbage): CONVDR_DBG_SKIP drops whole classes of
+// launches -- 1 gelu', 2 LayerNorm backward, 4 forward attention, 8 weight gradients, 16 attention backward, 64 forward
+// LayerNorm -- to measure what each class costs the STEP (tools/dbg/skip_probe.sh, profiles/r04_train_kd_sensitivity.txt).
+#ifdef CONVDR_ENABLE_TRACE
+static int dbg_skip() { static const int v = getenv("CONVDR_DBG_SKIP") ? atoi(getenv("CONVDR_DBG_SKIP")) : 0; return v; }
+#else
+static constexpr int dbg_skip() { return 0; }
+#endif   // convdr_train_set_side_stream (before the first backward of the process)
 
 struct WgradFork {
   hipStream_t main, side;
@@ -318,7 +327,8 @@ static int wgrad_launch(const WgradItem* it, int count, int64_t rows, float* sla
   }
   {
     ProfScope prof("gemm_wgrad", st);
-    hipLaunchKernelGGL((k_gemm_tn<T>), dim3((unsigned)tiles, (unsigned)nsplit), dim3(T::THREADS), TnCfg<T>::SMEM_BYTES, st, g);
+    if (!(dbg_skip() & 8))
+      hipLaunchKernelGGL((k_gemm_tn<T>), dim3((unsigned)tiles, (unsigned)nsplit), dim3(T::THREADS), TnCfg<T>::SMEM_BYTES, st, g);
     CONVDR_CHECK_LAUNCH("k_gemm_tn");
   }
   if (nsplit > 1 && !g.flags)
@@ -359,7 +369,8 @@ static int ln_bwd_kernel(const float* dY, const bf16_t* dYadd, const float* Yin,
                          const DropSite drop = DropSite{0u, 0u, 1.f}, const int32_t* row_map = nullptr) {
   const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
   ProfScope prof("layernorm_bwd", st);
-  hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, dYadd, Yin, rows, H, g, eps, dXf, dXb, part, drop, row_map);
+  if (!(dbg_skip() & 2))
+    hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, dYadd, Yin, rows, H, g, eps, dXf, dXb, part, drop, row_map);
   CONVDR_CHECK_LAUNCH("k_layernorm_bwd");
   *blocks_out = blocks;
   return 0;
@@ -472,7 +483,8 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
       AttnTrainArgs a{s.QKV, rows, cu_seqlens, seq_lens, H, s.ctx, drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att), s.LSE, p.ldt, 0.125f,
                       p.order};
       ProfScope prof("attention", st);
-      hipLaunchKernelGGL(k_attention_train_fwd, dim3(cls_tail ? 1 : (max_len + 127) / 128, cfg->heads, B), dim3(256), 4 * ATT_TILE, st, a);
+      if (!(dbg_skip() & 4))
+        hipLaunchKernelGGL(k_attention_train_fwd, dim3(cls_tail ? 1 : (max_len + 127) / 128, cfg->heads, B), dim3(256), 4 * ATT_TILE, st, a);
       CONVDR_CHECK_LAUNCH("k_attention_train_fwd");
     }
     if (cls_tail) {
@@ -502,7 +514,8 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
     g.rows = rows; g.W = (const bf16_t*)lw->wo; g.X = s.ctx; g.N = H; g.K = H; g.bias = lw->bo; g.Cf = s.Y1; g.R = s.Xin;
     g.drop = drop_site(dseed, DROP_SITE_ATTN_OUT, l, p_hid);
     if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_attn_out")) return e;
-    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, s.Y1, rows, H, lw->ln1_g, lw->ln1_b,
+    if (!(dbg_skip() & 64))
+      hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, s.Y1, rows, H, lw->ln1_g, lw->ln1_b,
                        cfg->ln_eps, s.X1, (float*)nullptr);
     CONVDR_CHECK_LAUNCH("k_layernorm");
     g = GemmArgs{};
@@ -513,7 +526,8 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
     g.drop = drop_site(dseed, DROP_SITE_FFN_OUT, l, p_hid);
     if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_ffn2")) return e;
     if (l + 1 < cfg->layers) {
-      hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, s.Y2, rows, H, lw->ln2_g, lw->ln2_b,
+      if (!(dbg_skip() & 64))
+        hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, s.Y2, rows, H, lw->ln2_g, lw->ln2_b,
                          cfg->ln_eps, P.layers[l + 1].Xin, (float*)nullptr);
       CONVDR_CHECK_LAUNCH("k_layernorm");
     } else if (cfg->pool_mean) {   // use_mean = True: masked mean of the whole last layer's output
@@ -615,7 +629,8 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
       {
         ProfScope prof("dgelu_colsum", st);
-        hipLaunchKernelGGL(k_dgelu_colsum, dim3((I + 255) / 256, chunks), dim3(256), 0, st, d.dHpre, s.Hpre, rows, I, d.part_b1);
+        if (!(dbg_skip() & 1))
+          hipLaunchKernelGGL(k_dgelu_colsum, dim3((I + 255) / 256, chunks), dim3(256), 0, st, d.dHpre, s.Hpre, rows, I, d.part_b1);
         CONVDR_CHECK_LAUNCH("k_dgelu_colsum");
       }
       // ---- FFN1: Hpre = X1 W1^T + b1;  dX1 = dHpre W1 (bf16 tile output) + dY2 (residual branch, fp32) ----
@@ -679,7 +694,8 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
         if (attr_done.first())
           CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_attention_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                ATTB_FUSED_SMEM));
-        hipLaunchKernelGGL(k_attention_bwd_fused, dim3(cfg->heads, B), dim3(512), ATTB_FUSED_SMEM, st, a);
+        if (!(dbg_skip() & 16))
+          hipLaunchKernelGGL(k_attention_bwd_fused, dim3(cfg->heads, B), dim3(512), ATTB_FUSED_SMEM, st, a);
       } else {
         const dim3 grid((max_len + 127) / 128, cfg->heads, B);
         hipLaunchKernelGGL(k_attention_bwd_dq, last ? dim3(1, cfg->heads, B) : grid, dim3(256), ATTB_DQ_SMEM, st, a);
