@@ -607,13 +607,14 @@ static __global__ void __launch_bounds__(256, 2) k_attention_bwd_dkv(const AttnB
 // dS arithmetic are what these latency- and VALU-bound kernels spend their time on -- and each pays its own prologue
 // (operand fragments, first tiles) and launch.  Here eight waves own 32 keys each (lane = key, exactly the dK / dV kernel's
 // scheme and arithmetic), loop over 64-query tiles, and additionally park dS (bf16, [key][query], the engine's tile
-// image) in LDS; one step later -- from the other of two dS sets, beside the next step of the waves that own keys -- waves 6
-// and 7 contract it with K^T read from the sequence's K tiles:
+// image) in LDS; one step later -- from the other of two dS sets, beside the next step of the waves that own keys -- waves
+// 4 .. 7 contract it (a 32-query x 32-dimension block each) with K^T read from the sequence's K tiles:
 //   dQ^T[d, q] = sum_key K^T[d, key] dS^T[key, q]      (both operands through ds_read_b64_tr_b16)
 // so dQ needs neither a second pass over the scores nor a cross-workgroup reduction (one workgroup sees every key), and a
 // step has one barrier.  D[q] = dO[q] . O[q] is computed in the prologue for the whole sequence (two threads per query).
 // Measured (configs[2], 11 layers): dQ kernel + dK / dV kernel 98 us per layer; this kernel 96.6 us in its first form (dQ
-// phase behind a second barrier, batch order), 77.7 us with the late dQ phase and the longest sequences dispatched first.
+// phase behind a second barrier, batch order), 77.7 us with the late dQ phase on two waves and the longest sequences
+// dispatched first, ~72 us with it on four.
 // The attention backward is ON the step's critical path: a timing-only cut of its work by 0.49 ms shortened the configs[2]
 // step by 0.8 ms (10.30 -> 9.49).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -622,7 +623,7 @@ constexpr int ATTF_SET = 2 * ATT_TILE + 512;          // Q tile | dO tile | 64 L
 constexpr int ATTF_K = 2 * ATTF_SET;                  // four K tiles (the sequence's keys)
 constexpr int ATTF_DS = ATTF_K + 4 * ATT_TILE;        // two sets of four dS^T tiles: rows = keys, columns = the 64 queries of a step
 constexpr int ATTF_D = ATTF_DS + 8 * ATT_TILE;        // D of the sequence's queries (256 floats)
-constexpr int ATTF_PARK = ATTF_D + 1024;              // park regions of the two dQ waves
+constexpr int ATTF_PARK = ATTF_D + 1024;              // park regions of the four dQ waves (2 KB each)
 constexpr int ATTB_FUSED_SMEM = ATTF_PARK + 2 * 4096;
 
 // one 8-row round of a 64-row tile per wave (eight waves: the whole tile)
@@ -633,6 +634,30 @@ __device__ __forceinline__ void attn_stage_rows8(const AttnTileSrc& s, int64_t f
   const uint32_t gch = (uint32_t)((lane & 7) ^ ((row >> 1) & 7));
   const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)((first_row + r0) * s.rowb) + col_bytes);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (lptr_t)(lds + r0 * 128), 16, s.voff + gch * 16, soff, 0, 0);
+}
+
+// One 32-row x 32-column bf16 block (half the head dimensions of 32 queries) from an accumulator tile: parked in the wave's
+// 2 KB ([32 rows][64 bytes]), written out 16 bytes per lane, four lanes per row.  Same register layout as attn_park_store.
+__device__ __forceinline__ void attn_park_store_half(char* so, const f32x16& o, float scale, int lane, bf16_t* dst, int64_t pitch,
+                                                     int nvalid) {
+  const int li = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    uint2 ov;
+    ov.x = pack_bf16x2(o[4 * g + 0] * scale, o[4 * g + 1] * scale);
+    ov.y = pack_bf16x2(o[4 * g + 2] * scale, o[4 * g + 3] * scale);
+    *(uint2*)(so + li * 64 + ((g ^ (li & 3)) << 4) + hi * 8) = ov;
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int c4 = lane & 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (lane >> 2) + 16 * i;
+    const uint4 v = *(const uint4*)(so + row * 64 + ((c4 ^ (row & 3)) << 4));
+    if (row < nvalid) *(uint4*)(dst + row * pitch + c4 * 8) = v;
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
 static __global__ void __launch_bounds__(512, 1) k_attention_bwd_fused(const AttnBwdArgs a) {
@@ -721,36 +746,36 @@ static __global__ void __launch_bounds__(512, 1) k_attention_bwd_fused(const Att
       *(uint4*)(ds_rowp + 4 * ATT_TILE + (hi * 4 + i) * 16) = make_uint4(0u, 0u, 0u, 0u);
     }
   }
-  // The dQ contraction of step i runs one step late, on waves 6 and 7, from the other dS^T set: beside step i + 1 of the waves
-  // that own keys (for sequences of at most 192 tokens waves 6 and 7 own none) -- one barrier per step, not two.
-  const bool dq_wave = wave >= 6;
-  const int qb = wave - 6;
-  TrLane trq = trl;   // dS^T fragments of this dQ wave's 32-query block (selected here: a run-time index would put the table in scratch)
+  // The dQ contraction of step i runs one step late, from the other dS^T set, on waves 4 .. 7 -- one 32-query x 32-dimension
+  // block each -- beside step i + 1 of the waves that own keys (for sequences of at most 128 tokens waves 4 .. 7 own none;
+  // past 192 tokens every wave owns keys and the contraction is spread over four of them): one barrier per step, not two.
+  const bool dq_wave = wave >= 4;
+  const int qb = (wave - 4) & 1, dtq = (wave - 4) >> 1;
+  TrLane trq = trl, trk = trl;   // fragment addresses selected here: a run-time table index would put the table in scratch
   trq.a[0][0] = qb ? trl.a[1][0] : trl.a[0][0];
   trq.a[0][1] = qb ? trl.a[1][1] : trl.a[0][1];
+  trk.a[0][0] = dtq ? trl.a[1][0] : trl.a[0][0];
+  trk.a[0][1] = dtq ? trl.a[1][1] : trl.a[0][1];
   auto dq_phase = [&](int qs, int set) {
-    f32x16 dq[2];
+    f32x16 dq;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
     for (int t = 0; t * 64 < len; ++t) {
       const uint32_t tK = s0 + ATTF_K + t * ATT_TILE, tS = s0 + ATTF_DS + (set * 4 + t) * ATT_TILE;
-      TrFrag ka[4][2], sf[4];
-      tr_frag<0>(tK, trl, 0, ka[0][0]);  tr_frag<0>(tK, trl, 1, ka[0][1]);  tr_frag<0>(tS, trq, 0, sf[0]);
-      tr_frag<16>(tK, trl, 0, ka[1][0]); tr_frag<16>(tK, trl, 1, ka[1][1]); tr_frag<16>(tS, trq, 0, sf[1]);
-      tr_frag<32>(tK, trl, 0, ka[2][0]); tr_frag<32>(tK, trl, 1, ka[2][1]); tr_frag<32>(tS, trq, 0, sf[2]);
-      tr_frag<48>(tK, trl, 0, ka[3][0]); tr_frag<48>(tK, trl, 1, ka[3][1]); tr_frag<48>(tS, trq, 0, sf[3]);
-      tr_wait4<0>(ka[0][0], ka[0][1], ka[1][0], ka[1][1]);
-      tr_wait4<0>(ka[2][0], ka[2][1], ka[3][0], ka[3][1]);
+      TrFrag ka[4], sf[4];
+      tr_frag<0>(tK, trk, 0, ka[0]);  tr_frag<0>(tS, trq, 0, sf[0]);
+      tr_frag<16>(tK, trk, 0, ka[1]); tr_frag<16>(tS, trq, 0, sf[1]);
+      tr_frag<32>(tK, trk, 0, ka[2]); tr_frag<32>(tS, trq, 0, sf[2]);
+      tr_frag<48>(tK, trk, 0, ka[3]); tr_frag<48>(tS, trq, 0, sf[3]);
+      tr_wait4<0>(ka[0], ka[1], ka[2], ka[3]);
       tr_wait4<0>(sf[0], sf[1], sf[2], sf[3]);
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s4][dt].v, sf[s4].v, dq[dt], 0, 0, 0);
+      for (int s4 = 0; s4 < 4; ++s4) dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s4].v, sf[s4].v, dq, 0, 0, 0);
     }
     const int r0 = qs + 32 * qb;
     const float keep = r0 + li < len ? 1.f : 0.f;
-    attn_park_store(smem + ATTF_PARK + qb * 4096, dq, keep, lane, a.dQKV + (base + r0) * H3 + h * 64, H3, plen - r0);
+    attn_park_store_half(smem + ATTF_PARK + (wave - 4) * 2048, dq, keep, lane, a.dQKV + (base + r0) * H3 + h * 64 + 32 * dtq, H3,
+                         plen - r0);
   };
   int it = 0;
   for (int q0 = 0; q0 < qlen; q0 += 64, ++it) {
