@@ -210,6 +210,15 @@ def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
+    # the step watchdog (train._StreamSets) probes its two stream sets on the first ~14 real steps of a process: done here,
+    # before the warm-up, so that neither the W warm-up steps nor the K timed ones carry the probe
+    # (N > 1: a fixed count -- every step holds collectives, so all ranks must run the same number of them)
+    if dist_on:
+        settle_steps = 16
+        for i in range(settle_steps):
+            step(i)
+    else:
+        settle_steps = TR.settle_streams(step, dev)
     for i in range(warmup):
         step(i)
     sync_all()
@@ -252,6 +261,7 @@ def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=
         "config": {"workload": "configs[2] train_kd", "batch_per_gpu": Bt, "student_seq": Ls, "teacher_seq": Lt,
                    "parallelism": "dp%d" % world, "mean_real_student_tokens": real_tokens, "student_dropout": float(dropout)},
         "final_loss": float(loss),
+        "stream_selfcheck": dict(TR.stream_decisions(dev), settle_steps=settle_steps),
         "TFLOPs_dense_padded_count": sps / world * flop_dense / Bt / 1e12,
         "TFLOPs_real_token_count_linear_only": flop_real * steps / el / 1e12,
         "frac_of_bf16_mfma_peak_real_tokens": flop_real * steps / el / 1e12 / MFMA_BF16_PEAK_TFLOPS / world,

@@ -254,7 +254,14 @@ enum { EPI_BF16 = 0, EPI_GELU_BF16 = 1, EPI_RESID_F32 = 2, EPI_QKV = 3, EPI_F32 
        // whole octet (16 bytes), and in this layout the 32 lanes of a half-wave then write 512 CONTIGUOUS bytes: the
        // tile leaves straight from the registers in whole lines -- no LDS park, no barrier, no re-read -- and the
        // consumer's LDS-DMA (16 tokens x 4 octets per instruction) reads whole lines too.
-       EPI_GELU_BLK = 8 };
+       EPI_GELU_BLK = 8,
+       // Training FFN1 of the full layers (round 5): Cb = gelu(y) row-major (FFN2's operand) and Cb2 = gelu'(y) in the BLOCKED
+       // layout -- the derivative is evaluated HERE, where Q(|y|) of the forward's own fit is already in a register (one
+       // quartic more, no second transcendental), and leaves register-direct in whole lines like EPI_GELU_BLK's tile.  The
+       // backward's FFN2 data-gradient GEMM (EPI_MUL_GP) multiplies its accumulators by it in its epilogue: the separate
+       // gelu' pass over [rows, I] (k_dgelu_colsum: 41 us per layer on the activation-gradient chain) is gone.
+       EPI_GELU_GP = 9,
+       EPI_MUL_GP = 10 };   // Cb = (acc) * Gp: Gp = the blocked gelu' image EPI_GELU_GP wrote
 // element offset of (token t, feature f) in the blocked layout of a [rows, N] matrix
 __host__ __device__ inline int64_t hm_blocked_offset(int64_t t, int f, int N) {
   return ((t >> 5) * (N >> 3) + (f >> 3)) * 256 + (t & 31) * 8 + (f & 7);
@@ -271,6 +278,7 @@ struct GemmArgs {
   bf16_t* Cb;         // EPI_BF16 / EPI_GELU_BF16: [rows, N]
   bf16_t* Cb2;        // EPI_GELU_SAVE: pre-activation [rows, N]
   float* Cf;          // EPI_RESID_F32 / EPI_F32:  [rows, N]
+  const bf16_t* Gp;   // EPI_MUL_GP: gelu'(pre-activation), blocked layout [rows / 32][N / 8][32][8] (written through Cb2 by EPI_GELU_GP)
   const bf16_t* R;    // EPI_RESID_F32: residual [rows, N] bf16
   const float* Rf;    // EPI_RESID_F32: fp32 residual instead of R when non-null (gradient residual stream)
   bf16_t *Qo, *Ko, *Vt;  // EPI_QKV (N = 3H): Q [rows, H], K [rows, H], Vt [H, ldt]
@@ -350,6 +358,44 @@ __device__ __forceinline__ float gelu_grad(float x) {
   const float cdf = x >= 0.f ? 1.f - q : q;
   const float e = __builtin_amdgcn_exp2f(-0.7213475204444817f * x * x);
   return fmaf(x * 0.3989422804014327f, e, cdf);
+}
+
+// gelu(x) AND gelu'(x) of two elements from ONE evaluation of the tail fit (EPI_GELU_GP).  With q = Q(t), t = |x|:
+//     gelu'(x) = Phi(x) + x phi(x) = 1 + r (x >= 0),  -r (x < 0),   r = t phi(t) - Q(t) = q m(t),
+// m(t) = t phi(t) / Q(t) - 1 (the inverse Mills ratio times t, minus one: smooth, ~ t^2 for large t) fitted by a quartic
+// against the FITTED q (minimax on the product q m: max |error| of gelu' 3.6e-5 over all x, tests/test_gelu_fit_cpu.py --
+// the level of gelu_grad's two-transcendental form, two orders below the bf16 rounding of the stored derivative).
+// Branch-free: gelu'(x) = 0.5 + copysign(0.5 + r, x).  x0, x1 are replaced by gelu(x) (bit-identical to gelu_tail2).
+__device__ __forceinline__ void gelu_tail2_gp(float& x0, float& x1, float& g0, float& g1) {
+  f32x2_t t, r;
+  float a, b;
+  const float nine = 9.f;
+  asm("v_min_f32 %0, |%1|, %2" : "=v"(a) : "v"(x0), "s"(nine));
+  asm("v_min_f32 %0, |%1|, %2" : "=v"(b) : "v"(x1), "s"(nine));
+  t.x = a; t.y = b;
+  asm("v_max_f32 %0, 0, %1" : "=v"(a) : "v"(x0));
+  asm("v_max_f32 %0, 0, %1" : "=v"(b) : "v"(x1));
+  r.x = a; r.y = b;
+  const f32x2_t c3 = {0.0041585f, 0.0041585f}, c2 = {-0.04571999f, -0.04571999f}, c1 = {-0.46495319f, -0.46495319f},
+                c0 = {-1.14955714f, -1.14955714f}, m1 = {-1.f, -1.f};
+  f32x2_t p = __builtin_elementwise_fma(t, c3, c2);
+  p = __builtin_elementwise_fma(p, t, c1);
+  p = __builtin_elementwise_fma(p, t, c0);
+  p = __builtin_elementwise_fma(p, t, m1);
+  f32x2_t q;
+  q.x = __builtin_amdgcn_exp2f(p.x);
+  q.y = __builtin_amdgcn_exp2f(p.y);
+  const f32x2_t d4 = {-0.0117551f, -0.0117551f}, d3 = {0.09555683f, 0.09555683f}, d2 = {0.64461331f, 0.64461331f},
+                d1 = {0.79644568f, 0.79644568f}, d0 = {-0.99992798f, -0.99992798f}, half = {0.5f, 0.5f};
+  f32x2_t m = __builtin_elementwise_fma(t, d4, d3);
+  m = __builtin_elementwise_fma(m, t, d2);
+  m = __builtin_elementwise_fma(m, t, d1);
+  m = __builtin_elementwise_fma(m, t, d0);
+  const f32x2_t hr = __builtin_elementwise_fma(q, m, half);   // 0.5 + r
+  g0 = 0.5f + __builtin_copysignf(hr.x, x0);
+  g1 = 0.5f + __builtin_copysignf(hr.y, x1);
+  r = __builtin_elementwise_fma(-t, q, r);
+  x0 = r.x; x1 = r.y;
 }
 
 // ---- bf16 output tiles leave through LDS ---------------------------------------------------------------------
@@ -741,7 +787,10 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
       lds_barrier();     // every wave is done with the last K step's stage (and the next tile's sbias is visible)
       CONVDR_TRACE(2)
       const bool full_n = n0 + T::TR <= a.N;  // workgroup-uniform: no per-quad feature bound checks on the fast path
-      constexpr bool BF16_OUT = EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV || EPI == EPI_GELU_SAVE;
+      constexpr bool BF16_OUT = EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV || EPI == EPI_GELU_SAVE ||
+                                EPI == EPI_GELU_GP || EPI == EPI_MUL_GP;
+      constexpr bool GP = EPI == EPI_GELU_GP || EPI == EPI_MUL_GP;   // a blocked gelu' image is written / read beside the tile
+      const int64_t rows32 = (a.rows + 31) & ~(int64_t)31;
       constexpr int NOUT = EPI == EPI_GELU_SAVE ? 2 : 1;   // second output: the pre-activation
 #pragma unroll
       for (int out = 0; out < NOUT; ++out)
@@ -773,6 +822,26 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
             const bool t_ok = t < a.rows;
             const int64_t tc = t_ok ? t : a.rows - 1;
             uint2 res[T::MT][4];
+            // blocked gelu' image: octet (mt * 4 + 2 j + hi) of this lane's token (see EPI_GELU_BLK for the layout)
+            u32x4_t gpq[GP ? T::MT : 1][2];
+            bf16_t* gp_blk = nullptr;
+            bool gp_ok = false;
+            if constexpr (GP) {
+              const int64_t tb = t0 + (we.wl * T::NT + nt) * 32;   // first token of this 32-token block (wave-uniform)
+              bf16_t* img = EPI == EPI_GELU_GP ? a.Cb2 : const_cast<bf16_t*>(a.Gp);
+              gp_blk = img + ((tb >> 5) * (a.N >> 3) + ((n0 + we.wr * T::MT * 32) >> 3)) * 256 + we.li * 8;
+              gp_ok = tb < rows32;
+              if constexpr (EPI == EPI_MUL_GP) {
+#pragma unroll
+                for (int mt = 0; mt < T::MT; ++mt)
+#pragma unroll
+                  for (int j = 0; j < 2; ++j) {
+                    const bool ok = gp_ok && n0 + we.wr * T::MT * 32 + mt * 32 < a.N;
+                    gpq[mt][j] = ok ? __builtin_nontemporal_load((const u32x4_t*)(gp_blk + (int64_t)(mt * 4 + 2 * j + we.hi) * 256))
+                                    : (u32x4_t){0u, 0u, 0u, 0u};
+                  }
+              }
+            }
             if constexpr (EPI == EPI_RESID_F32) {
               if (a.Rf == nullptr) {
 #pragma unroll
@@ -789,6 +858,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                   }
               }
             }
+            uint2 gpq_o0 = make_uint2(0u, 0u), gpq_o1 = make_uint2(0u, 0u);
 #pragma unroll
             for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
@@ -801,6 +871,36 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                   if (out == 0) {
                     gelu_tail2(y0, y1); gelu_tail2(y2, y3);
                   }
+                }
+                if constexpr (EPI == EPI_GELU_GP) {
+                  float d0, d1, d2, d3;
+                  gelu_tail2_gp(y0, y1, d0, d1); gelu_tail2_gp(y2, y3, d2, d3);
+                  // quads g = 2 j (features +0..3 / +4..7 of octet 2 j for hi = 0 / 1) and g = 2 j + 1 of one token: after the
+                  // swaps lane (li, 0) owns octet 2 j, lane (li, 1) octet 2 j + 1 -- 512 contiguous bytes per half-wave
+                  uint2& dq = (g & 1) ? gpq_o1 : gpq_o0;
+                  dq.x = pack_bf16x2(d0, d1);
+                  dq.y = pack_bf16x2(d2, d3);
+                  if (g & 1) {
+                    const auto sx = __builtin_amdgcn_permlane32_swap(gpq_o0.x, gpq_o1.x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(gpq_o0.y, gpq_o1.y, false, false);
+                    u32x4_t q4;
+                    q4.x = sx[0]; q4.y = sy[0]; q4.z = sx[1]; q4.w = sy[1];
+                    if (gp_ok && (full_n || f < a.N))
+                      store16<true>(gp_blk + (int64_t)(mt * 4 + (g & 2) + we.hi) * 256, q4);
+                  }
+                }
+                if constexpr (EPI == EPI_MUL_GP) {
+                  // the inverse of the swaps above hands each lane its two quads of the octet pair back
+                  if (!(g & 1)) {
+                    const u32x4_t q4 = gpq[mt][g >> 1];
+                    const auto sx = __builtin_amdgcn_permlane32_swap(q4.x, q4.z, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(q4.y, q4.w, false, false);
+                    gpq_o0 = make_uint2(sx[0], sy[0]);
+                    gpq_o1 = make_uint2(sx[1], sy[1]);
+                  }
+                  const uint2 dq = (g & 1) ? gpq_o1 : gpq_o0;
+                  y0 *= __uint_as_float(dq.x << 16); y1 *= __uint_as_float(dq.x & 0xffff0000u);
+                  y2 *= __uint_as_float(dq.y << 16); y3 *= __uint_as_float(dq.y & 0xffff0000u);
                 }
                 if constexpr (EPI == EPI_RESID_F32) {
                   if (a.drop.thresh) {   // workgroup-uniform: hidden dropout of the training forward (BertSelfOutput / BertOutput)

@@ -68,6 +68,10 @@ inline int64_t g_gemm_tile_policy = 0;
 // convdr_set_option "attn_bwd_fused": 1 (default) = sequences of at most 256 tokens take k_attention_bwd_fused (dQ, dK, dV in one
 // workgroup per (sequence, head)); 0 = always the dQ kernel + the dK / dV kernel (tests and A/B runs exercise both)
 inline int64_t g_attn_bwd_fused = 1;
+// convdr_set_option "gelu_gp": 1 (default) = the training forward's FFN1 writes gelu'(pre-activation) (EPI_GELU_GP) and the backward's
+// FFN2 data-gradient GEMM multiplies by it in its epilogue (EPI_MUL_GP); 0 = the round-2..4 form (pre-activation saved, separate
+// k_dgelu_colsum pass).  Read by the forward AND its backward: change it only between steps.
+inline int64_t g_gelu_gp = 1;
 struct TileCost { double step_us, epi_us; int per_cu; };
 inline double gemm_tile_cost(int64_t tiles, int nk, const TileCost& c) {
   const int64_t slots = (int64_t)device_cu_count() * c.per_cu;
@@ -77,7 +81,7 @@ template <int EPI>
 inline int launch_gemm(GemmArgs a, hipStream_t st, const char* prof_name) {
   CONVDR_REQUIRE(a.K % GEMM_BK == 0 && a.N % 4 == 0, "gemm: need K %% 64 == 0 and N %% 4 == 0 (K=%d N=%d)", a.K, a.N);
   if (EPI == EPI_QKV) CONVDR_REQUIRE(a.H % 128 == 0 && a.ldt % 8 == 0, "gemm: fused QKV needs hidden %% 128 == 0 (%d)", a.H);
-  if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_GELU_SAVE || EPI == EPI_GELU_BLK)
+  if (EPI == EPI_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_GELU_SAVE || EPI == EPI_GELU_BLK || EPI == EPI_GELU_GP || EPI == EPI_MUL_GP)
     CONVDR_REQUIRE(a.N % 8 == 0, "gemm: bf16 outputs are stored 16 bytes at a time, need N %% 8 == 0 (N=%d)", a.N);
   const bool fits = a.N % 256 == 0 && (EPI != EPI_QKV || a.H % 256 == 0);
   int splits = 1;
@@ -85,7 +89,8 @@ inline int launch_gemm(GemmArgs a, hipStream_t st, const char* prof_name) {
   const int64_t tiles256 = (int64_t)(a.N / 256) * ceil_div64(a.rows, 256) * splits;
   static const int force128 = getenv("CONVDR_DBG_TILE128") ? atoi(getenv("CONVDR_DBG_TILE128")) : 0;
   static const int min256 = getenv("CONVDR_TILE256_MIN_TILES") ? atoi(getenv("CONVDR_TILE256_MIN_TILES")) : 192;   // A/B knob
-  constexpr bool WIDE_OK = EPI == EPI_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU_SAVE || EPI == EPI_GELU_BF16 || EPI == EPI_F32;
+  constexpr bool WIDE_OK = EPI == EPI_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_GELU_SAVE || EPI == EPI_GELU_BF16 || EPI == EPI_F32 ||
+                           EPI == EPI_GELU_GP || EPI == EPI_MUL_GP;
   int choice = (fits && tiles256 >= min256) ? 256 : 128;
   if (fits && !force128 && g_gemm_tile_policy == 1) choice = 256;
   else if (fits && !force128 && g_gemm_tile_policy == 3) choice = 128;

@@ -151,7 +151,12 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
 // fork() makes the side stream wait for what the main stream has enqueued so far (the layer's activation gradients);
 // nothing on the main stream ever waits for the side stream before the final join, because every operand the branch
 // reads lives in a per-layer buffer (LayerBwd / LayerSave) and its scratch (slab, the bias part of `part`) is its own.
-static hipStream_t g_ext_side = nullptr;
+static hipStream_t g_ext_side[16] = {};   // per device, like WgradFork::get(): convdr_train_set_side_stream
+static int cur_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  return dev;
+}
 
 // Timing-only experiments (`make TRACE=1` library only: the results are garbage): CONVDR_DBG_SKIP drops whole classes of
 // launches -- 1 gelu', 2 LayerNorm backward, 4 forward attention, 8 weight gradients, 16 attention backward, 64 forward
@@ -186,7 +191,7 @@ struct WgradFork {
       // (10.7 -> 12.4 ms per step depending on nothing but how many streams the process had used before,
       // tools/dbg/stream_queue_probe.py): the host may hand in a stream it has verified to run concurrently with the main
       // one (convdr_train_set_side_stream; train.py:_aux_streams does that once per process).
-      if (g_ext_side) side = g_ext_side;
+      if (g_ext_side[cur_device_slot()]) side = g_ext_side[cur_device_slot()];
       else CONVDR_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
       CONVDR_CHECK_HIP(hipEventCreateWithFlags(&prod, hipEventDisableTiming));
       CONVDR_CHECK_HIP(hipEventCreateWithFlags(&fin, hipEventDisableTiming));
@@ -520,7 +525,10 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
     CONVDR_CHECK_LAUNCH("k_layernorm");
     g = GemmArgs{};
     g.rows = rows; g.W = (const bf16_t*)lw->w1; g.X = s.X1; g.N = I; g.K = H; g.bias = lw->b1; g.Cb = s.Hm; g.Cb2 = s.Hpre;
-    if (int e = launch_gemm<EPI_GELU_SAVE>(g, st, "gemm_ffn1")) return e;
+    // (gelu_gp: s.Hpre holds gelu'(pre-activation) in the blocked layout instead of the pre-activation itself)
+    if (g_gelu_gp) {
+      if (int e = launch_gemm<EPI_GELU_GP>(g, st, "gemm_ffn1")) return e;
+    } else if (int e = launch_gemm<EPI_GELU_SAVE>(g, st, "gemm_ffn1")) return e;
     g = GemmArgs{};
     g.rows = rows; g.W = (const bf16_t*)lw->w2; g.X = s.Hm; g.N = H; g.K = I; g.bias = lw->b2; g.Cf = s.Y2; g.R = s.X1;
     g.drop = drop_site(dseed, DROP_SITE_FFN_OUT, l, p_hid);
@@ -626,8 +634,13 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       other = cur_f;
       // ---- FFN2: Y2 = Hm W2^T + b2 + X1:  dHpre = (dY2 W2) * gelu'(Hpre) ----
       g.rows = rows; g.W = (const bf16_t*)lt->w2_t; g.X = d.dYb; g.N = I; g.K = H; g.Cb = d.dHpre;
-      if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
-      {
+      if (g_gelu_gp) {
+        // the forward left gelu'(Hpre) behind (EPI_GELU_GP): multiplied in this GEMM's epilogue; the FFN1 bias gradient --
+        // column sums of dHpre -- joins the QKV bias sums on the weight-gradient stream (below)
+        g.Gp = s.Hpre;
+        if (int e = launch_gemm<EPI_MUL_GP>(g, st, "gemm_dgrad")) return e;
+      } else {
+        if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
         ProfScope prof("dgelu_colsum", st);
         if (!(dbg_skip() & 1))
           hipLaunchKernelGGL(k_dgelu_colsum, dim3((I + 255) / 256, chunks), dim3(256), 0, st, d.dHpre, s.Hpre, rows, I, d.part_b1);
@@ -708,6 +721,8 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       if (int e = wf.fork()) return e;
     {
       hipLaunchKernelGGL(k_colsum_bf16, dim3((3 * H + 255) / 256, chunks), dim3(256), 0, ss, d.dQKV, rows, 3 * H, d.part_bqkv);
+      if (!last && g_gelu_gp)
+        hipLaunchKernelGGL(k_colsum_bf16, dim3((I + 255) / 256, chunks), dim3(256), 0, ss, d.dHpre, rows, I, d.part_b1);
       CONVDR_CHECK_LAUNCH("k_colsum_bf16");
       ReduceList r;
       if (!last) r.add_ln(d.part_ln2, blocks_ln2, H, lg->b2, lg->ln2_g, lg->ln2_b);
@@ -770,10 +785,19 @@ extern "C" int convdr_wgrad(const void* dy, int N, int64_t ld_dy, const void* x,
   return wgrad_batch(&it, 1, rows, slab, slab_elems, (hipStream_t)stream);
 }
 
+// The stream of the current device's weight-gradient branches.  Re-settable (round 5: train.py's step watchdog moves the
+// branch to another stream when the step is seen to have lost its overlap): every convdr_encoder_backward ends with the
+// caller's stream waiting for the side stream (WgradFork::join), so BETWEEN two backward calls enqueued on one stream nothing
+// is pending that a later launch on the new stream could overtake.  The stream must belong to the current device.
 extern "C" int convdr_train_set_side_stream(convdr_stream_t stream) {
+  CONVDR_REQUIRE(stream != nullptr, "convdr_train_set_side_stream: null stream");
+  int sdev = -1, cdev = -2;
+  CONVDR_CHECK_HIP(hipGetDevice(&cdev));
+  if (hipStreamGetDevice((hipStream_t)stream, &sdev) != hipSuccess) { (void)hipGetLastError(); sdev = cdev; }
+  CONVDR_REQUIRE(sdev == cdev, "convdr_train_set_side_stream: the stream belongs to device %d, the current device is %d", sdev, cdev);
   WgradFork& wf = WgradFork::get();
-  CONVDR_REQUIRE(!wf.ok || wf.side == (hipStream_t)stream, "convdr_train_set_side_stream: the weight-gradient stream of this device is already in use");
-  g_ext_side = (hipStream_t)stream;
+  g_ext_side[cur_device_slot()] = (hipStream_t)stream;
+  if (wf.ok) wf.side = (hipStream_t)stream;
   return 0;
 }
 

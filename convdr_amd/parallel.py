@@ -133,28 +133,44 @@ def train_sampler(dataset, shuffle=True, seed=0, drop_last=False, rank=None, wor
     return DistributedSampler(dataset, num_replicas=W, rank=r, shuffle=shuffle, seed=seed, drop_last=drop_last)
 
 
-def shard_batch(batch, rank=None, world=None):
+def shard_sizes(n, world):
+    """Chunk sizes of a batch of n scattered over `world` replicas the way nn.DataParallel does (torch.chunk semantics:
+    every replica ceil(n / W) samples until the batch runs out -- the last one short, possibly some empty)."""
+    c = -(-int(n) // int(world))
+    return [max(0, min(c, int(n) - r * c)) for r in range(int(world))]
+
+
+def shard_batch(batch, rank=None, world=None, return_weight=False):
     """This rank's contiguous slice of a GLOBAL batch (a tuple / list / dict of tensors or arrays whose first dimension is
-    the batch): what nn.DataParallel's scatter hands replica `rank` (run_convdr_train.py:77-78).  For drivers that keep
+    the batch): what nn.DataParallel's scatter hands replica `rank` (run_convdr_train.py:52,77-78).  For drivers that keep
     the reference's single global batch (e.g. to replay one of its runs); a DistributedSampler run never needs it.
-    The batch size must be divisible by the world size (DataParallel gives the last replica a short chunk; the step's
-    mean-over-ranks loss is only the global mean for equal chunks)."""
+    A batch that does not divide over the ranks is cut like DataParallel cuts it (`shard_sizes`: the last replica short).
+    The reference computes its mean losses over the gathered outputs of ALL replicas, so with per-rank mean losses the
+    global gradient is sum_r (n_r / n) grad_r: return_weight=True also returns n_r W / n, the factor `train_step(...,
+    loss_weight=)` multiplies this rank's loss by before the backward (the all-reduce sums and 1 / W rides on the clip
+    pass).  A rank left without samples raises: it would still have to join the step's collectives."""
     W = _world() if world is None else int(world)
     r = (dist.get_rank() if W > 1 else 0) if rank is None else int(rank)
     if W == 1:
-        return batch
+        return (batch, 1.0) if return_weight else batch
+    seen = []
 
     def cut(x):
         import numpy as np
         if not isinstance(x, (torch.Tensor, np.ndarray, list, tuple)):      # scalars, None, strings, nested dicts: replicated
             return x
         n = len(x)
-        if n % W:
-            raise ValueError("shard_batch: batch of %d does not divide over %d ranks" % (n, W))
-        return x[r * (n // W):(r + 1) * (n // W)]
-    if isinstance(batch, dict):
-        return {k: cut(v) for k, v in batch.items()}
-    return type(batch)(cut(x) for x in batch)
+        sizes = shard_sizes(n, W)
+        if sizes[r] == 0:
+            raise ValueError("shard_batch: a batch of %d leaves rank %d of %d without samples" % (n, r, W))
+        seen.append((n, sizes[r]))
+        b = sum(sizes[:r])
+        return x[b:b + sizes[r]]
+    out = {k: cut(v) for k, v in batch.items()} if isinstance(batch, dict) else type(batch)(cut(x) for x in batch)
+    if not return_weight:
+        return out
+    n, nr = seen[0] if seen else (1, 1)
+    return out, nr * W / float(n)
 
 
 class DataParallelStudent:
@@ -162,13 +178,30 @@ class DataParallelStudent:
 
     def __init__(self, model, group=None, broadcast=True):
         self.model, self.group = model, group
+        self.broadcast_collectives = 0
         if broadcast and _world(group) > 1:   # what the DDP constructor does (gen_passage_embeddings.py:64-69)
+            # one collective for everything that lives in the flat parameter arena (train.flatten_parameters: ~200 tensors,
+            # 0.5 GB for roberta-base), one each for whatever does not (buffers, un-flattened models)
+            m = model.module if hasattr(model, "module") else model
+            info = getattr(getattr(m, "roberta", None), "_flat", None)
+            done = set()
+            if info is not None:
+                dist.broadcast(info["P"], 0, group=group)
+                self.broadcast_collectives += 1
+                done = {id(p) for p in info["params"]}
             for t in list(model.parameters()) + list(model.buffers()):
-                dist.broadcast(t.data, 0, group=group)
+                if id(t) not in done:
+                    dist.broadcast(t.data, 0, group=group)
+                    self.broadcast_collectives += 1
             # the writes went through .data (no version bump): drop the packed bf16 copies made before them
             for mod in model.modules():
                 if hasattr(mod, "invalidate_packed"):
                     mod.invalidate_packed()
+        for p in model.parameters():          # a training entry point: the step's auxiliary streams are picked here
+            if p.is_cuda:
+                from .train import reserve_streams
+                reserve_streams(p.device)
+            break
 
     def _layer_buckets(self, n_flat):
         """[(begin, end)] of each encoder layer's gradients in the flat arena (train._tower_params order: 5 embedding
@@ -218,12 +251,11 @@ class DataParallelStudent:
             from . import _lib
             L = _lib.lib()
             cur = torch.cuda.current_stream(flat.device)
-            if getattr(self, "_comm", None) is None:
-                # a stream that has been seen to run beside the compute stream (train._aux_streams: HIP's stream -> hardware
-                # queue multiplexing decides whether the collectives overlap the backward or serialise with it)
-                from .train import _aux_streams
-                self._comm = _aux_streams(flat.device)[2]
-            comm, works = self._comm, []
+            # a stream that has been seen to run beside the compute stream (train._StreamSets: HIP's stream -> hardware queue
+            # multiplexing decides whether the collectives overlap the backward or serialise with it; the step watchdog may
+            # move the set between steps, so it is looked up per call)
+            from .train import _aux_streams
+            comm, works = _aux_streams(flat.device)[2], []
             with torch.cuda.device(flat.device), torch.cuda.stream(comm):
                 for l in reversed(range(len(buckets))):
                     _lib.check(L.convdr_backward_wait_layer(l, comm.cuda_stream), "convdr_backward_wait_layer")

