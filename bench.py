@@ -45,6 +45,41 @@ def _init_group(dev):
         dist.init_process_group(backend)
 
 
+def _comm_timed(fn, dev, reps=5):
+    """ms per call of `fn` (a collective or a short chain around one): barrier, then `reps` calls between two events on the
+    current stream, max over ranks."""
+    import torch
+    import torch.distributed as dist
+    fn()
+    torch.cuda.synchronize()
+    dist.barrier()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    t = torch.tensor([a.elapsed_time(b) / reps], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
+def _comm_common(dev, el):
+    """What every N > 1 line says about its transport: the backend, the ranks the collective library really connected
+    (an all-reduce of ones), and every rank's own clock around the timed region (min / max: a straggler shows here)."""
+    import torch
+    import torch.distributed as dist
+    W = dist.get_world_size()
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    els = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(W)]
+    dist.all_gather(els, torch.tensor([el], device=dev, dtype=torch.float64))
+    els = [e.item() for e in els]
+    return {"backend": dist.get_backend(), "world_size": W, "rccl_ranks_seen": int(round(ones.item())),
+            "per_rank_elapsed_s": {"min": min(els), "max": max(els), "all": els},
+            "shared_gpu_rehearsal": bool(os.environ.get("CONVDR_BENCH_SHARE_GPU"))}
+
+
 def live_traffic(kname, timeout=240):
     """HBM-side bytes per launch of the roofline kernel measured IN THIS RUN: two child passes of this script (one step, no
     extras) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only: MI355X_MICROARCH.md,
@@ -80,6 +115,42 @@ def live_traffic(kname, timeout=240):
         finally:
             shutil.rmtree(td, ignore_errors=True)
     return got
+
+
+def live_kernel_trace(kname, timeout=300):
+    """Average dispatch duration (us) of the roofline kernel ON THE PROFILER'S CLOCK, measured in this run: one child pass
+    of this script (4 steps after 2 warm-up steps, no extras) under `rocprofv3 --kernel-trace` -- the figure a reader
+    reproduces with `rocprofv3 --kernel-trace --stats -- python bench.py` (profiles/rNN_bench_default.kernel_stats.txt).
+    The first dispatches (warm-up) are dropped.  (avg_us, dispatches) or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    td = tempfile.mkdtemp(prefix="convdr_kt_")
+    try:
+        subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "-d", td, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                        "--steps", "4", "--warmup", "2", "--passages", "65536", "--queries", "64", "--no-cpu-baseline", "--no-extras"],
+                       cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       timeout=timeout, check=True)
+        rows = []
+        for path in glob.glob(os.path.join(td, "**", "*kernel_trace.csv"), recursive=True):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if kname in row["Kernel_Name"]:
+                        rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+        rows.sort()
+        rows = rows[len(rows) // 3:]                 # the warm-up steps' dispatches (2 of 6 steps)
+        if not rows:
+            return None
+        return sum(e - b for b, e in rows) / len(rows) / 1e3, len(rows)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
 
 
 def _power_state():
@@ -165,10 +236,13 @@ def cpu_baseline(nq, d, k, L, budget_s=9.0):
     return out
 
 
-def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=True, dropout=0.1):
+def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=True, dropout=0.1, teacher_cache=False):
     """configs[2]: run_convdr_train.py KD-only loop (MSE teacher-student), batch 64, seq 256, synthetic turns.
     dropout: hidden / attention-probability dropout of the student (the reference trains with model.train() and the
     released configs' 0.1, run_convdr_train.py:107); the teacher is in eval mode.
+    teacher_cache: the frozen teacher's target embeddings come from a train.TeacherEmbeddingCache filled once before the timed
+    region (what a second epoch, or a precompute pass, gives a real run) instead of a teacher forward per step -- numerically
+    identical; NOT the reference flow, reported as its own leg.
     Returns the JSON-able result dict on rank 0 (None elsewhere); the caller owns the process group."""
     import numpy as np
     import torch
@@ -203,8 +277,16 @@ def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=
         # 4-tensor batch, lengths recovered from the device masks)
         batches.append((ci, cm, ti, tm) if os.environ.get("CONVDR_BENCH_NO_HOST_LENS") else (ci, cm, ti, tm, cl, tl))
 
+    cache, sample_ids = None, [list(range(b * Bt, (b + 1) * Bt)) for b in range(4)]
+    if teacher_cache:
+        cache = TR.TeacherEmbeddingCache(4 * Bt, dim=D_OUT, device=dev)
+        for b in range(4):
+            kw = {} if len(batches[b]) < 6 else {"seq_lens": batches[b][5]}
+            cache.fill(teacher, sample_ids[b], batches[b][2], batches[b][3], **kw)
+
     def step(i):
-        return TR.train_step(targs, student, teacher, opt, sched, batches[i % 4], ddp=ddp, force_overlap=dist_on and world == 1)
+        kw = {"teacher_embs": cache.lookup(sample_ids[i % 4])} if cache is not None else {}
+        return TR.train_step(targs, student, teacher, opt, sched, batches[i % 4], ddp=ddp, force_overlap=dist_on and world == 1, **kw)
 
     def sync_all():
         if dist_on:
@@ -243,7 +325,36 @@ def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=
             if cnt:
                 kern[nme] = {"ms_per_step": ms / prof_steps, "launches_per_step": cnt / prof_steps}
         L_.convdr_prof_enable(0)
+    comm = None
     if dist_on:
+        # ---- what the N > 1 line needs to explain itself (outside the timed region) ----
+        comm = _comm_common(dev, el)
+        # the gradient all-reduce that is NOT hidden under the backward: the same steps without the collectives (ddp = None:
+        # every rank trains alone -- timing only, the replicas diverge from here on, which is why this comes last)
+        sync_all()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            TR.train_step(targs, student, teacher, opt, sched, batches[i % 4])
+        sync_all()
+        el_no = time.perf_counter() - t1
+        t2 = torch.tensor([el_no], device=dev, dtype=torch.float64)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        flat = student.roberta._flat["P"]
+        bk = ddp._layer_buckets(flat.numel())
+        comm["gradient_allreduce"] = {
+            "exposed_ms_per_step": (el - t2.item()) / steps * 1e3,
+            "ms_per_step_with": el / steps * 1e3, "ms_per_step_without_collectives": t2.item() / steps * 1e3,
+            "path": getattr(ddp, "last_path", None),
+            "collectives_per_step": (len(bk) + 2) if bk else 1,
+            "bytes_per_layer_collective": int((bk[0][1] - bk[0][0]) * 4) if bk else None,
+            "bytes_embeddings_collective": int(bk[0][0] * 4) if bk else None,
+            "bytes_head_collective": int((flat.numel() - bk[-1][1]) * 4) if bk else None,
+            "bytes_total_per_step": int(flat.numel() * 4)}
+        big = torch.empty(flat.numel(), dtype=torch.float32, device=dev)
+        comm["gradient_allreduce"]["one_collective_alone_ms"] = _comm_timed(lambda: dist.all_reduce(big), dev, reps=3)
+        comm["gradient_allreduce"]["one_collective_alone_GB_per_s_algorithmic"] = flat.numel() * 4 / 1e9 / (comm["gradient_allreduce"]["one_collective_alone_ms"] / 1e3)
+        comm["constructor_broadcast_collectives"] = ddp.broadcast_collectives
+        del big
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
@@ -258,10 +369,12 @@ def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=
         "value": sps, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16 compute, fp32 master weights / optimizer", "data": "synthetic OR-QuAC-shaped turns (ragged)",
-        "config": {"workload": "configs[2] train_kd", "batch_per_gpu": Bt, "student_seq": Ls, "teacher_seq": Lt,
+        "config": {"workload": "configs[2] train_kd" + (" with the frozen teacher's target embeddings looked up from a cache (not the reference flow)" if teacher_cache else ""),
+                   "batch_per_gpu": Bt, "student_seq": Ls, "teacher_seq": Lt,
                    "parallelism": "dp%d" % world, "mean_real_student_tokens": real_tokens, "student_dropout": float(dropout)},
         "final_loss": float(loss),
         "stream_selfcheck": dict(TR.stream_decisions(dev), settle_steps=settle_steps),
+        "comm": comm,
         "TFLOPs_dense_padded_count": sps / world * flop_dense / Bt / 1e12,
         "TFLOPs_real_token_count_linear_only": flop_real * steps / el / 1e12,
         "frac_of_bf16_mfma_peak_real_tokens": flop_real * steps / el / 1e12 / MFMA_BF16_PEAK_TFLOPS / world,
@@ -335,7 +448,8 @@ def main_train(args):
     dist_on = world > 1 or bool(os.environ.get("CONVDR_BENCH_FORCE_DIST"))   # (the latter: 1-rank rehearsal of the N > 1 path)
     if dist_on:
         _init_group(dev)
-    out = train_kd_measure(dev, rank, world, dist_on, args.steps, args.warmup, args.train_batch, dropout=args.train_dropout)
+    out = train_kd_measure(dev, rank, world, dist_on, args.steps, args.warmup, args.train_batch, dropout=args.train_dropout,
+                           teacher_cache=args.teacher_cache)
     if dist_on:
         dist.destroy_process_group()
     if out is not None:
@@ -701,6 +815,9 @@ def main():
                     help="encode_search = BASELINE configs[1] (the headline line); train_kd = configs[2]: KD-only "
                          "(MSE teacher-student) training steps, batch 64, student seq 256, teacher seq 64")
     ap.add_argument("--train-batch", type=int, default=64)
+    ap.add_argument("--teacher-cache", action="store_true",
+                    help="train_kd: the frozen teacher's target embeddings come from a train.TeacherEmbeddingCache (a second "
+                         "epoch / precompute pass) instead of a teacher forward per step; not the reference flow")
     ap.add_argument("--train-dropout", type=float, default=0.1,
                     help="student dropout of the train_kd workload (the reference's training configuration: 0.1)")
     args = ap.parse_args()
@@ -812,7 +929,21 @@ def main():
         if cnt:
             spans[name] = (ms / cnt, cnt, ms / args.steps)
     L_.convdr_prof_enable(0)
+    comm = None
     if dist_on:
+        # ---- what the N > 1 line needs to explain itself (outside the timed region): each exchange step timed on its own ----
+        comm = _comm_common(dev, el)
+        force = world == 1
+        with torch.no_grad():
+            Qall = parallel.all_gather_rows(Q_local, force=force)[:nq]
+            Dl, Il = index.search_tensors(Qall, k)
+            idl = embid[Il.clamp(min=0)]
+            comm["query_allgather"] = {"ms": _comm_timed(lambda: parallel.all_gather_rows(Q_local, force=force), dev),
+                                       "bytes_per_rank": int(Q_local.numel() * 4), "bytes_gathered": int(Q_local.numel() * 4 * world)}
+            comm["topk_allgather_and_merge"] = {"ms": _comm_timed(lambda: parallel.exchange_topk(Dl, idl, k, force=force), dev),
+                                                "bytes_per_rank": int(nq * k * 12), "bytes_gathered": int(nq * k * 12 * world),
+                                                "merge_launches": world - 1}
+            comm["local_certified_search_ms"] = _comm_timed(lambda: index.search_tensors(Qall, k), dev, reps=3)
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
@@ -849,6 +980,7 @@ def main():
                       "scan": "fp16 MFMA (v_mfma_f32_32x32x16_f16), eps = 1.07e-3 |q| max|p - centre|; certified by the fp64 re-score",
                       "candidates_per_query": {"emitted": emitted, "rescored_band": band}},
         "kernels": kern,
+        "comm": comm,
         "roofline": {"kernel": "k_gemm<EPI_GELU_BLK> (FFN1 [%d x 768] x [768 x 3072], bias + GELU + blocked bf16 output fused)" % rows, "bound": "mfma",
                      "achieved": dom_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": dom_tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None},
@@ -871,7 +1003,7 @@ def main():
     roof["power"] = _power_state() if not args.no_extras else None     # (not in the profiler's child passes: rocm-smi is an exec)
     try:
         kname = "k_gemm<8, convdr::TileCfg<2, 4, 4, 2>"      # EPI_GELU_BLK on 256 x 256 tiles (k_gemm<1, ..> before round 3)
-        rnd = next((r for r in ("r04", "r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r + "_bench_default.kernel_stats.txt"))), "r02")
+        rnd = next((r for r in ("r05", "r04", "r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r + "_bench_default.kernel_stats.txt"))), "r02")
         if EB * SL == 262144:
             for ln in open(os.path.join(ROOT, "profiles", rnd + "_bench_default.kernel_stats.txt")):
                 if kname in ln:
@@ -891,7 +1023,22 @@ def main():
                                             % (rnd, rows * H * 2 + rows * I * 2 + H * I * 2))
     except Exception:
         pass
+    roof["frac_hipevent"] = roof["frac"]
+    roof["frac_source"] = "hipEvent pairs on the launch stream around every timed FFN1 launch (no profiler pass was possible in this run)"
     if world == 1 and not dist_on and not args.no_extras and EB * SL == 262144:
+        # `achieved` / `frac` = the kernel's average dispatch duration on the PROFILER's clock, measured in this run by a child
+        # pass under rocprofv3 --kernel-trace: the number `rocprofv3 --kernel-trace --stats -- python bench.py` reproduces
+        # (profiles/r05_bench_default.kernel_stats.txt).  The hipEvent figure of the timed region stays beside it
+        # (achieved_hipevent / frac_hipevent): back-to-back persistent GEMMs read 3-11 % longer under the tracer.
+        kt = live_kernel_trace("k_gemm<8, convdr::TileCfg<2, 4, 4, 2>")
+        if kt is not None:
+            roof["rocprof_live_avg_us"], roof["rocprof_live_dispatches"] = kt
+            roof["achieved"] = gemm_flop[dom] / kt[0] / 1e6
+            roof["frac"] = roof["achieved"] / MFMA_BF16_PEAK_TFLOPS
+            roof["frac_source"] = ("average dispatch duration of the kernel in a child pass of this script under rocprofv3 --kernel-trace "
+                                   "(%d dispatches, measured in this run); hipEvent figure of the timed region: achieved_hipevent / frac_hipevent" % kt[1])
+            if clock_mhz:
+                roof["frac_at_delivered_clock_hipevent"] = roof["frac_at_delivered_clock"]
         # the roofline kernel's traffic, measured in this run (the committed PMC figure above stays beside it)
         lt = live_traffic("k_gemm<8, convdr::TileCfg<2, 4, 4, 2>")
         if lt is not None:
@@ -907,11 +1054,13 @@ def main():
             del index, building, model
             torch.cuda.empty_cache()
             keys = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "final_loss", "TFLOPs_dense_padded_count",
-                    "TFLOPs_real_token_count_linear_only", "frac_of_bf16_mfma_peak_real_tokens", "kernels")
+                    "TFLOPs_real_token_count_linear_only", "frac_of_bf16_mfma_peak_real_tokens", "kernels", "stream_selfcheck")
             kd = train_kd_measure(dev, 0, 1, False, 10, 3, 64, dropout=0.1)       # the reference's training configuration
             line["train_kd"] = {kk: kd[kk] for kk in keys}
             kd0 = train_kd_measure(dev, 0, 1, False, 10, 3, 64, with_kernels=False, dropout=0.0)
             line["train_kd_no_dropout"] = {kk: kd0[kk] for kk in ("value", "unit", "ms_per_step", "config", "final_loss")}
+            kdc = train_kd_measure(dev, 0, 1, False, 10, 3, 64, with_kernels=False, dropout=0.1, teacher_cache=True)
+            line["train_kd_teacher_cache"] = {kk: kdc[kk] for kk in ("value", "unit", "ms_per_step", "config", "final_loss")}
             line["train_rank"] = train_rank_measure(dev)
             line["encode_loop"] = extras_encode_loop(dev, random_rdot_model().to(dev).eval())
             line["registry"] = extras_registry(dev)

@@ -533,6 +533,18 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
   auto decode = [&](uint32_t i) {
     const uint32_t logical = chunk_base + i;
     int tt = logical / a.tilesN, tn = logical - tt * a.tilesN;
+#ifdef CONVDR_GEMM_PANEL   // A/B builds only (make VARIANT=panelN EXTRA=-DCONVDR_GEMM_PANEL=N; profiles/r05_gemm_raster_ab.txt):
+    // weight-set-aware raster -- an XCD sweeps its token tiles once per PANEL of CONVDR_GEMM_PANEL feature tiles, so that the
+    // weights its 32 workgroups have live at any time are PANEL tiles (6 x 393 KB = 2.4 MB of FFN1's 4.7 MB) instead of all
+    // of them, at the price of re-reading the XCD's activation tiles once per panel.  Shapes whose tile counts do not divide
+    // keep the default order.
+    if (a.tilesN % CONVDR_GEMM_PANEL == 0 && a.tilesN > CONVDR_GEMM_PANEL && (a.tilesT & 7) == 0) {
+      const uint32_t nT = a.tilesT >> 3, per_panel = CONVDR_GEMM_PANEL * nT;      // token tiles of this XCD's chunk
+      const uint32_t panel = i / per_panel, r = i - panel * per_panel;
+      tt = xcd * nT + r / CONVDR_GEMM_PANEL;
+      tn = panel * CONVDR_GEMM_PANEL + r % CONVDR_GEMM_PANEL;
+    }
+#endif
     if (a.dbg_same_tile) { tt = 0; tn = 0; }
     Coord c;
     c.t0 = (int64_t)tt * T::TL;      // the launcher lays tiles out as [tilesT][tilesN] with TR == TL
@@ -653,6 +665,36 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
                                (a.trace && trace_tile == 8) ? a.trace + ((size_t)blockIdx.x * 64 + 56) * 16 : nullptr);
     }
     landed = false;
+    // EPI_MUL_GP: the tile's gelu' image (128 KB from HBM, written by the forward milliseconds ago) is fetched HERE, ahead of
+    // the next tile's prologue in the vector-memory queue and with the fragment registers of the main loop free to hold it
+    // (64 VGPRs for a 256 x 256 tile): its round trip passes under the prologue issue and the epilogue's first barrier.
+    // Fetched inside the epilogue, one 32-token block at a time, the same loads left the matrix pipe idle for two HBM round
+    // trips per tile: the dgrad GEMM gained exactly the 46 us per layer the separate gelu' pass had cost (step unchanged).
+    constexpr bool GP_PRE = EPI == EPI_MUL_GP;
+    u32x4_t gp_pre[GP_PRE ? T::NT : 1][GP_PRE ? T::MT : 1][2];
+    if constexpr (GP_PRE) {
+      int tid_p = threadIdx.x;
+      asm volatile("" : "+v"(tid_p));
+      const WavePos<T> wp(tid_p);
+      const int64_t rows32p = (a.rows + 31) & ~(int64_t)31;
+      // (every load is UNCONDITIONAL -- blocks past the end of the matrix read the image's first block, their products are
+      //  never stored: behind a lane condition hipcc put each load in its own branch with s_waitcnt vmcnt(0) at the join,
+      //  sixteen serialised HBM round trips per tile)
+#pragma unroll
+      for (int nt = 0; nt < T::NT; ++nt) {
+        const int64_t tb = c.t0 + (wp.wl * T::NT + nt) * 32;
+        const int64_t tbc = tb < rows32p ? tb : 0;
+#pragma unroll
+        for (int mt = 0; mt < T::MT; ++mt) {
+          const int f0 = c.n0 + wp.wr * T::MT * 32 + mt * 32;
+          const int f0c = f0 < a.N ? f0 : 0;
+          const bf16_t* blk = a.Gp + ((tbc >> 5) * (a.N >> 3) + (f0c >> 3)) * 256 + wp.li * 8;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            gp_pre[nt][mt][j] = __builtin_nontemporal_load((const u32x4_t*)(blk + (int64_t)(2 * j + wp.hi) * 256));
+        }
+      }
+    }
     // hipcc does not see the main loop's inline-asm waits: make it retire the bias loads HERE (a no-op wait, nothing
     // is in flight), not at their first use further down
     asm volatile("" : "+v"(bias_next));
@@ -831,15 +873,11 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm(const GemmArgs a)
               bf16_t* img = EPI == EPI_GELU_GP ? a.Cb2 : const_cast<bf16_t*>(a.Gp);
               gp_blk = img + ((tb >> 5) * (a.N >> 3) + ((n0 + we.wr * T::MT * 32) >> 3)) * 256 + we.li * 8;
               gp_ok = tb < rows32;
-              if constexpr (EPI == EPI_MUL_GP) {
+              if constexpr (EPI == EPI_MUL_GP) {   // (fetched right after the main loop: gp_pre)
 #pragma unroll
                 for (int mt = 0; mt < T::MT; ++mt)
 #pragma unroll
-                  for (int j = 0; j < 2; ++j) {
-                    const bool ok = gp_ok && n0 + we.wr * T::MT * 32 + mt * 32 < a.N;
-                    gpq[mt][j] = ok ? __builtin_nontemporal_load((const u32x4_t*)(gp_blk + (int64_t)(mt * 4 + 2 * j + we.hi) * 256))
-                                    : (u32x4_t){0u, 0u, 0u, 0u};
-                  }
+                  for (int j = 0; j < 2; ++j) gpq[mt][j] = gp_pre[nt][mt][j];
               }
             }
             if constexpr (EPI == EPI_RESID_F32) {

@@ -280,12 +280,25 @@ __device__ __forceinline__ int gemm_nt_mainloop(const TileSrc<T>& src, int K, ch
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       if (s + 1 < 4) load_frags(s + 1, (s + 1) & 1);
+#if defined(CONVDR_FRAG_BLOCK) || defined(CONVDR_FRAG_BLOCK_2STAGE)
       __builtin_amdgcn_sched_barrier(0);   // the prefetch stays ahead of this sub-step's MFMAs
+#endif
 #pragma unroll
       for (int i = 0; i < T::MT; ++i)
 #pragma unroll
         for (int j = 0; j < T::NT; ++j)
           acc.c[i][j] = mfma_32x32x16<F16>(fa[s & 1][i], fb[s & 1][j], acc.c[i][j]);
+#if !defined(CONVDR_FRAG_BLOCK) && !defined(CONVDR_FRAG_BLOCK_2STAGE)
+      if (s + 1 < 4) {   // fragment reads of sub-step s + 1 threaded between this sub-step's MFMAs (see the R3 loop below)
+#pragma unroll
+        for (int r = 0; r < T::MT + T::NT && r < T::MT * T::NT; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, T::MT + T::NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, T::MT * T::NT, 0);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     CONVDR_STEP_TRACE(4)
@@ -405,15 +418,34 @@ __device__ __forceinline__ R3Slots gemm_nt_mainloop_r3(const TileSrcAll<T>& src,
     if (r1_deferred && kt == 0 && issue_l) R3Issue<T>::template r<R_AUX>(src.R, 1, sR + (rs == 2 ? 0 : rs + 1) * T::R_BYTES, w.wave);
     if (issue_l) R3Issue<T>::l(src.L, kt + 1, l_dst, w.wave);
     CONVDR_R3_STEP(3)
+    // Round 5: the fragment reads of sub-step s + 1 are THREADED between the MFMAs of sub-step s -- one ds_read_b128 behind
+    // each of the first MT + NT MFMAs (sched_group_barrier) -- instead of issued as a block in front of them.  As a block the
+    // six reads of all eight waves hit the LDS together (48 KB per sub-step at once) and every wave's first MFMA of the
+    // sub-step waited out that queue; threaded, the LDS sees one read per wave per ~32 cycles.  Main loop of the stand-alone
+    // prototype (tools/proto/w16_proto.hip): 2,744 -> 2,569 ticks per K step (2,485 with no fragment reads at all).
+    // CONVDR_FRAG_BLOCK=1 at compile time gives the round-2..4 form back (A/B builds).
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       if (s + 1 < 4) load_frags(s + 1, (s + 1) & 1);
+#ifdef CONVDR_FRAG_BLOCK
       __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int i = 0; i < T::MT; ++i)
 #pragma unroll
         for (int j = 0; j < T::NT; ++j)
           acc.c[i][j] = mfma_32x32x16<F16>(fa[s & 1][i], fb[s & 1][j], acc.c[i][j]);
+#ifndef CONVDR_FRAG_BLOCK
+      if (s + 1 < 4) {
+#pragma unroll
+        for (int r = 0; r < T::MT + T::NT && r < T::MT * T::NT; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, T::MT + T::NT, 0);   // (tiles with fewer MFMAs than reads: the rest of the reads)
+        __builtin_amdgcn_sched_group_barrier(0x008, T::MT * T::NT, 0);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     CONVDR_R3_STEP(4)

@@ -356,6 +356,9 @@ static int wgrad_batch(const WgradItem* it, int count, int64_t rows, float* slab
   }
   // 256 x 256 tiles (half the L2 -> LDS bytes per FLOP of 128 x 128: at two 128-tiles per CU the operand stream, not the
   // matrix pipe, bounded the round-1 kernel) unless a matrix is smaller than a tile
+  // (round 5: 128 x 128 tiles here too -- 64 KB of LDS, so that a weight-gradient workgroup SHARES a compute unit with a
+  //  128 x 128 workgroup of the activation-gradient chain instead of owning it -- measured worse: step 10.3-10.6 vs 9.78 ms,
+  //  the data-gradient GEMMs 3.0 -> 3.6-4.1 ms per step; profiles/r05_ab_wgrad_tile128.txt)
   if (big) return wgrad_launch<Tile256>(it, count, rows, slab, slab_elems, st, tail_split);
   return wgrad_launch<Tile128>(it, count, rows, slab, slab_elems, st, tail_split);
 }

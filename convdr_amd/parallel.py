@@ -96,9 +96,16 @@ def search_sharded_device(index, queries, k, embid, group=None, force=False, cer
     else:
         D, I, status = index.search_device(queries, k)[:3]
     ids = torch.where(I >= 0, embid[I.clamp(min=0)], torch.full_like(I, -1))
+    Dm, Im = exchange_topk(D, ids, k, group=group, force=force)
+    return Dm, Im, status
+
+
+def exchange_topk(D, ids, k, group=None, force=False):
+    """The exchange step of the sharded search on its own (bench.py times it apart from the local search): every rank's
+    certified (scores [nq, k] fp32, record offsets [nq, k] int64) -> ONE all-gather -> device merge -> global (D, offsets)."""
     W = _world(group)
     if W == 1 and not (force and dist.is_initialized()):
-        return D, ids, status
+        return D, ids
     # one collective for both: [nq, k, 3] int32 = (score bits, offset low word, offset high word)
     nq = D.shape[0]
     buf = torch.empty((nq, k, 3), dtype=torch.int32, device=D.device)
@@ -113,8 +120,7 @@ def search_sharded_device(index, queries, k, embid, group=None, force=False, cer
         out = torch.stack(parts)
     D_all = out[..., 0].contiguous().view(torch.float32)
     I_all = out[..., 1:].contiguous().view(torch.int64).view(W, nq, k)
-    Dm, Im = merge_rank_topk(D_all, I_all, k)
-    return Dm, Im, status
+    return merge_rank_topk(D_all, I_all, k)
 
 
 def train_sampler(dataset, shuffle=True, seed=0, drop_last=False, rank=None, world=None):

@@ -43,7 +43,7 @@ class FlatIPIndex:
     add() after the first re-allocates (FAISS semantics need one contiguous block): fine for the reference's one add per
     reset, not for building a 117 GB corpus from slices."""
 
-    def __init__(self, d, device=None, cap=4096, rank_target=0, precision="auto", center=True):
+    def __init__(self, d, device=None, cap=4096, rank_target=0, precision="auto", center=True, prepin=True):
         import torch
         if not torch.cuda.is_available():
             raise _lib.ConvdrError("FlatIPIndex needs a GPU (no CPU fallback)")
@@ -65,12 +65,34 @@ class FlatIPIndex:
         self.stats = {}
         self._s32 = self._s16 = self._slo = None
         self.reset()
+        if prepin:
+            self.prepin_staging()
+
+    def prepin_staging(self, wait=False):
+        """Allocate and page-lock the process-wide staging buffers of the block loader (4 x 64 MB on the GPU's NUMA node, ~60 ms)
+        NOW, on a background thread: the first add() of a block file used to pay for it (19 GB/s against 49 GB/s for every
+        later block; the reference's flow constructs the index, then loads 8 block files: run_convdr_inference.py:353,164-180).
+        Called by the constructor (prepin=True); add() joins the thread if it is still running."""
+        import threading
+        key = _staging_key(self.device, self.d, max(2, int(self.host_stage_buffers)))
+        rows = max(1, int(self.host_chunk_bytes) // (4 * self.d))
+        with _STAGING_LOCK:
+            ent = _STAGING.get(key)
+            th = _STAGING_THREADS.get(key)
+            if (ent is not None and ent[0][0].shape[0] >= rows) or (th is not None and th.is_alive()):
+                pass
+            else:
+                th = threading.Thread(target=_staging, args=(self.device, rows, self.d, key[2]), daemon=True, name="convdr-prepin")
+                _STAGING_THREADS[key] = th
+                th.start()
+        if wait and th is not None:
+            th.join()
 
     def twin(self):
         """An empty index with this one's parameters (search_one_by_one keeps two blocks in flight: one being searched, one
         being loaded)."""
         t = FlatIPIndex(self.d_in, device=self.device, cap=self.cap, rank_target=self.rank_target, precision=self.precision,
-                        center=self.center)
+                        center=self.center, prepin=False)
         t.host_chunk_bytes, t.host_copy_threads, t.host_stage_buffers = self.host_chunk_bytes, self.host_copy_threads, self.host_stage_buffers
         return t
 
@@ -195,10 +217,13 @@ class FlatIPIndex:
             arr = x if isinstance(x, np.ndarray) else x.numpy()
             if arr.dtype == np.float32 and arr.ndim == 2 and arr.shape[0] * arr.shape[1] * 4 > chunk_bytes // 2:
                 return self._add_host_streamed(arr, chunk_bytes)
+        from_host = not (isinstance(x, torch.Tensor) and x.is_cuda)
         t = torch.as_tensor(x)
         if t.dtype != torch.float32:
             t = t.float()
-        t = t.to(self.device, non_blocking=True).contiguous()
+        # (a host source that is not pinned -- e.g. the mmap of a small block file, which search_one_by_one closes right
+        #  after add() returns -- is copied synchronously: nothing may still be reading it when add() is back)
+        t = t.to(self.device, non_blocking=not from_host or t.is_pinned()).contiguous()
         assert t.dim() == 2 and t.shape[1] == self.d, "expected [n, %d], got %s" % (self.d, tuple(t.shape))
         m = int(t.shape[0])
         if m == 0:
@@ -532,7 +557,11 @@ class FlatIPIndex:
 # Pinned staging buffers and the copy thread pool are process-wide: pinning 64 MB costs ~20 ms (hipHostMalloc), i.e. a
 # fresh set per index would cost as much as loading a 3 GB block through them.
 _STAGING = {}
+_STAGING_THREADS = {}
 _POOLS = {}
+import threading as _threading
+_STAGING_LOCK = _threading.Lock()        # guards the dictionaries
+_STAGING_BUILD = _threading.Lock()       # held while buffers are allocated and pinned
 _NUMA = {}
 
 
@@ -596,12 +625,21 @@ def pinned_near(device, shape, dtype):
     return t
 
 
+def _staging_key(device, d, nbuf):
+    return (str(device), int(d), int(nbuf))
+
+
 def _staging(device, rows, d, nbuf):
+    """([nbuf pinned [rows, d] fp32 buffers], [their last H2D-copy events]) of `device`: process-wide, grown on demand.
+    Serialised by _STAGING_BUILD (a background pre-pin -- FlatIPIndex.prepin_staging -- and the first add() may race)."""
     import torch
-    key = (str(device), int(d), int(nbuf))
-    ent = _STAGING.get(key)
-    if ent is None or ent[0][0].shape[0] < rows:
-        ent = _STAGING[key] = ([pinned_near(device, (rows, d), torch.float32) for _ in range(nbuf)], [None] * nbuf)
+    key = _staging_key(device, d, nbuf)
+    with _STAGING_BUILD:
+        ent = _STAGING.get(key)
+        if ent is None or ent[0][0].shape[0] < rows:
+            ent = ([pinned_near(device, (rows, d), torch.float32) for _ in range(nbuf)], [None] * nbuf)
+            with _STAGING_LOCK:
+                _STAGING[key] = ent
     return ent
 
 
@@ -668,6 +706,9 @@ def search_one_by_one(ann_data_dir, gpu_index, query_embedding, topN, max_blocks
     round trip), then the host reads block i + 1 into the twin index (file -> pinned staging -> HBM on the copy stream)
     while the GPU searches block i; block i's certificates are read (search_finish), its result merged and its storage
     dropped only after that.  The reference's load -> add -> search -> merge -> reset is strictly serial (:157-242).
+    HBM residency: with two blocks in flight TWO fp32 blocks and their 16-bit scan copies are resident at once (2 x 1.5 x the
+    block: 44 GB for CAsT's 14.6 GB blocks, of 288 GB) -- pass an index that is not a FlatIPIndex-with-twin, or search block
+    files one at a time with index.add(BlockView) / search / reset yourself, where that does not fit.
     timings (optional dict): filled with the wall seconds spent per stage."""
     import time
     from . import blocks
@@ -717,7 +758,8 @@ def search_one_by_one(ann_data_dir, gpu_index, query_embedding, topN, max_blocks
                 pending = (idx.search_begin(query_embedding, topN), idx, ids)
                 tm["search_finish_merge_s"] += time.perf_counter() - t1
             finally:
-                view.close()                 # (the file is read by host threads only, and add() has joined them)
+                view.close()                 # (streamed blocks: read by host threads that add() has joined; small blocks:
+                                             #  copied synchronously by add() -- nothing reads the mapping any more)
         if pending is not None:
             t1 = time.perf_counter()
             finish(pending)

@@ -327,7 +327,7 @@ def test_replay_residual_is_bf16_rounding(golden_dir, fixture):
     it: oracle/encoder.py's bf16-emulating mode rounds exactly where the kernels round (weights, LayerNorm outputs, Q / K / V,
     the 64-key tiles' unnormalised probabilities, context, GELU output) and keeps fp32 where they keep fp32; against THAT
     oracle the first step of each replay (losses and every parameter gradient, same weights, same batch, same documents)
-    must agree to 1e-3 -- a defect in the ranking backward would not.  The fp32 comparison is recorded beside it."""
+    must agree to ~1e-4 (3x measured) -- a defect in the ranking backward would not.  The fp32 comparison is recorded beside it."""
     from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
     from convdr_amd import train as TR
     z = np.load(os.path.join(golden_dir, fixture))
@@ -379,14 +379,15 @@ def test_replay_residual_is_bf16_rounding(golden_dir, fixture):
             worst_cos = max(worst_cos, 1 - float((a @ b) / (a.norm() * b.norm())))
             worst_norm = max(worst_norm, abs(float(a.norm() / b.norm()) - 1))
         res[mode] = (abs(l1.item() - o1.item()) / (o1.item() + 1e-3), abs(l2.item() - o2.item()), worst_cos, worst_norm)
-    # against the emulated oracle: the north-star bar
-    margin(tag + "/loss1_rel_vs_bf16_oracle", res["bf16"][0], 1e-3)
-    margin(tag + "/loss2_abs_vs_bf16_oracle", res["bf16"][1], 1e-3)
-    margin(tag + "/grad_worst_1-cos_vs_bf16_oracle", res["bf16"][2], 1e-3)
-    margin(tag + "/grad_worst_norm_dev_vs_bf16_oracle", res["bf16"][3], 1e-2)
-    # against the fp32 oracle: recorded (the residual the replay tests see), loosely bounded
-    margin(tag + "/loss2_abs_vs_fp32_oracle", res["fp32"][1], 0.12)
-    margin(tag + "/grad_worst_1-cos_vs_fp32_oracle", res["fp32"][2], 0.3)
+    # against the emulated oracle: ~3x the values measured on an MI355X (rounds 4-5: loss1 3.1e-5 / 2.4e-6, loss2 3.5e-5 / 8.1e-6,
+    # gradients 1 - cos 1.8e-5 / 2.2e-5, norm 4.4e-4 / 3.6e-4) -- a tenth of the north star's 1e-3
+    margin(tag + "/loss1_rel_vs_bf16_oracle", res["bf16"][0], 1e-4)
+    margin(tag + "/loss2_abs_vs_bf16_oracle", res["bf16"][1], 1e-4)
+    margin(tag + "/grad_worst_1-cos_vs_bf16_oracle", res["bf16"][2], 7e-5)
+    margin(tag + "/grad_worst_norm_dev_vs_bf16_oracle", res["bf16"][3], 1.5e-3)
+    # against the fp32 oracle: recorded (the residual the replay tests see), bounded at ~3x measured (0.014 / 0.021; 0.080 / 0.043)
+    margin(tag + "/loss2_abs_vs_fp32_oracle", res["fp32"][1], 0.065)
+    margin(tag + "/grad_worst_1-cos_vs_fp32_oracle", res["fp32"][2], 0.25)
     assert res["bf16"][1] < res["fp32"][1] + 1e-6 and res["bf16"][2] <= res["fp32"][2] + 1e-9, res      # the emulation explains it
 
 
@@ -419,7 +420,7 @@ def test_nll_triple_residual_is_bf16_rounding():
     scale = {k: max(float(pp[k].norm()) for pp in per_pass if k in pp) for k in total}
     model = model.cuda().train()
     (loss,) = model(q[0].cuda(), q[1].cuda(), a[0].cuda(), a[1].cuda(), b[0].cuda(), b[1].cuda())
-    margin("emu_nll_triple/loss_abs_vs_bf16_oracle", abs(loss.item() - ref_loss.item()), 1e-3 * max(1.0, abs(ref_loss.item())))
+    margin("emu_nll_triple/loss_abs_vs_bf16_oracle", abs(loss.item() - ref_loss.item()), 1e-4 * max(1.0, abs(ref_loss.item())))   # measured 2.9e-5
     loss.backward()
     worst, seen = 0.0, 0
     for n, p in model.named_parameters():
@@ -1036,18 +1037,49 @@ def test_kd_step_at_configs2_size_matches_autograd(weights):
                                      "attention.output.dense.weight", "attention.output.LayerNorm.weight",
                                      "intermediate.dense.weight", "intermediate.dense.bias", "output.dense.weight",
                                      "output.dense.bias", "output.LayerNorm.bias")]
-    worst_cos, worst_norm = 1.0, 0.0
-    for n in sample:
-        g, r = named[n].grad.detach().cpu().double().reshape(-1), sd_s[n].grad.double().reshape(-1)
-        c = float((g @ r) / (g.norm() * r.norm() + 1e-300))
-        worst_cos = min(worst_cos, c)
-        worst_norm = max(worst_norm, abs(float(g.norm() / r.norm()) - 1))
-        assert c > 0.999 - (0.004 if tr else 0.0), "%s: cosine %.5f" % (n, c)
-    margin(tag + "/grad_worst_1-cos", 1 - worst_cos, bar["cos"])       # init: 3.8e-5
-    margin(tag + "/grad_worst_norm_dev", worst_norm, bar["norm"])      # 1.8e-3
+    def worst_of(ref_sd):
+        worst_cos, worst_norm, who = 1.0, 0.0, None
+        for n in sample:
+            g, r = named[n].grad.detach().cpu().double().reshape(-1), ref_sd[n].grad.double().reshape(-1)
+            c = float((g @ r) / (g.norm() * r.norm() + 1e-300))
+            if c < worst_cos:
+                worst_cos, who = c, n
+            worst_norm = max(worst_norm, abs(float(g.norm() / r.norm()) - 1))
+        return worst_cos, worst_norm, who
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in student.parameters() if p.grad is not None)).item()
     gr = np.sqrt(sum(float((v.grad.double() ** 2).sum()) for v in sd_s.values() if v.requires_grad and v.grad is not None))
-    margin(tag + "/grad_norm_rel", abs(gn / gr - 1), bar["gnorm"])            # init: 5.7e-4
+    if not tr:
+        worst_cos, worst_norm, who = worst_of(sd_s)
+        assert worst_cos > 0.999, "%s: cosine %.5f" % (who, worst_cos)
+        margin(tag + "/grad_worst_1-cos", 1 - worst_cos, bar["cos"])       # 3.8e-5
+        margin(tag + "/grad_worst_norm_dev", worst_norm, bar["norm"])      # 1.8e-3
+        margin(tag + "/grad_norm_rel", abs(gn / gr - 1), bar["gnorm"])            # 5.7e-4
+        return
+    # Trained statistics: the gradient THROUGH saturated attention heads is the noise-sensitive quantity.  dL/dq, dL/dk of a
+    # head whose softmax sits at p ~ 1 are small differences of large terms (dS = P (dP - D), D = dO . O): the bf16 rounding of the
+    # FORWARD's operands alone moves them -- the bf16-EMULATING oracle (fp32 autograd through a forward that rounds where the
+    # kernels round) is 0.7-1.4e-2 (1 - cos) from the fp32 oracle on the query projections of layers 0 / 5 and on the embedding
+    # tables, and the HIP path is as far from either as they are from each other -- and in the last layer, where only the 64 CLS
+    # queries carry gradient, the bf16-stored context in D = dO . O (flash attention's usual form) shows: 7.6e-2 on a gradient
+    # whose norm is 0.6 % of the layer's value-projection gradient.  So: every sampled parameter against fp32 with a loose bar
+    # (recorded), the parameters that carry the update (norm >= 10 % of the largest) with a tight one, the concatenated sample
+    # tight, and the emulating oracle's own distance from fp32 recorded beside them.
+    sd_e = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd_s.items()}
+    e_emu = OE.rdot_nll_emb(sd_e, ids_s, m_s, num_layers=NL, num_heads=12, emulate_bf16=True)
+    torch.nn.functional.mse_loss(e_emu, t_ref).backward()
+    cos_ = lambda a, b: float((a @ b) / (a.norm() * b.norm() + 1e-300))
+    rows_ = []
+    for n in sample:
+        g_, e_, r_ = (t.double().reshape(-1) for t in (named[n].grad.detach().cpu(), sd_e[n].grad, sd_s[n].grad))
+        rows_.append((n, 1 - cos_(g_, r_), 1 - cos_(e_, r_), float(r_.norm()), g_, r_))
+        print("%-70s 1-cos: hip/fp32 %.2e  emu/fp32 %.2e  |g| %.3e" % (n, rows_[-1][1], rows_[-1][2], rows_[-1][3]))
+    big = max(r[3] for r in rows_)
+    margin(tag + "/grad_worst_1-cos_vs_fp32_oracle", max(r[1] for r in rows_), 0.25)                         # measured 7.6e-2 (layer 11 query)
+    margin(tag + "/grad_worst_1-cos_vs_fp32_oracle_large_norm_params", max(r[1] for r in rows_ if r[3] >= 0.1 * big), 4e-3)   # 1.1e-3
+    margin(tag + "/bf16_emulating_oracle_worst_1-cos_vs_fp32_oracle", max(r[2] for r in rows_), 0.05)        # 1.35e-2: inherent
+    ga, ra = torch.cat([r[4] for r in rows_]), torch.cat([r[5] for r in rows_])
+    margin(tag + "/grad_sample_concatenated_1-cos_vs_fp32_oracle", 1 - cos_(ga, ra), 2e-3)
+    margin(tag + "/grad_norm_rel_vs_fp32_oracle", abs(gn / gr - 1), 5e-2)
 
 
 def test_rank_step_at_configs4_per_gpu_size_matches_autograd():

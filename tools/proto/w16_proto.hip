@@ -20,8 +20,10 @@ using T16b = TileCfg<2, 8, 4, 1>;   // 16 waves of 128 x 32: the wave keeps 4 R 
 // ROLES 0: every wave issues its share of both chunks (L under the first fragment reads, R after the MFMAs)
 // ROLES 1: the first half of the waves issues the whole R chunk after its MFMAs, the second half the whole L chunk at the top
 // FRAG3: fragments prefetched one sub-step ahead (two register sets) as in the product; 0 = one set, read just in time
-template <class T, int ROLES>
+template <class T, int ROLES, int MODE = 0>
 __device__ __forceinline__ void loop_body(const Args& a) {
+  constexpr bool NO_DMA = MODE == 1 || MODE == 3 || MODE == 4, NO_FRAG = MODE == 2 || MODE == 3 || MODE == 4, NO_BAR = MODE == 4;
+  constexpr bool ILV = MODE >= 5;   // fragment reads of sub-step s + 1 threaded between the MFMAs of sub-step s (5: 1 per MFMA, 6: 2 per 2 MFMAs)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sR = smem;
   char* sL = smem + 3 * T::R_BYTES;
@@ -51,9 +53,10 @@ __device__ __forceinline__ void loop_body(const Args& a) {
     gemm_stage<T::TL, LW, LFIRST>(srcL, 0, sL + ls * T::L_BYTES, w.wave);
     if (r_wave) gemm_stage<T::TR, RW, 0>(srcR, 1, sR + ((rs + 1) % 3) * T::R_BYTES, w.wave);
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk && r_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R_DPW) : "memory");
+      if (NO_DMA) { if (kt == 0) lds_dma_wait_all(); }
+      else if (kt + 1 < nk && r_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R_DPW) : "memory");
       else lds_dma_wait_all();
-      lds_barrier();
+      if (!NO_BAR || kt == 0) lds_barrier();
       const char* tR = sR + rs * T::R_BYTES + offR;
       const char* tL = sL + ls * T::L_BYTES + offL;
       bf16x8 fa[2][T::MT], fb[2][T::NT];
@@ -63,25 +66,54 @@ __device__ __forceinline__ void loop_body(const Args& a) {
     _Pragma("unroll") for (int j = 0; j < T::NT; ++j) fb[set_][j] = *(const bf16x8*)(tL + j * 32 * 128 + ch_); \
     _Pragma("unroll") for (int i = 0; i < T::MT; ++i) fa[set_][i] = *(const bf16x8*)(tR + i * 32 * 128 + ch_); \
   } while (0)
-      load_frags(0, 0);
+      if (!NO_FRAG || kt == 0) load_frags(0, 0);
       __builtin_amdgcn_sched_barrier(0);
       const bool issue_l = kt + 1 < nk, issue_r = kt + 2 < nk;
       char* l_dst = sL + (ls ^ 1) * T::L_BYTES;
       const int rnext = rs == 0 ? 2 : rs - 1;
       char* r_dst = sR + rnext * T::R_BYTES;
-      if (issue_l) gemm_stage<T::TL, LW, LFIRST>(srcL, kt + 1, l_dst, w.wave);
+      if (issue_l && !NO_DMA && MODE != 7 && MODE != 8) gemm_stage<T::TL, LW, LFIRST>(srcL, kt + 1, l_dst, w.wave);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        if (s + 1 < 4) load_frags(s + 1, (s + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (MODE == 7 && s == 1 && issue_l) { gemm_stage<T::TL, LW, LFIRST>(srcL, kt + 1, l_dst, w.wave); __builtin_amdgcn_sched_barrier(0); }
+        if (MODE == 8 && s == 1 && issue_l) gemm_stage<T::TL, LW, LFIRST>(srcL, kt + 1, l_dst, w.wave);
+        if (s + 1 < 4 && (!NO_FRAG || kt == 0)) load_frags(s + 1, (s + 1) & 1);
+        if (!ILV) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < T::MT; ++i)
 #pragma unroll
           for (int j = 0; j < T::NT; ++j)
             acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][j], acc.c[i][j], 0, 0, 0);
+        if (ILV && s + 1 < 4) {
+          if (MODE == 8 && s == 1) {
+#pragma unroll
+            for (int r = 0; r < T::MT + T::NT; ++r) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one VMEM read (LDS-DMA piece)
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          } else if (MODE == 5 || MODE == 7 || MODE == 8) {
+#pragma unroll
+            for (int r = 0; r < T::MT + T::NT; ++r) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one DS read
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < (T::MT + T::NT) / 2; ++r) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, T::MT * T::NT, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (issue_r && r_wave) gemm_stage<T::TR, RW, 0>(srcR, kt + 2, r_dst, w.wave);
+      if (issue_r && r_wave && !NO_DMA) gemm_stage<T::TR, RW, 0>(srcR, kt + 2, r_dst, w.wave);
       rs = rs == 2 ? 0 : rs + 1;
       ls ^= 1;
     }
@@ -98,6 +130,15 @@ __device__ __forceinline__ void loop_body(const Args& a) {
 
 __global__ void __launch_bounds__(512) k8_0(const Args a) { loop_body<T8, 0>(a); }
 __global__ void __launch_bounds__(512) k8_1(const Args a) { loop_body<T8, 1>(a); }
+__global__ void __launch_bounds__(512) k8_nodma(const Args a) { loop_body<T8, 1, 1>(a); }
+__global__ void __launch_bounds__(512) k8_nofrag(const Args a) { loop_body<T8, 1, 2>(a); }
+__global__ void __launch_bounds__(512) k8_neither(const Args a) { loop_body<T8, 1, 3>(a); }
+__global__ void __launch_bounds__(512) k8_bare(const Args a) { loop_body<T8, 1, 4>(a); }
+__global__ void __launch_bounds__(512) k8_ilv1(const Args a) { loop_body<T8, 1, 5>(a); }
+__global__ void __launch_bounds__(512) k8_ilv2(const Args a) { loop_body<T8, 1, 6>(a); }
+__global__ void __launch_bounds__(512) k8_ilv_l1(const Args a) { loop_body<T8, 1, 7>(a); }
+__global__ void __launch_bounds__(512) k8_ilv_lt(const Args a) { loop_body<T8, 1, 8>(a); }
+__global__ void __launch_bounds__(1024) k16_ilv(const Args a) { loop_body<T16, 1, 5>(a); }
 __global__ void __launch_bounds__(1024) k16_0(const Args a) { loop_body<T16, 0>(a); }
 __global__ void __launch_bounds__(1024) k16_1(const Args a) { loop_body<T16, 1>(a); }
 __global__ void __launch_bounds__(1024) k16b_0(const Args a) { loop_body<T16b, 0>(a); }
@@ -152,6 +193,15 @@ int main(int argc, char** argv) {
   for (int rep = 0; rep < 3; ++rep) {
     run<T8>(k8_1, a, 10, "8 waves (2/SIMD) 128x64 per wave, roles (product)");
     run<T8>(k8_0, a, 10, "8 waves (2/SIMD) 128x64 per wave, shared issue");
+    run<T8>(k8_ilv1, a, 10, "8 waves roles, fragment reads 1 per MFMA (interleaved)");
+    run<T8>(k8_ilv2, a, 10, "8 waves roles, fragment reads 2 per 2 MFMAs");
+    run<T8>(k8_ilv_l1, a, 10, "8 waves roles, ILV + L chunk issued after sub-step 0");
+    run<T8>(k8_ilv_lt, a, 10, "8 waves roles, ILV + L chunk threaded through sub-step 1");
+    run<T16>(k16_ilv, a, 10, "16 waves (4/SIMD) 64x64, roles, ILV");
+    run<T8>(k8_nodma, a, 10, "8 waves roles, NO DMA in the loop (timing only)");
+    run<T8>(k8_nofrag, a, 10, "8 waves roles, NO fragment reads in the loop");
+    run<T8>(k8_neither, a, 10, "8 waves roles, neither (MFMA + barrier)");
+    run<T8>(k8_bare, a, 10, "8 waves roles, neither, no barrier (bare MFMA)");
     run<T16>(k16_0, a, 10, "16 waves (4/SIMD) 64x64 per wave, shared issue");
     run<T16>(k16_1, a, 10, "16 waves (4/SIMD) 64x64 per wave, roles");
     run<T16b>(k16b_0, a, 10, "16 waves (4/SIMD) 128x32 per wave, shared issue");
