@@ -924,7 +924,7 @@ def main():
     ip_ms = sum(b.elapsed_time(c) for _, b, c in ev) / args.steps
     spans = {}
     for name in ("gemm_qkv", "gemm_attn_out", "gemm_ffn1", "gemm_ffn2", "attention", "layernorm", "embed_ln", "gemm_head",
-                 "ip_scan_emit", "ip_scan_sample", "ip_rescore", "ip_cut", "ip_select"):
+                 "ip_scan_emit", "ip_scan_sample", "ip_rescore", "ip_cut", "ip_select", "ip_finish"):
         ms, cnt = _lib.prof_collect(name)
         if cnt:
             spans[name] = (ms / cnt, cnt, ms / args.steps)

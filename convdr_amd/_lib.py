@@ -146,6 +146,13 @@ register("convdr_inbatch_ce_fwd_bwd", C.c_int, [_p, _p, C.c_int, C.c_int, C.c_in
 register("convdr_grad_norm_clip", C.c_int, [_p, C.c_int64, C.c_float, C.c_float, _p, _p, C.c_int, _p])
 register("convdr_pair_nll_fwd_bwd", C.c_int, [_p, _p, _p, _p, _p, C.c_int, C.c_int, C.c_int, C.c_float, _p, _p, _p, _p, _p])
 register("convdr_train_set_side_stream", C.c_int, [_p])
+# RCCL-backed collectives for torch-free hosts (csrc/comm.hip); convdr_amd/parallel.py itself stays on torch.distributed
+register("convdr_comm_unique_id", C.c_int, [_p])
+register("convdr_comm_init", C.c_int, [C.POINTER(_p), C.c_int, C.c_int, _p])
+register("convdr_comm_ranks", C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(C.c_int)])
+register("convdr_comm_allgather", C.c_int, [_p, _p, _p, C.c_size_t, _p])
+register("convdr_comm_allreduce_f32", C.c_int, [_p, _p, _p, C.c_size_t, _p])
+register("convdr_comm_destroy", C.c_int, [_p])
 register("convdr_grad_sumsq", C.c_int, [_p, C.c_int64, _p, C.c_int, _p])
 register("convdr_grad_norm_finish", C.c_int, [_p, C.c_int, C.c_float, C.c_float, _p, _p])
 register("convdr_scale_f32", C.c_int, [_p, C.c_int64, _p, _p])

@@ -14,6 +14,7 @@ typedef uint16_t bf16_t;  // storage type for bf16 in global memory
 
 // ---- error reporting across the C ABI ------------------------------------
 void set_error(const char* fmt, ...);
+extern int64_t g_ip_fused_finish;   // ip_topk.hip; convdr_set_option("ip_fused_finish") lives in encoder.hip
 int hip_fail(hipError_t e, const char* what);
 // compute units of the current device, rounded down to a multiple of the 8 XCDs (256 on MI355X); persistent kernels
 // launch this many workgroups (x resident workgroups per CU)

@@ -296,6 +296,10 @@ extern "C" int convdr_set_option(const char* name, int64_t value) {
     g_attn_bwd_fused = value;
     return 0;
   }
+  if (strcmp(name, "ip_fused_finish") == 0) {   // search: 1 = cut + re-score + select in one launch per search (k_ip_finish), 0 = three launches
+    convdr::g_ip_fused_finish = value;
+    return 0;
+  }
   if (strcmp(name, "gelu_gp") == 0) {   // training: 1 = gelu' evaluated in the forward's FFN1 epilogue, multiplied in the FFN2 dgrad epilogue
     g_gelu_gp = value;
     return 0;

@@ -287,6 +287,7 @@ struct GemmArgs {
   int H;
   int64_t ldt;
   int tilesN, tilesT;
+  int tile_hint;      // launcher: 256 = take 256 x 256 tiles when the shape allows, whatever the cost model says (0 = cost model)
   int nt_out;         // bf16 tile outputs leave non-temporally (set by the launcher for outputs of 128 MB and more: what the next
                       // kernel streams from HBM anyway stays out of L2; a training-size output its consumer finds in L2 does not)
   int dbg_same_tile;  // experiment: every workgroup reads tile (0, 0) (all-L2-hit upper bound); results are garbage

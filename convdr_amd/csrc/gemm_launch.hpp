@@ -105,6 +105,7 @@ inline int launch_gemm(GemmArgs a, hipStream_t st, const char* prof_name) {
       choice = (t256 <= tW && t256 <= t128) ? 256 : (tW <= t128 ? 192 : 128);
     }
   }
+  if (fits && a.tile_hint == 256) choice = 256;
   if (force128) choice = 128;
   if (choice == 256) return launch_gemm_t<EPI, Tile256>(a, st, prof_name);
   if constexpr (WIDE_OK) {

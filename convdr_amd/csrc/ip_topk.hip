@@ -852,6 +852,140 @@ __global__ void __launch_bounds__(IP_SELECT_THREADS) k_ip_select(int k, int cap,
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 5: cut + re-score + select of ONE query in ONE workgroup (k_ip_cut, k_ip_rescore and k_ip_select chained three
+// launches per search with the band making a round trip through HBM between them; at 100 queries the three were 39 us of
+// kernel time plus their boundaries around a 290 us scan).  Same arithmetic, phase by phase:
+//   1. the query's candidate list into LDS, radix select of S~(k), cut = S~(k) - 2 eps, certificate (status, retry
+//      threshold), the band compacted IN LDS (ids);
+//   2. canonical fp64 re-score of the band: one wave per candidate, sixteen waves per query, each wave's next candidate's
+//      loads in flight while it folds the current one (the same lane / butterfly order as k_ip_rescore: bit-identical);
+//   3. radix select of the k-th exact score on the high key word, bitonic sort of the survivors, D / I written.
+// LDS: cap x (4 id + 4 key) for phase 1, the key half reused with the id half's neighbour as cap x 8 scores from phase 2 on
+// -> cap x 16 bytes (64 KB at the default cap of 4096: two workgroups per CU).  The per-query band size and packed candidate
+// count are still written (convdr_ip_debug_*).  convdr_set_option("ip_fused_finish", 0) gives the three launches back.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_ip_finish(int64_t n, int k, int cap, const uint32_t* __restrict__ counts,
+                                                   uint32_t* __restrict__ counts_packed,
+                                                   const uint32_t* __restrict__ cand_id, const float* __restrict__ cand_s,
+                                                   const float* __restrict__ tau, const float* __restrict__ qnorm,
+                                                   const float* __restrict__ p_max_norm, float eps_coef, float eps_abs,
+                                                   float p_scale, float norm_limit, const float* __restrict__ Q,
+                                                   const float* __restrict__ P, int d, uint32_t* __restrict__ m_out,
+                                                   int32_t* __restrict__ status, float* __restrict__ tau_retry,
+                                                   float* __restrict__ D, int64_t* __restrict__ I) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ SelectScratch sc;
+  __shared__ uint32_t sh_m, sh_g;
+  const int q = blockIdx.x;
+  const uint32_t cnt = counts[(int64_t)q * IP_COUNT_STRIDE];
+  if (threadIdx.x == 0) counts_packed[q] = cnt;
+  const int c = cnt < (uint32_t)cap ? (int)cnt : cap;
+  double* sx = (double*)smem;                                   // [cap] exact scores (phases 2, 3)
+  uint32_t* key = (uint32_t*)smem;                              // [cap] order keys of the scan scores (phase 1; dead before sx is written)
+  uint32_t* id = (uint32_t*)(smem + (size_t)cap * 8);           // [cap] candidate ids, then the band's ids
+  uint32_t* bid = (uint32_t*)(smem + (size_t)cap * 12);         // [cap] the band, compacted
+  for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    key[i] = f32_order_key(cand_s[(int64_t)q * cap + i]);
+    id[i] = cand_id[(int64_t)q * cap + i];
+  }
+  if (threadIdx.x == 0) { sh_m = 0; sh_g = 0; }
+  __syncthreads();
+  // ---- phase 1: cut (k_ip_cut) ----
+  const int need = (int64_t)k < n ? k : (int)n;
+  const float t = tau[q];
+  const float pm = p_max_norm[0] * p_scale;
+  const float eps = (eps_coef * qnorm[q] * pm + eps_abs * (qnorm[q] + pm) + eps_abs * eps_abs) * 1.001f + 1e-30f;
+  const bool have_k = need > 0 && c >= need;
+  float cut = -INFINITY;
+  if (have_k)
+    cut = f32_from_order_key((uint32_t)block_kth_largest<32>([&](int i) { return (uint64_t)key[i]; }, c, (uint32_t)need, sc)) -
+          2.f * eps;
+  for (int i = threadIdx.x; i < c; i += blockDim.x)
+    if (f32_from_order_key(key[i]) >= cut) bid[atomicAdd(&sh_m, 1u)] = id[i];
+  __syncthreads();
+  const int m = (int)sh_m;
+  if (threadIdx.x == 0) {
+    int st = CONVDR_IP_OK;
+    float retry = -INFINITY;
+    if (cnt > (uint32_t)cap) {
+      st = CONVDR_IP_OVERFLOW;
+      const float cand = nextafterf(cut, -INFINITY);
+      retry = cand > t ? cand : t;
+    } else if (c < need) {
+      st = CONVDR_IP_TOO_FEW;
+      retry = t - 4.f * eps - 1e-3f * fabsf(t);
+    } else if (need > 0 && t > -INFINITY && cut < t) {
+      st = CONVDR_IP_UNCERTAIN;
+      retry = nextafterf(cut, -INFINITY);
+    }
+    if (pm > norm_limit || qnorm[q] > norm_limit) {
+      st = CONVDR_IP_RANGE;
+      retry = -INFINITY;
+    }
+    m_out[q] = (uint32_t)m;
+    status[q] = st;
+    tau_retry[q] = retry;
+  }
+  // ---- phase 2: canonical fp64 re-score (k_ip_rescore), one wave per band candidate ----
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const float* qv = Q + (int64_t)q * d;
+    for (int slot = wave; slot < m; slot += nw) {
+      const float* pv = P + (int64_t)bid[slot] * d;
+      double acc = 0.0;
+      for (int e = lane * 4; e < d; e += 256) {
+        const float4 x = *(const float4*)(qv + e);
+        const float4 y = *(const float4*)(pv + e);
+        acc = fma((double)x.x, (double)y.x, acc);
+        acc = fma((double)x.y, (double)y.y, acc);
+        acc = fma((double)x.z, (double)y.z, acc);
+        acc = fma((double)x.w, (double)y.w, acc);
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      if (lane == 0) sx[slot] = acc;     // (key[] is dead: every thread passed the barrier after the compaction)
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: exact top-k of the band (k_ip_select); id[] now holds the band ----
+  for (int i = threadIdx.x; i < m; i += blockDim.x) id[i] = bid[i];
+  __syncthreads();
+  int g = m;
+  if (m > k) {
+    const uint64_t kth = block_kth_largest<32>([&](int i) { return f64_order_key(sx[i]) >> 32; }, m, (uint32_t)k, sc);
+    double ms[IP_SELECT_PER_THREAD];
+    uint32_t mi[IP_SELECT_PER_THREAD];
+#pragma unroll
+    for (int e = 0; e < IP_SELECT_PER_THREAD; ++e) {
+      const int i = threadIdx.x + e * IP_SELECT_THREADS;
+      ms[e] = i < m ? sx[i] : 0.0;
+      mi[e] = i < m ? id[i] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < IP_SELECT_PER_THREAD; ++e) {
+      const int i = threadIdx.x + e * IP_SELECT_THREADS;
+      if (i < m && (f64_order_key(ms[e]) >> 32) >= kth) {
+        const uint32_t slot = atomicAdd(&sh_g, 1u);
+        sx[slot] = ms[e];
+        id[slot] = mi[e];
+      }
+    }
+    __syncthreads();
+    g = (int)sh_g;
+  }
+  int np2 = 2;
+  while (np2 < g) np2 <<= 1;
+  for (int i = g + threadIdx.x; i < np2; i += blockDim.x) { sx[i] = -INFINITY; id[i] = 0xffffffffu; }
+  __syncthreads();
+  bitonic_cand(sx, id, np2);
+  for (int j = threadIdx.x; j < k; j += blockDim.x) {
+    D[(int64_t)q * k + j] = j < g ? (float)sx[j] : -FLT_MAX;
+    I[(int64_t)q * k + j] = j < g ? (int64_t)id[j] : -1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side plan shared by workspace sizing and the search call
 // ------------------------------------------------------------------------------------------
 constexpr int IP_TILE_128 = 0, IP_TILE_256 = 1, IP_TILE_TALL = 2;
@@ -866,6 +1000,8 @@ struct IpPlan {
   int npow2;
   size_t o_qb, o_qlo, o_qnorm, o_tau, o_counts, o_counts_packed, o_m, o_T, o_id, o_s, o_x, total;
 };
+
+int64_t g_ip_fused_finish = 1;   // convdr_set_option("ip_fused_finish"): 1 = k_ip_finish, 0 = k_ip_cut + k_ip_rescore + k_ip_select
 
 static IpPlan ip_plan(int nq, int64_t n, int d, int k, int cap) {
   IpPlan p;
@@ -1170,6 +1306,17 @@ static int ip_search(int kind, float p_scale, const float* q_f32, int nq, const 
     CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_cut, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
     CONVDR_CHECK_HIP(
         hipFuncSetAttribute((const void*)k_ip_select, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12));
+    CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_ip_finish, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
+  }
+  if (g_ip_fused_finish && n > 0) {
+    ProfScope prof("ip_finish", st);
+    hipLaunchKernelGGL(k_ip_finish, dim3(nq), dim3(1024), (size_t)cap * 16, st, n, k, cap, counts,
+                       (uint32_t*)(ws + p.o_counts_packed), cand_id, cand_s, tau, qnorm, p_max_norm,
+                       ip_eps_coef(d, p_bf16_lo != nullptr, kind), ip_eps_abs(d, p_bf16_lo != nullptr, kind),
+                       kind == IP_KIND_F16 ? p_scale : 1.f, kind == IP_KIND_F16 ? IP_F16_NORM_LIMIT : INFINITY, q_f32, p_f32, d,
+                       band, status, tau_retry, D, I);
+    CONVDR_CHECK_LAUNCH("k_ip_finish");
+    return 0;
   }
   {
   ProfScope prof("ip_cut", st);

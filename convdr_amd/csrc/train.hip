@@ -652,6 +652,12 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       // ---- FFN1: Hpre = X1 W1^T + b1;  dX1 = dHpre W1 (bf16 tile output) + dY2 (residual branch, fp32) ----
       g = GemmArgs{};
       g.rows = rows; g.W = (const bf16_t*)lt->w1_t; g.X = d.dHpre; g.N = H; g.K = I; g.Cb = p.dXb1;
+      {   // A/B knob (round 5): the long-K data-gradient GEMM on 256 x 256 tiles -- the launcher's cost model counts 256 CUs,
+          // but beside the weight-gradient branch (108 workgroups that own their CUs) ~148 are free: 108 big tiles fit in one
+          // round where 432 small ones need two
+        static const bool big = getenv("CONVDR_DGRAD_FFN1_256") && atoi(getenv("CONVDR_DGRAD_FFN1_256"));
+        if (big) g.tile_hint = 256;
+      }
       if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
       // ---- LayerNorm1: dY1 = LN'(dY2 + dXb1) ----
       dY1 = other;

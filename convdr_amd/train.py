@@ -342,6 +342,9 @@ class _EncoderFn(torch.autograd.Function):
             # stream forks off BEFORE the forward is enqueued -- the weights are final in stream order here; forking after it
             # (rounds 2-4) made the packing wait for the whole forward and the loss wait for the packing: 0.08 ms per step
             main = torch.cuda.current_stream()
+            # (round 5: on the third auxiliary stream instead -- in train_step the teacher's forward is enqueued on this stream
+            #  BEFORE the student's, so the packing only starts when the teacher is done -- measured no different: 9.61-9.89 vs
+            #  9.61-9.79 ms, three alternations)
             side = _side_stream(dev)
             side.wait_event(main.record_event())
             _lib.check(L_.convdr_encoder_train_forward(C.byref(c), C.byref(w), _lib.ptr(ids), 0, _lib.ptr(mask), B, L,

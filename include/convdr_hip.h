@@ -362,6 +362,31 @@ int convdr_set_option(const char* name, int64_t value);
  * Vt, ctx, Hm, Y, cls_b, cls_y, cls_f, head_y; out[13] = leading dimension of Vt. */
 int convdr_encoder_debug_layout(const convdr_encoder_config* cfg, int64_t rows, int B, int64_t* out);
 
+/* ------------------------------------------------------------------------------------------
+ * Collectives of the N > 1 paths for hosts that are not Python: thin wrappers over RCCL (xGMI).
+ * The reference's own interface for these exchanges is torch.distributed (gen_passage_embeddings.py:314, DDP /
+ * nn.DataParallel run_convdr_train.py:77-78, faiss IndexShards run_convdr_inference.py:355-368), which
+ * convdr_amd/parallel.py keeps using; a torch-free host gets the same three steps here:
+ *   query all-gather            convdr_comm_allgather(comm, Q_local, Q_all, nq_local * d * 4, stream)
+ *   per-rank top-k all-gather   convdr_comm_allgather(comm, packed (score, offset) lists, all lists, nq * k * 12, stream)
+ *                               followed by W - 1 convdr_topk_merge calls
+ *   gradient all-reduce (sum)   convdr_comm_allreduce_f32(comm, arena slice, arena slice, count, stream) behind
+ *                               convdr_backward_wait_layer; 1 / W rides on convdr_grad_norm_clip(pre_scale)
+ * One communicator per process and device (one process per GPU).  librccl.so is looked up at the first call (the copy
+ * the process has already loaded, e.g. torch's; else the system one): it is not a link-time dependency.
+ * convdr_comm_unique_id fills CONVDR_COMM_ID_BYTES HOST bytes on one rank; the host distributes them out of band (file, MPI,
+ * socket) and every rank calls convdr_comm_init with them.  send / recv are device pointers; in-place use
+ * (recv + rank * bytes == send, or recv == send for the all-reduce) is allowed as in RCCL.
+ * ------------------------------------------------------------------------------------------ */
+#define CONVDR_COMM_ID_BYTES 128
+typedef struct convdr_comm_opaque* convdr_comm_t;
+int convdr_comm_unique_id(void* id_out_host);
+int convdr_comm_init(convdr_comm_t* comm, int nranks, int rank, const void* unique_id_host);
+int convdr_comm_ranks(convdr_comm_t comm, int* nranks, int* rank);
+int convdr_comm_allgather(convdr_comm_t comm, const void* send, void* recv, size_t bytes_per_rank, convdr_stream_t stream);
+int convdr_comm_allreduce_f32(convdr_comm_t comm, const float* send, float* recv, size_t count, convdr_stream_t stream);
+int convdr_comm_destroy(convdr_comm_t comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -581,3 +581,43 @@ def test_one_million_block_of_a_trained_statistics_model_certifies(torch_cuda):
         S = Q @ P[s:s + 125_000].T
         above += (S > kth + 5e-3).sum(1)
     assert (above <= k - 1).all(), above.max().item()
+
+
+@pytest.mark.parametrize("n,nq,k,d,kind", [
+    (700, 16, 100, 768, "plain"),        # n <= cap: every passage is a candidate, band = everything above the cut
+    (40000, 24, 100, 768, "plain"),      # sampled threshold pass
+    (33000, 130, 7, 128, "plain"),       # two query tiles
+    (60, 5, 100, 768, "plain"),          # k > n: -1 padding
+    (20000, 9, 50, 768, "dups"),         # exact ties at the k-th score (duplicated rows): survivors ordered by index
+    (30000, 12, 100, 768, "clustered"),  # large common component: wide bands, retries through the ladder
+])
+def test_one_launch_finish_equals_the_three_launch_chain(torch_cuda, n, nq, k, d, kind):
+    """Round 5: k_ip_finish (cut + fp64 re-score + select of a query in ONE workgroup) against k_ip_cut + k_ip_rescore +
+    k_ip_select (convdr_set_option("ip_fused_finish", 0)): identical (D, I), identical ladder statistics, both equal to the
+    oracle.  (Every other search test of the suite runs the default = fused form.)"""
+    from convdr_amd import _lib
+    rs = np.random.RandomState(n + nq)
+    P = synth_corpus(300 + n % 83, n, d)
+    if kind == "dups":
+        P[rs.randint(0, n, size=n // 4)] = P[rs.randint(0, n, size=n // 4)]
+    elif kind == "clustered":
+        P = (0.9 * rs.randn(d).astype(np.float32)[None, :] + 0.12 * P).astype(np.float32)
+    Q = synth_corpus(9, nq, d)
+    if kind == "clustered":
+        Q = (0.9 * P[:nq] / 0.9 + 0.05 * Q).astype(np.float32)
+    out = {}
+    for fused in (1, 0):
+        _lib.check(_lib.lib().convdr_set_option(b"ip_fused_finish", fused), "set_option")
+        try:
+            idx = _index(d)
+            idx.add(P)
+            D, I = idx.search(Q, k)
+            out[fused] = (D, I, {s: idx.stats.get(s) for s in ("retried", "rounds", "x3_queries", "exhaustive_queries")})
+        finally:
+            _lib.lib().convdr_set_option(b"ip_fused_finish", 1)
+    np.testing.assert_array_equal(out[1][0], out[0][0])
+    np.testing.assert_array_equal(out[1][1], out[0][1])
+    assert out[1][2] == out[0][2], (out[1][2], out[0][2])
+    Dr, Ir = OS.flat_ip_search(Q, P, k)
+    np.testing.assert_array_equal(out[1][1], Ir)
+    np.testing.assert_array_equal(out[1][0], Dr)

@@ -211,3 +211,34 @@ def test_two_ranks_ranking_step_with_inbatch_negatives_equals_one_process_on_the
     assert abs(0.5 * (out[0][1] + out[1][1]) - out[0][3]) < 2e-5 * max(1.0, abs(out[0][3])), out
     for o in out:
         assert o[0] < 0.02, out      # weights after the step: mean |difference| per tensor, in units of the step size
+
+
+def test_c_abi_collectives_over_rccl_one_rank():
+    """convdr_comm_* (csrc/comm.hip: RCCL behind the C ABI, for hosts that are not Python -- SURVEY.md section 8b's proposed
+    wrappers): a 1-rank communicator on the one GPU of the box (RCCL refuses two ranks per device): unique id -> init ->
+    ranks -> all-gather (identity at W = 1) -> in-place sum all-reduce (identity) -> destroy, through ctypes exactly as a
+    C host would call them, with the RCCL torch has already loaded (no second copy of the library in the process)."""
+    import ctypes as C
+    from convdr_amd import _lib
+    L = _lib.lib()
+    ident = (C.c_char * 128)()
+    _lib.check(L.convdr_comm_unique_id(ident), "convdr_comm_unique_id")
+    comm = C.c_void_p()
+    _lib.check(L.convdr_comm_init(C.byref(comm), 1, 0, ident), "convdr_comm_init")
+    try:
+        n, r = C.c_int(-1), C.c_int(-1)
+        _lib.check(L.convdr_comm_ranks(comm, C.byref(n), C.byref(r)), "convdr_comm_ranks")
+        assert (n.value, r.value) == (1, 0)
+        x = torch.randn(1000, 768, device="cuda")
+        y = torch.empty_like(x)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(L.convdr_comm_allgather(comm, _lib.ptr(x), _lib.ptr(y), x.numel() * 4, st), "convdr_comm_allgather")
+        g = torch.randn(28_000_000 // 4, device="cuda")                 # one encoder layer's gradient slice
+        g0 = g.clone()
+        _lib.check(L.convdr_comm_allreduce_f32(comm, _lib.ptr(g), _lib.ptr(g), g.numel(), st), "convdr_comm_allreduce_f32")
+        torch.cuda.synchronize()
+        assert torch.equal(y, x) and torch.equal(g, g0)
+        # argument errors come back as error codes, not crashes
+        assert L.convdr_comm_init(C.byref(C.c_void_p()), 2, 5, ident) != 0 and b"rank 5 of 2" in L.convdr_last_error()
+    finally:
+        _lib.check(L.convdr_comm_destroy(comm), "convdr_comm_destroy")
