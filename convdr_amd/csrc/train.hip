@@ -652,11 +652,16 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       // ---- FFN1: Hpre = X1 W1^T + b1;  dX1 = dHpre W1 (bf16 tile output) + dY2 (residual branch, fp32) ----
       g = GemmArgs{};
       g.rows = rows; g.W = (const bf16_t*)lt->w1_t; g.X = d.dHpre; g.N = H; g.K = I; g.Cb = p.dXb1;
-      {   // A/B knob (round 5): the long-K data-gradient GEMM on 256 x 256 tiles -- the launcher's cost model counts 256 CUs,
-          // but beside the weight-gradient branch (108 workgroups that own their CUs) ~148 are free: 108 big tiles fit in one
-          // round where 432 small ones need two
-        static const bool big = getenv("CONVDR_DGRAD_FFN1_256") && atoi(getenv("CONVDR_DGRAD_FFN1_256"));
-        if (big) g.tile_hint = 256;
+      {   // Round 5: this long-K data-gradient GEMM takes 256 x 256 tiles when they fit beside the weight-gradient branch.  The
+          // launcher's cost model counts every CU, but the branch of the layer above (one 160 KB-LDS workgroup per 256 x 256
+          // tile of the four weight matrices: 108 for roberta-base) owns its CUs while this kernel runs: at 9.2 k rows 108
+          // big tiles fit the ~148 free CUs in one round where 432 small ones need two.  Step 9.36 -> 9.21 ms (three
+          // alternations, profiles/r05_ab_dgrad_tiles.txt); the QKV data-gradient GEMM the same way: -0.10 alone, nothing
+          // on top of this one.  CONVDR_DGRAD_FFN1_256=0: the cost model's choice (A/B).
+        static const bool off = getenv("CONVDR_DGRAD_FFN1_256") && !atoi(getenv("CONVDR_DGRAD_FFN1_256"));
+        const int64_t wg_tiles = (int64_t)((I + 255) / 256) * ((H + 255) / 256) * 2 + (int64_t)((3 * H + 255) / 256 + (H + 255) / 256) * ((H + 255) / 256);
+        const int64_t free_cus = device_cu_count() - (wg_tiles < device_cu_count() / 2 ? wg_tiles : device_cu_count() / 2);
+        if (!off && fork_wgrad && H % 256 == 0 && (int64_t)(H / 256) * ceil_div64(rows, 256) <= free_cus) g.tile_hint = 256;
       }
       if (int e = launch_gemm<EPI_BF16>(g, st, "gemm_dgrad")) return e;
       // ---- LayerNorm1: dY1 = LN'(dY2 + dXb1) ----

@@ -14,6 +14,8 @@ from tests.helpers import cosine
 pytestmark = pytest.mark.gpu
 
 COS_TOL = 1e-3
+MAX_ABS_TOL = 0.08      # per-element bar of _check (embeddings are LayerNorm outputs of magnitude ~1-3); the worst value over the
+                        # suite is recorded (encoder_checks/worst_max_abs_err) so that the bar can sit at 3x measured
 
 
 def _sd(z):
@@ -29,11 +31,19 @@ def _tiny_rdot(z):
     return model.cuda().eval()
 
 
+_WORST_ABS = [0.0, 0.0]
+
+
 def _check(emb, ref, what):
+    from tests.helpers import margin
     emb = emb.detach().cpu().numpy()
     cs = cosine(emb, ref)
     assert cs.min() > 1 - COS_TOL, "%s: cosine %s" % (what, cs)
-    assert np.abs(emb - ref).max() < 0.08, "%s: max abs err %g" % (what, np.abs(emb - ref).max())
+    assert np.abs(emb - ref).max() < MAX_ABS_TOL, "%s: max abs err %g" % (what, np.abs(emb - ref).max())
+    _WORST_ABS[0] = max(_WORST_ABS[0], float(np.abs(emb - ref).max()))
+    _WORST_ABS[1] = max(_WORST_ABS[1], float(1 - cs.min()))
+    margin("encoder_checks/worst_max_abs_err", _WORST_ABS[0], MAX_ABS_TOL)
+    margin("encoder_checks/worst_1-cos", _WORST_ABS[1], COS_TOL)
 
 
 def test_rdot_nll_matches_reference_fixture(golden_dir):

@@ -13,11 +13,11 @@ from tests.helpers import cosine, margin
 pytestmark = pytest.mark.gpu
 
 
-def _tiny(layers=2, seed=0, vocab=200):
+def _tiny(layers=2, seed=0, vocab=200, inter=256):
     from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
     torch.manual_seed(seed)
     cfg = RobertaConfig(vocab_size=vocab, hidden_size=128, num_hidden_layers=layers, num_attention_heads=2,
-                        intermediate_size=256, max_position_embeddings=140, hidden_dropout_prob=0.0,
+                        intermediate_size=inter, max_position_embeddings=140, hidden_dropout_prob=0.0,
                         attention_probs_dropout_prob=0.0)
     m = MSMarcoConfigDict["rdot_nll"].model_class(cfg)
     with torch.no_grad():
@@ -72,13 +72,16 @@ def _record_worst(tag, cos_bar, norm_bar):
     margin(tag + "/grad_worst_norm_dev", w[1], norm_bar)
 
 
-@pytest.mark.parametrize("B,L,lens", [(5, 40, [40, 17, 33, 1, 8]), (3, 130, [130, 64, 65])])
-def test_encoder_backward_matches_autograd(B, L, lens):
+@pytest.mark.parametrize("B,L,lens,inter", [(5, 40, [40, 17, 33, 1, 8], 256), (3, 130, [130, 64, 65], 256),
+                                            # an FFN width that is not a multiple of the tile (320 = 2.5 x 128): the blocked gelu'
+                                            # image of EPI_GELU_GP / EPI_MUL_GP with a ragged last feature tile
+                                            (4, 70, [70, 33, 9, 64], 320)])
+def test_encoder_backward_matches_autograd(B, L, lens, inter):
     rs = np.random.RandomState(1)
-    model = _tiny()
+    model = _tiny(layers=3 if inter != 256 else 2, inter=inter)
     ids, mask = _batch(rs, B, L, lens)
     G = torch.from_numpy(rs.randn(B, 768).astype(np.float32))
-    ref_emb, ref = _oracle_grads(model, ids, mask, G)
+    ref_emb, ref = _oracle_grads(model, ids, mask, G, layers=3 if inter != 256 else 2)
     model = model.cuda().train()
     emb = model(ids.cuda(), mask.cuda())
     assert emb.requires_grad
@@ -94,12 +97,12 @@ def test_encoder_backward_matches_autograd(B, L, lens):
                 qb = dict(model.named_parameters())[n.replace("key.bias", "query.bias")].grad
                 assert p.grad.norm().item() < 0.02 * qb.norm().item() + 1e-6, n
             else:
-                _compare(n, p.grad, ref[n], cos_tol=1 - 2e-4, norm_tol=6e-3, tag="bwd_tiny_L%d" % L)
+                _compare(n, p.grad, ref[n], cos_tol=1 - 2e-4, norm_tol=6e-3, tag="bwd_tiny_L%d_I%d" % (L, inter))
             seen += 1
         else:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n       # pooler / classifier: unused
     assert seen == len(ref)
-    _record_worst("bwd_tiny_L%d" % L, 2e-4, 6e-3)       # measured 3.6e-5 / 1.8e-3 (MI355X, r02)
+    _record_worst("bwd_tiny_L%d_I%d" % (L, inter), 2e-4, 6e-3)       # measured 3.6e-5 / 1.8e-3 (MI355X, r02)
 
 
 def test_backward_is_deterministic_and_accumulates():
