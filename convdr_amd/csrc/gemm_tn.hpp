@@ -31,7 +31,10 @@ struct TnCfg {
   static constexpr int R_ROWB = T::TR * 2, L_ROWB = T::TL * 2;          // bytes per staged row
   static constexpr int R_BYTES = 64 * R_ROWB, L_BYTES = 64 * L_ROWB;    // one K step (64 t) of each operand
   static constexpr int STAGE_BYTES = R_BYTES + L_BYTES;
-  static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
+  // 8-wave tiles run the R3 K step (three R slots + two L slots, gemm_tn_mainloop_r3: 160 KB for 256 x 256), 4-wave tiles the
+  // two-stage loop (two workgroups per CU)
+  static constexpr bool R3 = T::WAVES == 8;
+  static constexpr int SMEM_BYTES = R3 ? 3 * R_BYTES + 2 * L_BYTES : 2 * STAGE_BYTES;
 };
 
 // Issue by role: in the 8-wave tile the YOUNGER wave of each SIMD (waves 4-7) issues the whole next K step's DMA at the top
@@ -187,6 +190,88 @@ __device__ __forceinline__ void gemm_tn_mainloop(const TnStageSrc<T::TR, TnIssue
   }
 }
 
+// The R3 K step for the TN engine (round 5; gemm_nt.hpp has the NT form and the reasoning).  In the two-stage loop the younger
+// wave of each SIMD issued the WHOLE next K step -- 16 LDS-DMA instructions, ~1.2 k cycles through the texture path -- before
+// its own fragments, and a K step took ~3.4 k cycles for 2,048 of matrix work.  Here: three R slots + two L slots = the whole
+// 160 KB; the YOUNGER waves (4-7) issue the L chunk of step t + 1 (8 instructions each) under their first fragment reads, the
+// OLDER waves (0-3) the R chunk of step t + 2 after their MFMAs, in the time they used to spend in the barrier; counted vmcnt
+// (an R wave leaves its newest group in flight).
+template <class T>
+__device__ __forceinline__ void gemm_tn_mainloop_r3(const TnStageSrc<T::TR, T::WAVES / 2>& srcR,
+                                                    const TnStageSrc<T::TL, T::WAVES / 2>& srcL, int nk, char* smem,
+                                                    GemmAcc<T>& acc, const WavePos<T>& w) {
+  using C = TnCfg<T>;
+  constexpr int HW = T::WAVES / 2;
+  const bool r_wave = w.wave < HW;                             // wave-uniform
+  const int iw = r_wave ? w.wave : w.wave - HW;
+  constexpr int R_DPW = TnStageSrc<T::TR, HW>::ROUNDS;         // DMA instructions per R wave per chunk
+  const int i16 = w.lane & 15, g = w.lane >> 4;
+  const int rsw = i16 >> 2;
+  const int trow = 8 * (g >> 1) + rsw;
+  const int cb = 32 * (g & 1) + 8 * (i16 & 3);
+  uint32_t offR[T::MT], offL[T::NT];
+  const uint32_t s0 = lds_off(smem);
+#pragma unroll
+  for (int i = 0; i < T::MT; ++i) {
+    const int seg = w.wr * T::MT + i;
+    offR[i] = s0 + trow * C::R_ROWB + (((seg & ~3) | ((seg ^ rsw) & 3)) << 6) + cb;
+  }
+#pragma unroll
+  for (int j = 0; j < T::NT; ++j) {
+    const int seg = w.wl * T::NT + j;
+    offL[j] = s0 + 3 * C::R_BYTES + trow * C::L_ROWB + (((seg & ~3) | ((seg ^ rsw) & 3)) << 6) + cb;
+  }
+  constexpr int NFRAG_READS = 2 * (T::MT + T::NT);
+  char* sR = smem;
+  char* sL = smem + 3 * C::R_BYTES;
+  if (r_wave) {
+    srcR.issue(0, sR, iw);
+    if (nk > 1) srcR.issue(1, sR + C::R_BYTES, iw);
+  } else {
+    srcL.issue(0, sL, iw);
+  }
+  int rs = 0, ls = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (r_wave && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R_DPW) : "memory");
+    else lds_dma_wait_all();
+    lds_barrier();
+    const uint32_t sbR = rs * C::R_BYTES, sbL = ls * C::L_BYTES;
+    TnFrag fa[2][T::MT], fb[2][T::NT];
+#define CONVDR_TN_LOAD(S, SET)                                                                          \
+  {                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < T::NT; ++j) tn_frag<16 * (S) * C::L_ROWB, C::L_ROWB>(offL[j] + sbL, fb[SET][j]); \
+    _Pragma("unroll") for (int i = 0; i < T::MT; ++i) tn_frag<16 * (S) * C::R_ROWB, C::R_ROWB>(offR[i] + sbR, fa[SET][i]); \
+  }
+#define CONVDR_TN_MMA(SET)                                                                              \
+  {                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < T::MT; ++i)                                                   \
+      _Pragma("unroll") for (int j = 0; j < T::NT; ++j)                                                 \
+        acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i].v, fb[SET][j].v, acc.c[i][j], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  }
+    CONVDR_TN_LOAD(0, 0)
+    CONVDR_TN_LOAD(1, 1)
+    // the L chunk of step t + 1 under the first fragments' LDS round trip (its slot was read in step t - 1: free since the barrier)
+    if (!r_wave && kt + 1 < nk) srcL.issue(kt + 1, sL + (ls ^ 1) * C::L_BYTES, iw);
+    tn_wait_frags<NFRAG_READS, T::MT, T::NT>(fa[0], fb[0]);
+    CONVDR_TN_MMA(0)
+    CONVDR_TN_LOAD(2, 0)
+    tn_wait_frags<NFRAG_READS, T::MT, T::NT>(fa[1], fb[1]);
+    CONVDR_TN_MMA(1)
+    CONVDR_TN_LOAD(3, 1)
+    tn_wait_frags<NFRAG_READS, T::MT, T::NT>(fa[0], fb[0]);
+    CONVDR_TN_MMA(0)
+    tn_wait_frags<0, T::MT, T::NT>(fa[1], fb[1]);
+    CONVDR_TN_MMA(1)
+#undef CONVDR_TN_LOAD
+#undef CONVDR_TN_MMA
+    // the R chunk of step t + 2 once this wave's MFMAs are in the pipe (slot (t + 2) % 3 was read in step t - 1)
+    if (r_wave && kt + 2 < nk) srcR.issue(kt + 2, sR + (rs == 0 ? 2 : rs - 1) * C::R_BYTES, iw);
+    rs = rs == 2 ? 0 : rs + 1;
+    ls ^= 1;
+  }
+}
+
 // One launch serves up to TN_MAX_PROBLEMS independent products (the four weight gradients of an encoder layer have the
 // same contraction length and become available within one layer of the backward chain): blockIdx.x walks the
 // concatenated tile lists, blockIdx.y the slices of the contraction range.
@@ -237,10 +322,22 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm_tn(const GemmTnAr
   GemmAcc<T> acc;
   acc.zero();
   if (nk > 0) {
-    const int iw = w.wave >= TnIssue<T>::FIRST ? w.wave - TnIssue<T>::FIRST : 0;   // index among the issuing waves
-    const TnStageSrc<T::TR, TnIssue<T>::W> srcR(q.Rm, q.ldr, q.NR, r0, t_begin, a.rows, iw, w.lane);
-    const TnStageSrc<T::TL, TnIssue<T>::W> srcL(q.Lm, q.ldl, q.NL, l0, t_begin, a.rows, iw, w.lane);
-    gemm_tn_mainloop<T>(srcR, srcL, nk, smem, acc, w);
+#ifdef CONVDR_TN_TWO_STAGE
+    constexpr bool USE_R3 = false;
+#else
+    constexpr bool USE_R3 = TnCfg<T>::R3;
+#endif
+    if constexpr (USE_R3) {
+      const int iw = w.wave < T::WAVES / 2 ? w.wave : w.wave - T::WAVES / 2;         // index among the waves of its role
+      const TnStageSrc<T::TR, T::WAVES / 2> srcR(q.Rm, q.ldr, q.NR, r0, t_begin, a.rows, iw, w.lane);
+      const TnStageSrc<T::TL, T::WAVES / 2> srcL(q.Lm, q.ldl, q.NL, l0, t_begin, a.rows, iw, w.lane);
+      gemm_tn_mainloop_r3<T>(srcR, srcL, nk, smem, acc, w);
+    } else {
+      const int iw = w.wave >= TnIssue<T>::FIRST ? w.wave - TnIssue<T>::FIRST : 0;   // index among the issuing waves
+      const TnStageSrc<T::TR, TnIssue<T>::W> srcR(q.Rm, q.ldr, q.NR, r0, t_begin, a.rows, iw, w.lane);
+      const TnStageSrc<T::TL, TnIssue<T>::W> srcL(q.Lm, q.ldl, q.NL, l0, t_begin, a.rows, iw, w.lane);
+      gemm_tn_mainloop<T>(srcR, srcL, nk, smem, acc, w);
+    }
   }
   const bool ordered = a.nsplit > 1 && a.flags != nullptr;
   const bool slab = a.nsplit > 1 && !ordered;

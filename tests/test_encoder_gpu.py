@@ -14,8 +14,8 @@ from tests.helpers import cosine
 pytestmark = pytest.mark.gpu
 
 COS_TOL = 1e-3
-MAX_ABS_TOL = 0.08      # per-element bar of _check (embeddings are LayerNorm outputs of magnitude ~1-3); the worst value over the
-                        # suite is recorded (encoder_checks/worst_max_abs_err) so that the bar can sit at 3x measured
+MAX_ABS_TOL = 0.08      # per-element bar of _check (embeddings are LayerNorm outputs of magnitude ~1-3): ~2x the worst value over the
+                        # suite, which the tests record (encoder_checks/worst_max_abs_err: 0.037 on an MI355X, round 5)
 
 
 def _sd(z):

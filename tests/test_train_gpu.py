@@ -1078,10 +1078,10 @@ def test_kd_step_at_configs2_size_matches_autograd(weights):
         print("%-70s 1-cos: hip/fp32 %.2e  emu/fp32 %.2e  |g| %.3e" % (n, rows_[-1][1], rows_[-1][2], rows_[-1][3]))
     big = max(r[3] for r in rows_)
     margin(tag + "/grad_worst_1-cos_vs_fp32_oracle", max(r[1] for r in rows_), 0.25)                         # measured 7.6e-2 (layer 11 query)
-    margin(tag + "/grad_worst_1-cos_vs_fp32_oracle_large_norm_params", max(r[1] for r in rows_ if r[3] >= 0.1 * big), 4e-3)   # 1.1e-3
+    margin(tag + "/grad_worst_1-cos_vs_fp32_oracle_large_norm_params", max(r[1] for r in rows_ if r[3] >= 0.1 * big), 6e-3)   # measured 2.1e-3
     margin(tag + "/bf16_emulating_oracle_worst_1-cos_vs_fp32_oracle", max(r[2] for r in rows_), 0.05)        # 1.35e-2: inherent
     ga, ra = torch.cat([r[4] for r in rows_]), torch.cat([r[5] for r in rows_])
-    margin(tag + "/grad_sample_concatenated_1-cos_vs_fp32_oracle", 1 - cos_(ga, ra), 2e-3)
+    margin(tag + "/grad_sample_concatenated_1-cos_vs_fp32_oracle", 1 - cos_(ga, ra), 8e-4)                   # measured 2.6e-4
     margin(tag + "/grad_norm_rel_vs_fp32_oracle", abs(gn / gr - 1), 5e-2)
 
 
