@@ -163,6 +163,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
     const char* tR = sW + wslot * LN_R_BYTES + offR;
     const char* tL = sA + (kt & 1) * LN_L_BYTES + offL;
     wslot = wslot == 2 ? 0 : wslot + 1;
+#ifdef CONVDR_LN_FRAG_JIT   // the round 1-4 form (A/B builds): hipcc read each weight fragment right before the MFMA pair that uses it
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int ch = ((2 * s + w.hi) ^ sw) * 16;
@@ -178,6 +179,44 @@ __global__ void __launch_bounds__(512, 2) k_gemm_resid_ln(const GemmLnArgs a) {
           acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc.c[i][j], 0, 0, 0);
       }
     }
+#else
+    // Round 5: ROLLING fragment prefetch.  A slice is 12 (weight fragment, MFMA pair) units (2 sub-steps x 6 feature blocks);
+    // with 192 accumulators there is no room for a second fragment set, and left to itself hipcc read each weight fragment
+    // right before its MFMA pair and waited for it at once (`ds_read x 2; s_waitcnt lgkmcnt(1); mfma x 2`): one exposed LDS
+    // round trip per pair, six per sub-step.  Here THREE weight-fragment registers rotate -- the fragment of unit u + 2 is
+    // read before the MFMAs of unit u -- and the two activation fragments of sub-step 1 are read (into their own registers)
+    // during sub-step 0: 12 more VGPRs in the loop, one exposed round trip per slice (right after the barrier, where nothing
+    // can be prefetched).  sched_group_barrier pins the order.
+    {
+      constexpr int UNITS = 2 * T::MT;
+      static_assert(T::NT == 2, "TileLN: two activation fragments per sub-step");
+      const int ch0 = ((0 + w.hi) ^ sw) * 16, ch1 = ((2 + w.hi) ^ sw) * 16;
+      bf16x8 fb[2][T::NT], fa[3];
+      auto load_a = [&](int u) { fa[u % 3] = *(const bf16x8*)(tR + (u % T::MT) * 32 * 64 + (u < T::MT ? ch0 : ch1)); };
+#pragma unroll
+      for (int j = 0; j < T::NT; ++j) fb[0][j] = *(const bf16x8*)(tL + j * 32 * 64 + ch0);
+      load_a(0);
+      load_a(1);
+#pragma unroll
+      for (int u = 0; u < UNITS; ++u) {
+        if (u + 2 < UNITS) load_a(u + 2);
+        if (u == 2) {
+#pragma unroll
+          for (int j = 0; j < T::NT; ++j) fb[1][j] = *(const bf16x8*)(tL + j * 32 * 64 + ch1);
+        }
+#pragma unroll
+        for (int j = 0; j < T::NT; ++j)
+          acc.c[u % T::MT][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u % 3], fb[u / T::MT][j], acc.c[u % T::MT][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, T::NT + 2, 0);          // fb[0], fa(0), fa(1)
+#pragma unroll
+      for (int u = 0; u < UNITS; ++u) {
+        if (u + 2 < UNITS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // fa(u + 2)
+        if (u == 2) __builtin_amdgcn_sched_group_barrier(0x100, T::NT, 0);          // fb of sub-step 1
+        __builtin_amdgcn_sched_group_barrier(0x008, T::NT, 0);                      // the unit's MFMA pair
+      }
+    }
+#endif
     // the weight slice of step t + 2 once this wave's MFMAs of the step are in the pipe: the ~60-cycle issue stalls then
     // cost no matrix-pipe time (two steps of slack for the landing)
     if (issue_w) ln_stage32<T::TR, LN_W_WAVES, LN_W_FIRST>(srcW, kt + 2, w_dst, w.wave, w_slice_stride);

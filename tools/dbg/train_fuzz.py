@@ -17,7 +17,7 @@ def run(c):
     hidden = int(rs.choice([128, 256, 768]))
     heads = hidden // 64
     layers = int(rs.choice([1, 2, 3]))
-    inter = int(rs.choice([256, 512, 3072]))
+    inter = int(rs.choice([256, 512, 3072, 192, 320, 704]))     # (192 / 320 / 704: ragged last feature tile of the blocked gelu' image)
     L = int(rs.choice([1, 8, 40, 130, 256]))
     B = int(rs.choice([1, 2, 5, 9]))
     lens = [int(rs.randint(1, L + 1)) for _ in range(B)]
