@@ -249,22 +249,44 @@ __device__ __forceinline__ void gemm_tn_mainloop_r3(const TnStageSrc<T::TR, T::W
         acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i].v, fb[SET][j].v, acc.c[i][j], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
   }
+// MMA(SET) with the reads of sub-step S (into the SAME set) threaded through it: the R fragment of row i is re-read as soon as
+// the row's MFMAs have issued, the L fragments after the last row.  As one block in front of the next sub-step's MFMAs the
+// twelve transposing reads of all eight waves hit the LDS together and held up every wave's first MFMA (gemm_nt.hpp, round 5).
+// The waits stay as they were: LDS reads return in order, so "all but the newest 12" still names the other set.
+#define CONVDR_TN_MMA_LOAD(SET, S)                                                                      \
+  {                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < T::MT; ++i) {                                                 \
+      _Pragma("unroll") for (int j = 0; j < T::NT; ++j)                                                 \
+        acc.c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i].v, fb[SET][j].v, acc.c[i][j], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+      tn_frag<16 * (S) * C::R_ROWB, C::R_ROWB>(offR[i] + sbR, fa[SET][i]);                              \
+    }                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < T::NT; ++j) tn_frag<16 * (S) * C::L_ROWB, C::L_ROWB>(offL[j] + sbL, fb[SET][j]); \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  }
     CONVDR_TN_LOAD(0, 0)
     CONVDR_TN_LOAD(1, 1)
     // the L chunk of step t + 1 under the first fragments' LDS round trip (its slot was read in step t - 1: free since the barrier)
     if (!r_wave && kt + 1 < nk) srcL.issue(kt + 1, sL + (ls ^ 1) * C::L_BYTES, iw);
     tn_wait_frags<NFRAG_READS, T::MT, T::NT>(fa[0], fb[0]);
+#ifdef CONVDR_TN_FRAG_BLOCK
     CONVDR_TN_MMA(0)
     CONVDR_TN_LOAD(2, 0)
     tn_wait_frags<NFRAG_READS, T::MT, T::NT>(fa[1], fb[1]);
     CONVDR_TN_MMA(1)
     CONVDR_TN_LOAD(3, 1)
+#else
+    CONVDR_TN_MMA_LOAD(0, 2)
+    tn_wait_frags<NFRAG_READS, T::MT, T::NT>(fa[1], fb[1]);
+    CONVDR_TN_MMA_LOAD(1, 3)
+#endif
     tn_wait_frags<NFRAG_READS, T::MT, T::NT>(fa[0], fb[0]);
     CONVDR_TN_MMA(0)
     tn_wait_frags<0, T::MT, T::NT>(fa[1], fb[1]);
     CONVDR_TN_MMA(1)
 #undef CONVDR_TN_LOAD
 #undef CONVDR_TN_MMA
+#undef CONVDR_TN_MMA_LOAD
     // the R chunk of step t + 2 once this wave's MFMAs are in the pipe (slot (t + 2) % 3 was read in step t - 1)
     if (r_wave && kt + 2 < nk) srcR.issue(kt + 2, sR + (rs == 0 ? 2 : rs - 1) * C::R_BYTES, iw);
     rs = rs == 2 ? 0 : rs + 1;
