@@ -304,6 +304,10 @@ extern "C" int convdr_set_option(const char* name, int64_t value) {
     g_gelu_gp = value;
     return 0;
   }
+  if (strcmp(name, "ln_bwd_rows") == 0) {   // training: LayerNorm backward kernel of the H = 768 encoder layers (gemm_launch.hpp)
+    g_ln_bwd_rows = value;
+    return 0;
+  }
   if (strcmp(name, "fused_ln_max_k") == 0) {
     g_fused_ln_max_k = value;
     return 0;

@@ -72,6 +72,9 @@ inline int64_t g_attn_bwd_fused = 1;
 // FFN2 data-gradient GEMM multiplies by it in its epilogue (EPI_MUL_GP); 0 = the round-2..4 form (pre-activation saved, separate
 // k_dgelu_colsum pass).  Read by the forward AND its backward: change it only between steps.
 inline int64_t g_gelu_gp = 1;
+// convdr_set_option "ln_bwd_rows": LayerNorm backward of the encoder layers (H = 768): 0 = the general kernel, 1 = the straight-line
+// form (k_layernorm_bwd_rows) without, 2 (default) = with the register prefetch of the next row.  Same formulas; rounding-level differences.
+inline int64_t g_ln_bwd_rows = getenv("CONVDR_LN_BWD_ROWS") ? atoi(getenv("CONVDR_LN_BWD_ROWS")) : 2;
 struct TileCost { double step_us, epi_us; int per_cu; };
 inline double gemm_tile_cost(int64_t tiles, int nk, const TileCost& c) {
   const int64_t slots = (int64_t)device_cu_count() * c.per_cu;

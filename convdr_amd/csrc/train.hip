@@ -375,10 +375,25 @@ static int colsum_chunks(int64_t rows) { return rows >= 2048 ? COLSUM_CHUNKS : 8
 static int ln_bwd_kernel(const float* dY, const bf16_t* dYadd, const float* Yin, int64_t rows, int H, const float* g, float eps,
                          float* dXf, bf16_t* dXb, float* part, int* blocks_out, hipStream_t st,
                          const DropSite drop = DropSite{0u, 0u, 1.f}, const int32_t* row_map = nullptr) {
-  const int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
+  int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
   ProfScope prof("layernorm_bwd", st);
   if (!(dbg_skip() & 2))
-    hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, dYadd, Yin, rows, H, g, eps, dXf, dXb, part, drop, row_map);
+  {
+    // g_ln_bwd_rows (option "ln_bwd_rows" / CONVDR_LN_BWD_ROWS): 0 = the general kernel everywhere (A/B), 1 = straight-line form without, 2 (default) = with the
+    // register prefetch of the next row; CONVDR_LN_BWD_GRID: workgroups of the straight-line form.  configs[2] step, medians of
+    // three alternations on one box: 9.16 ms (0) -> 8.96 (2), 8.93-8.96 for (1) and for grids 384 / 444 / 512 -- the 24
+    // launches of a step 0.94 -> 0.74 ms (profiles/r05_ab_ln_bwd_rows.txt).
+    const int mode = (int)g_ln_bwd_rows;
+    static const int grid_env = getenv("CONVDR_LN_BWD_GRID") ? atoi(getenv("CONVDR_LN_BWD_GRID")) : 0;
+    if (mode && H == 768 && dY && dYadd && dXf && dXb && !row_map) {
+      if (grid_env > 0 && grid_env < blocks) blocks = grid_env;
+      if (mode == 2)
+        hipLaunchKernelGGL((k_layernorm_bwd_rows<3, true, 3>), dim3(blocks), dim3(256), 0, st, dY, dYadd, Yin, rows, g, eps, dXf, dXb, part, drop);
+      else
+        hipLaunchKernelGGL((k_layernorm_bwd_rows<3, false, 4>), dim3(blocks), dim3(256), 0, st, dY, dYadd, Yin, rows, g, eps, dXf, dXb, part, drop);
+    } else
+      hipLaunchKernelGGL(k_layernorm_bwd, dim3(blocks), dim3(256), 0, st, dY, dYadd, Yin, rows, H, g, eps, dXf, dXb, part, drop, row_map);
+  }
   CONVDR_CHECK_LAUNCH("k_layernorm_bwd");
   *blocks_out = blocks;
   return 0;

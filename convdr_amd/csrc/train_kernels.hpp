@@ -199,6 +199,141 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const float* __restrict__
   }
 }
 
+// The encoder layers' form of the kernel above: H == 256 J exactly, both halves of the incoming gradient and both outputs
+// present, rows indexed directly.  Same formulas in the same order (results equal up to hipcc's per-kernel choice of FMA
+// contractions: tests/test_train_gpu.py compares the two inside one backward); what changes is the code shape.
+// The general kernel guards every 16-byte group with `e0 < H` and every optional operand with a pointer test, and hipcc turns
+// each guard into its own basic block with its own s_waitcnt: the 3 J loads of a row went out one dependent round trip after
+// the other -- a latency chain per row, which is why a register prefetch of the NEXT row paid there.  Here the 3 J loads of a
+// row are issued back to back (ISA: nine global_load in a row, counted vmcnt).  Where it showed: the second LayerNorm backward
+// of a layer runs while the weight-gradient branch of the layer above owns 108 of the 256 CUs, the 768 workgroups (3 per CU at
+// 168 VGPRs) need two rounds on the 148 left, and two rounds of latency chains were 45 us against 25 us for the same kernel
+// one LayerNorm earlier (profiles/r05_train_kd.dispatches.txt).  Measured (profiles/r05_ab_ln_bwd_rows.txt): the 24 launches of
+// a configs[2] step 0.94 -> 0.74 ms, the step -0.2 ms; PREFETCH (3 workgroups per CU) and no prefetch at WPE = 4 waves per SIMD
+// (128 VGPRs, no spill; 5 or 6 would spill 40-100 registers) measure the same, as do grids of 384-768 workgroups.
+template <int J, bool PREFETCH, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_layernorm_bwd_rows(const float* __restrict__ dY, const bf16_t* __restrict__ dYb,
+                                                            const float* __restrict__ Yin, int64_t rows,
+                                                            const float* __restrict__ g, float eps, float* __restrict__ dXf,
+                                                            bf16_t* __restrict__ dXb, float* __restrict__ part,
+                                                            const DropSite drop) {
+  constexpr int H = 256 * J;
+  __shared__ float red[3][H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 ag[J], ab[J], ax[J], gg[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    ag[j] = make_float4(0, 0, 0, 0); ab[j] = make_float4(0, 0, 0, 0); ax[j] = make_float4(0, 0, 0, 0);
+    gg[j] = *(const float4*)(g + 256 * j + 4 * lane);
+  }
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  float4 y[J], d[J];
+  uint2 b[J];
+  float4 yn[J], dn[J];
+  uint2 bn[J];
+  int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (PREFETCH && row < rows) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int64_t off = row * H + 256 * j + 4 * lane;
+      yn[j] = *(const float4*)(Yin + off); dn[j] = *(const float4*)(dY + off); bn[j] = *(const uint2*)(dYb + off);
+    }
+  }
+#pragma unroll 1
+  for (; row < rows; row += stride) {
+    if (PREFETCH) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) { y[j] = yn[j]; d[j] = dn[j]; b[j] = bn[j]; }
+      // the next row's loads go out before this row's four dependent wave reductions; past the end: this row again (the
+      // address stays valid and no branch splits the block)
+      const int64_t nrow = row + stride < rows ? row + stride : row;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int64_t off = nrow * H + 256 * j + 4 * lane;
+        yn[j] = *(const float4*)(Yin + off); dn[j] = *(const float4*)(dY + off); bn[j] = *(const uint2*)(dYb + off);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int64_t off = row * H + 256 * j + 4 * lane;
+        y[j] = *(const float4*)(Yin + off); d[j] = *(const float4*)(dY + off); b[j] = *(const uint2*)(dYb + off);
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      d[j].x += __uint_as_float(b[j].x << 16); d[j].y += __uint_as_float(b[j].x & 0xffff0000u);
+      d[j].z += __uint_as_float(b[j].y << 16); d[j].w += __uint_as_float(b[j].y & 0xffff0000u);
+      s += y[j].x + y[j].y + y[j].z + y[j].w;
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      y[j].x -= mean; y[j].y -= mean; y[j].z -= mean; y[j].w -= mean;
+      q += y[j].x * y[j].x + y[j].y * y[j].y + y[j].z * y[j].z + y[j].w * y[j].w;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      y[j].x *= rstd; y[j].y *= rstd; y[j].z *= rstd; y[j].w *= rstd;  // xhat
+      ab[j].x += d[j].x; ab[j].y += d[j].y; ab[j].z += d[j].z; ab[j].w += d[j].w;
+      ag[j].x += d[j].x * y[j].x; ag[j].y += d[j].y * y[j].y; ag[j].z += d[j].z * y[j].z; ag[j].w += d[j].w * y[j].w;
+      d[j].x *= gg[j].x; d[j].y *= gg[j].y; d[j].z *= gg[j].z; d[j].w *= gg[j].w;  // g * dy
+      m1 += d[j].x + d[j].y + d[j].z + d[j].w;
+      m2 += d[j].x * y[j].x + d[j].y * y[j].y + d[j].z * y[j].z + d[j].w * y[j].w;
+    }
+    m1 = wave_sum(m1) / (float)H;
+    m2 = wave_sum(m2) / (float)H;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int e0 = 256 * j + 4 * lane;
+      float4 o;
+      o.x = rstd * (d[j].x - m1 - y[j].x * m2);
+      o.y = rstd * (d[j].y - m1 - y[j].y * m2);
+      o.z = rstd * (d[j].z - m1 - y[j].z * m2);
+      o.w = rstd * (d[j].w - m1 - y[j].w * m2);
+      *(float4*)(dXf + row * H + e0) = o;   // residual branch: not dropped
+      if (drop.thresh) {
+        float k0, k1, k2, k3;
+        drop_hidden4(drop, row, e0, H, k0, k1, k2, k3);
+        o.x *= k0; o.y *= k1; o.z *= k2; o.w *= k3;
+      }
+      ax[j].x += o.x; ax[j].y += o.y; ax[j].z += o.z; ax[j].w += o.w;
+      uint2 p;
+      p.x = pack_bf16x2(o.x, o.y);
+      p.y = pack_bf16x2(o.z, o.w);
+      *(uint2*)(dXb + row * H + e0) = p;
+    }
+  }
+  auto f4add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {   // fixed order (wave 0 + 1 + 2 + 3): deterministic
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int e0 = 256 * j + 4 * lane;
+        if (w > 0) {
+          f4add(ax[j], *(const float4*)&red[0][e0]);
+          f4add(ag[j], *(const float4*)&red[1][e0]);
+          f4add(ab[j], *(const float4*)&red[2][e0]);
+        }
+        if (w < 3) {
+          *(float4*)&red[0][e0] = ax[j];
+          *(float4*)&red[1][e0] = ag[j];
+          *(float4*)&red[2][e0] = ab[j];
+        } else {
+          *(float4*)(part + ((int64_t)blockIdx.x * 3 + 0) * H + e0) = ax[j];
+          *(float4*)(part + ((int64_t)blockIdx.x * 3 + 1) * H + e0) = ag[j];
+          *(float4*)(part + ((int64_t)blockIdx.x * 3 + 2) * H + e0) = ab[j];
+        }
+      }
+    }
+    if (w < 3) __syncthreads();
+  }
+}
+
 // out[e] (+)= sum_p part[p * stride + e], p in fixed order (deterministic).  16 bytes per thread, four partials in
 // flight per accumulator chain (the one-load-at-a-time form of round 1 spent its time in dependent L2 round trips).
 __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, int nparts, int64_t stride,

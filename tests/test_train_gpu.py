@@ -769,6 +769,51 @@ def _backward_at_256_tile_scale(tag):
     _record_worst(tag, 3e-4, 2e-3)              # measured 6.7e-5 / 4.6e-4
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_layernorm_backward_straight_line_kernel_matches_general_kernel(dropout):
+    """k_layernorm_bwd_rows (H = 768: every load of a row issued back to back, no per-group guards; option "ln_bwd_rows" 1 / 2)
+    against the general k_layernorm_bwd (0) inside the same backward of a 3-layer roberta-base-wide student, with and without
+    dropout (the mask of the dense output feeding the LayerNorm is regenerated inside the kernel).  The formulas are the same;
+    which multiply-adds hipcc contracts into FMAs is its choice per kernel, so the results differ at rounding level (an fp32
+    ulp in dX flips a bf16 ulp of the data gradient now and then): every gradient within 2e-3 of its norm (measured <= 3e-4).
+    Ragged batch: the packed row count is not a multiple of the 4 rows a workgroup takes per round."""
+    from convdr_amd import _lib
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    torch.manual_seed(5)
+    cfg = RobertaConfig(vocab_size=300, hidden_size=768, num_hidden_layers=3, num_attention_heads=12, intermediate_size=3072,
+                        max_position_embeddings=140, hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)
+    model = MSMarcoConfigDict["rdot_nll"].model_class(cfg).cuda().train()
+    rs = np.random.RandomState(5)
+    B, L = 37, 128
+    lens = rs.randint(20, L + 1, size=B).tolist()
+    if sum(lens) % 4 == 0:
+        lens[0] -= 1
+    ids, mask = _batch(rs, B, L, lens, vocab=300)
+    ids, mask = ids.cuda(), mask.cuda()
+    G = torch.from_numpy(rs.randn(B, 768).astype(np.float32)).cuda()
+    grads = {}
+    try:
+        for mode in (0, 1, 2):
+            _lib.check(_lib.lib().convdr_set_option(b"ln_bwd_rows", mode), "set_option")
+            model.zero_grad()
+            model.dropout_seed, model.__dict__["_dropout_calls"] = 1234, 0     # the same masks in the three runs
+            (model(ids, mask) * G).sum().backward()
+            grads[mode] = {n: p.grad.detach().double().clone() for n, p in model.named_parameters() if p.grad is not None}
+    finally:
+        _lib.lib().convdr_set_option(b"ln_bwd_rows", 2)
+    assert len(grads[0]) >= 40
+    worst = 0.0
+    for n, g0 in grads[0].items():
+        assert g0.abs().max().item() > 0, n
+        if n.endswith("attention.self.key.bias"):     # analytically zero (softmax is shift-invariant): rounding noise only
+            continue
+        for mode in (1, 2):
+            rel = ((grads[mode][n] - g0).norm() / g0.norm()).item()
+            assert rel <= 2e-3, (n, mode, rel)
+            worst = max(worst, rel)
+    margin("ln_bwd_rows_vs_general_rel_norm_p%g" % dropout, worst, 2e-3)
+
+
 @pytest.mark.parametrize("rows,N,K,pad", [(1000, 128, 256, 0), (77, 72, 40, 8), (4100, 768, 384, 0), (64, 8, 8, 0), (1, 136, 264, 16),
                                           (9001, 2304, 768, 0), (333, 264, 520, 8), (40000, 256, 320, 0)])
 def test_wgrad_tn_engine_matches_fp64(rows, N, K, pad):
