@@ -80,8 +80,7 @@ static int gemm_resid_ln(const bf16_t* W, const bf16_t* Wks, const bf16_t* A, in
   g.rows = rows; g.W = W; g.X = A; g.N = H; g.K = K; g.bias = bias; g.Cf = Yf; g.R = R;
   if (int e = launch_gemm<EPI_RESID_F32>(g, st, name)) return e;
   ProfScope prof("layernorm", st);
-  hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, Yf, rows, H, gamma, beta, eps, X,
-                     (float*)nullptr);
+  launch_layernorm_bf16(Yf, rows, H, gamma, beta, eps, X, st);
   CONVDR_CHECK_LAUNCH("k_layernorm");
   return 0;
 }
@@ -302,6 +301,10 @@ extern "C" int convdr_set_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "gelu_gp") == 0) {   // training: 1 = gelu' evaluated in the forward's FFN1 epilogue, multiplied in the FFN2 dgrad epilogue
     g_gelu_gp = value;
+    return 0;
+  }
+  if (strcmp(name, "ln_rows") == 0) {   // forward LayerNorm of H = 768 rows: 1 (default) straight-line kernel, 0 the general one
+    g_ln_rows = value;
     return 0;
   }
   if (strcmp(name, "ln_bwd_rows") == 0) {   // training: LayerNorm backward kernel of the H = 768 encoder layers (gemm_launch.hpp)

@@ -196,6 +196,57 @@ static __global__ void __launch_bounds__(256) k_layernorm(const float* __restric
   ln_store(x, H, lane, Xb ? Xb + row * H : nullptr, Xf ? Xf + row * H : nullptr);
 }
 
+// The same for H == 256 J with the bf16 output only (the encoder layers' case), as straight-line code: the kernel above keeps
+// each 16-byte group behind an `e0 < H` guard, and hipcc gives every guarded load of gamma / beta -- which it cannot hoist
+// over the guard -- its own block and its own s_waitcnt behind the two row reductions: three dependent L2 round trips per
+// row.  Here the row, gamma and beta are requested together.  Same formulas (see k_layernorm_bwd_rows, train_kernels.hpp).
+template <int J>
+static __global__ void __launch_bounds__(256) k_layernorm_rows(const float* __restrict__ Y, int64_t rows,
+                                                               const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                               bf16_t* __restrict__ Xb) {
+  constexpr int H = 256 * J;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float4 x[J], gg[J], bb[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int e0 = 256 * j + 4 * lane;
+    x[j] = *(const float4*)(Y + row * H + e0);
+    gg[j] = *(const float4*)(g + e0);
+    bb[j] = *(const float4*)(b + e0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) s += x[j].x + x[j].y + x[j].z + x[j].w;
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const float a = x[j].x - mean, c = x[j].y - mean, d = x[j].z - mean, e = x[j].w - mean;
+    q += a * a + c * c + d * d + e * e;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int e0 = 256 * j + 4 * lane;
+    uint2 o;
+    o.x = pack_bf16x2((x[j].x - mean) * rstd * gg[j].x + bb[j].x, (x[j].y - mean) * rstd * gg[j].y + bb[j].y);
+    o.y = pack_bf16x2((x[j].z - mean) * rstd * gg[j].z + bb[j].z, (x[j].w - mean) * rstd * gg[j].w + bb[j].w);
+    *(uint2*)(Xb + row * H + e0) = o;
+  }
+}
+
+// fp32 rows -> LayerNorm -> bf16 rows: the straight-line kernel where it applies (convdr_set_option "ln_rows" 0: never)
+inline int64_t g_ln_rows = 1;
+static inline void launch_layernorm_bf16(const float* Y, int64_t rows, int H, const float* g, const float* b, float eps, bf16_t* Xb,
+                                         hipStream_t st) {
+  if (g_ln_rows && H == 768)
+    hipLaunchKernelGGL(k_layernorm_rows<3>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, Y, rows, g, b, eps, Xb);
+  else
+    hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, Y, rows, H, g, b, eps, Xb, (float*)nullptr);
+}
+
 // out[b, :] = in[cu[b], :]  (CLS rows), bf16 and/or fp32
 static __global__ void __launch_bounds__(256) k_gather_cls(const int32_t* __restrict__ cu, int B, int H,
                                                     const bf16_t* __restrict__ Xb, const float* __restrict__ Xf,

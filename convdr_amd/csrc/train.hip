@@ -169,7 +169,7 @@ static constexpr int dbg_skip() { return 0; }
 
 struct WgradFork {
   hipStream_t main, side;
-  hipEvent_t prod, fin;
+  hipEvent_t prod, fin, head_fin, emb_main;   // emb_main: the embedding gradients are written (recorded on the main stream, before the join)   // head_fin: the head's parameter-gradient jobs on the side stream have read p.part
   // "every gradient of layer l is written": one event on each stream (convdr_backward_wait_layer)
   hipEvent_t layer_main[TRAIN_MAX_LAYERS], layer_side[TRAIN_MAX_LAYERS];
   int layers_recorded;
@@ -195,6 +195,8 @@ struct WgradFork {
       else CONVDR_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
       CONVDR_CHECK_HIP(hipEventCreateWithFlags(&prod, hipEventDisableTiming));
       CONVDR_CHECK_HIP(hipEventCreateWithFlags(&fin, hipEventDisableTiming));
+      CONVDR_CHECK_HIP(hipEventCreateWithFlags(&head_fin, hipEventDisableTiming));
+      CONVDR_CHECK_HIP(hipEventCreateWithFlags(&emb_main, hipEventDisableTiming));
       for (int i = 0; i < TRAIN_MAX_LAYERS; ++i) {
         CONVDR_CHECK_HIP(hipEventCreateWithFlags(&layer_main[i], hipEventDisableTiming));
         CONVDR_CHECK_HIP(hipEventCreateWithFlags(&layer_side[i], hipEventDisableTiming));
@@ -538,8 +540,7 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
     g.drop = drop_site(dseed, DROP_SITE_ATTN_OUT, l, p_hid);
     if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_attn_out")) return e;
     if (!(dbg_skip() & 64))
-      hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, s.Y1, rows, H, lw->ln1_g, lw->ln1_b,
-                       cfg->ln_eps, s.X1, (float*)nullptr);
+      launch_layernorm_bf16(s.Y1, rows, H, lw->ln1_g, lw->ln1_b, cfg->ln_eps, s.X1, st);
     CONVDR_CHECK_LAUNCH("k_layernorm");
     g = GemmArgs{};
     g.rows = rows; g.W = (const bf16_t*)lw->w1; g.X = s.X1; g.N = I; g.K = H; g.bias = lw->b1; g.Cb = s.Hm; g.Cb2 = s.Hpre;
@@ -553,12 +554,10 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
     if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_ffn2")) return e;
     if (l + 1 < cfg->layers) {
       if (!(dbg_skip() & 64))
-        hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, s.Y2, rows, H, lw->ln2_g, lw->ln2_b,
-                         cfg->ln_eps, P.layers[l + 1].Xin, (float*)nullptr);
+        launch_layernorm_bf16(s.Y2, rows, H, lw->ln2_g, lw->ln2_b, cfg->ln_eps, P.layers[l + 1].Xin, st);
       CONVDR_CHECK_LAUNCH("k_layernorm");
     } else if (cfg->pool_mean) {   // use_mean = True: masked mean of the whole last layer's output
-      hipLaunchKernelGGL(k_layernorm, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, s.Y2, rows, H, lw->ln2_g, lw->ln2_b,
-                         cfg->ln_eps, p.Xout, (float*)nullptr);
+      launch_layernorm_bf16(s.Y2, rows, H, lw->ln2_g, lw->ln2_b, cfg->ln_eps, p.Xout, st);
       hipLaunchKernelGGL(k_masked_mean, dim3(B), dim3(256), 0, st, p.Xout, cu_seqlens, seq_lens, H, p.cls_b,
                          cfg->out_dim > 0 ? p.cls_f : out);
       CONVDR_CHECK_LAUNCH("k_masked_mean");
@@ -594,18 +593,40 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
   const convdr_layer_grads* lg_last = &gr->layers[NL - 1];
   const float* dcls = d_out;  // gradient w.r.t. LayerNorm2(cls rows) of the last layer
 
+  WgradFork& wf = WgradFork::get();
+  static const bool fork_wgrad = !(getenv("CONVDR_NO_WGRAD_FORK") && atoi(getenv("CONVDR_NO_WGRAD_FORK")));
+  if (int e = wf.init(st)) return e;
+  hipStream_t ss = fork_wgrad ? wf.side : st;   // stream of the weight-gradient branches
+  // The head and the CLS-row LayerNorm are a chain of ~6 launches of a few microseconds each in front of the first big kernel:
+  // what only FINISHES parameter gradients (the two partial-sum reductions, the head's weight gradient) goes to the
+  // weight-gradient stream, off that chain (round 5; CONVDR_HEAD_WGRAD_INLINE=1: on the main stream as in rounds 1-4).
+  static const bool head_inline = getenv("CONVDR_HEAD_WGRAD_INLINE") && atoi(getenv("CONVDR_HEAD_WGRAD_INLINE"));
+  // (the two LayerNorm backwards keep their partial sums apart: the second one starts while the first one's reduction may
+  //  still be pending on the other stream)
+  const int64_t part2_off = (int64_t)ceil_div64(B, 4) * 3 * 1024;
+  const bool side_ok = fork_wgrad && !head_inline && 2 * ceil_div64(B, 4) <= LN_BWD_BLOCKS;
+  hipStream_t hs = side_ok ? ss : st;
+  float* part2 = side_ok ? p.part + part2_off : p.part;
+
   // ---- head: out = LayerNorm(head_y), head_y = cls_b . head_w^T + head_b ----
   if (cfg->out_dim > 0) {
     const int E = cfg->out_dim;
-    if (int e = ln_bwd(d_out, nullptr, p.head_y, B, E, w->head_ln_g, cfg->head_ln_eps, p.dhead_y, p.dhead_yb, p, gr->head_b,
-                       gr->head_ln_g, gr->head_ln_b, st))
+    int blocks = 0;
+    if (int e = ln_bwd_kernel(d_out, nullptr, p.head_y, B, E, w->head_ln_g, cfg->head_ln_eps, p.dhead_y, p.dhead_yb, p.part, &blocks, st))
       return e;
+    if (side_ok)
+      if (int e = wf.fork()) return e;
+    {
+      ReduceList r;
+      r.add_ln(p.part, blocks, E, gr->head_b, gr->head_ln_g, gr->head_ln_b);
+      if (int e = r.launch(hs)) return e;
+    }
+    // d head_w [E, H] = d head_y^T . cls_b
+    if (int e = wgrad(p.dhead_yb, E, E, p.cls_b, H, H, B, p, gr->head_w, hs)) return e;
     // d cls = d head_y . head_w : dgrad with the transposed head weight [H, E]
     GemmArgs g{};
     g.rows = B; g.W = (const bf16_t*)head_w_t; g.X = p.dhead_yb; g.N = H; g.K = E; g.Cf = p.dcls_f;
     if (int e = launch_gemm<EPI_F32>(g, st, "gemm_dgrad")) return e;
-    // d head_w [E, H] = d head_y^T . cls_b
-    if (int e = wgrad(p.dhead_yb, E, E, p.cls_b, H, H, B, p, gr->head_w, st)) return e;
     dcls = p.dcls_f;
   }
   // ---- last layer's LayerNorm2 on the CLS rows only, scattered into a zero [rows, H] gradient ----
@@ -616,16 +637,19 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     CONVDR_CHECK_LAUNCH("k_masked_mean_bwd");
   } else {
     // (its dbias output is the last layer's FFN2 bias gradient: only the CLS rows of that layer carry gradient)
-    if (int e = ln_bwd(dcls, nullptr, p.cls_y, B, H, w->layers[NL - 1].ln2_g, cfg->ln_eps, p.dcls_y, (bf16_t*)nullptr, p,
-                       p_hid > 0.f ? nullptr : lg_last->b2, lg_last->ln2_g, lg_last->ln2_b, st))
+    int blocks = 0;
+    if (int e = ln_bwd_kernel(dcls, nullptr, p.cls_y, B, H, w->layers[NL - 1].ln2_g, cfg->ln_eps, p.dcls_y, (bf16_t*)nullptr, part2,
+                              &blocks, st))
       return e;
+    if (side_ok)
+      if (int e = wf.fork()) return e;
+    ReduceList r;
+    r.add_ln(part2, blocks, H, p_hid > 0.f ? nullptr : lg_last->b2, lg_last->ln2_g, lg_last->ln2_b);
+    if (int e = r.launch(hs)) return e;
     // (p.dcls_y [B, H]: the gradient of the CLS rows' pre-LayerNorm2 sums; the last layer's tail stays on those B rows)
   }
+  if (side_ok) CONVDR_CHECK_HIP(hipEventRecord(wf.head_fin, ss));
 
-  WgradFork& wf = WgradFork::get();
-  static const bool fork_wgrad = !(getenv("CONVDR_NO_WGRAD_FORK") && atoi(getenv("CONVDR_NO_WGRAD_FORK")));
-  if (int e = wf.init(st)) return e;
-  hipStream_t ss = fork_wgrad ? wf.side : st;   // stream of the weight-gradient branches
   // The gradient flowing down the residual stream is cur_f (fp32) + cur_b (bf16 dgrad tile output, or null)
   float* cur_f = p.G0;
   const bf16_t* cur_b = nullptr;
@@ -792,6 +816,7 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
   {
     const int blocks = (int)(ceil_div64(rows, 4) < EMB_BWD_BLOCKS ? ceil_div64(rows, 4) : EMB_BWD_BLOCKS);
     ProfScope prof("embed_bwd", st);
+    if (side_ok) CONVDR_CHECK_HIP(hipStreamWaitEvent(st, wf.head_fin, 0));   // p.part is rewritten here (long complete: first jobs of that stream)
     hipLaunchKernelGGL(k_embed_bwd, dim3(blocks), dim3(256), 0, st, cur_f, cur_b, p.tok_id, p.tok_pos, rows, H, w->word_emb, w->pos_emb,
                        w->type_emb, w->emb_ln_g, cfg->ln_eps, gr->word_emb, gr->pos_emb, p.part,
                        drop_site(dseed, DROP_SITE_EMB, 0, p_hid));
@@ -801,6 +826,7 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     for (int k = 0; k < 3; ++k) r.add(p.part + (size_t)k * H, blocks, (int64_t)3 * H, H, outs[k]);
     if (int e = r.launch(st)) return e;
   }
+  CONVDR_CHECK_HIP(hipEventRecord(wf.emb_main, st));   // convdr_backward_wait_layer(-1): the embedding gradients, ahead of the join
   if (fork_wgrad)
     if (int e = wf.join()) return e;   // every weight gradient is complete for whatever follows on `stream`
   return 0;
@@ -832,9 +858,13 @@ extern "C" int convdr_train_set_side_stream(convdr_stream_t stream) {
 
 extern "C" int convdr_backward_wait_layer(int layer, convdr_stream_t stream) {
   WgradFork& wf = WgradFork::get();
-  CONVDR_REQUIRE(wf.ok && layer >= 0 && layer < wf.layers_recorded,
+  CONVDR_REQUIRE(wf.ok && layer >= -1 && layer < wf.layers_recorded,
                  "convdr_backward_wait_layer: layer %d of a backward with %d layers (none enqueued yet?)", layer,
                  wf.ok ? wf.layers_recorded : 0);
+  if (layer == -1) {   // the embedding tables + embedding LayerNorm: written by the main chain's last kernels, before it joins the branch
+    CONVDR_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, wf.emb_main, 0));
+    return 0;
+  }
   CONVDR_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, wf.layer_main[layer], 0));
   CONVDR_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, wf.layer_side[layer], 0));
   return 0;

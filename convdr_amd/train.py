@@ -480,6 +480,18 @@ class _MSE(torch.autograd.Function):
         return ds * g, None
 
 
+def _mse_value_and_grad(student_embs, teacher_embs):
+    """(MSE, d MSE / d student) in the one launch _MSE.forward makes, without the autograd node: train_step seeds the
+    encoder's backward with the gradient directly when the KD term is the whole loss."""
+    s32, t32 = student_embs.detach().float().contiguous(), teacher_embs.detach().float().contiguous()
+    loss = torch.empty((), dtype=torch.float32, device=s32.device)
+    ds = torch.empty_like(s32)
+    with torch.cuda.device(s32.device):
+        _lib.check(_lib.lib().convdr_mse_fwd_bwd(_lib.ptr(s32), _lib.ptr(t32), s32.numel(), 1.0, _lib.ptr(loss), _lib.ptr(ds),
+                                                 _lib.stream_ptr()), "convdr_mse_fwd_bwd")
+    return loss, ds
+
+
 def mse_loss(student_embs, teacher_embs):
     """nn.MSELoss() (run_convdr_train.py:460, :115); gradient flows to the student only."""
     return _MSE.apply(student_embs, teacher_embs.detach())
@@ -604,10 +616,14 @@ def _flat_view(tensors):
     return torch.as_strided(base, (n,), (1,), base.storage_offset())
 
 
+_EMB_SUMSQ_MAIN = os.environ.get("CONVDR_EMB_SUMSQ_MAIN", "0") == "1"     # A/B: the embedding slice's sum behind the backward's join (rounds 3-4)
+
+
 def _overlapped_sumsq(flat, tower, scratch, dev):
     """Sum of squares of a FRESH gradient arena, piece by piece: every encoder layer's slice on a side stream as soon as
     the backward's completion events say it is final (convdr_backward_wait_layer) -- under the backward of the layers
-    below --, embeddings and head on the current stream after the backward.  Returns the number of partial sums written
+    below --, the embeddings behind the main chain's last kernels (beside layer 0's weight-gradient branch), the head on the
+    current stream after the backward.  Returns the number of partial sums written
     to `scratch`, or 0 when the arena is not the one the tower's last backward wrote."""
     info = getattr(tower, "_flat", None)
     if info is None or getattr(tower, "_last_backward_arena", None) != flat.data_ptr():
@@ -625,14 +641,22 @@ def _overlapped_sumsq(flat, tower, scratch, dev):
     main = torch.cuda.current_stream(dev)
     side = _norm_stream(dev)
     base, sbase = flat.data_ptr(), scratch.data_ptr()
+    b0, e1 = int(offs[5]), int(offs[5 + 16 * nl])
     with torch.cuda.stream(side):
         for l in reversed(range(nl)):
+            if l == 0 and not _EMB_SUMSQ_MAIN:
+                # the embedding slice (a third of the arena) is written by the main chain's last kernels, BEFORE that chain
+                # waits for layer 0's weight-gradient branch: summed here, beside that branch, instead of behind the join
+                # (and ahead of layer 0's slice on this stream, whose event is that branch's end)
+                _lib.check(L.convdr_backward_wait_layer(-1, side.cuda_stream), "convdr_backward_wait_layer")
+                _lib.check(L.convdr_grad_sumsq(C.c_void_p(base), b0, C.c_void_p(sbase + 4 * nl * per), nb_emb, side.cuda_stream),
+                           "convdr_grad_sumsq")
             b, e = int(offs[5 + 16 * l]), int(offs[5 + 16 * (l + 1)])
             _lib.check(L.convdr_backward_wait_layer(l, side.cuda_stream), "convdr_backward_wait_layer")
             _lib.check(L.convdr_grad_sumsq(C.c_void_p(base + 4 * b), e - b, C.c_void_p(sbase + 4 * l * per), per, side.cuda_stream),
                        "convdr_grad_sumsq")
-    b0, e1 = int(offs[5]), int(offs[5 + 16 * nl])
-    _lib.check(L.convdr_grad_sumsq(C.c_void_p(base), b0, C.c_void_p(sbase + 4 * nl * per), nb_emb, main.cuda_stream), "convdr_grad_sumsq")
+    if _EMB_SUMSQ_MAIN:
+        _lib.check(L.convdr_grad_sumsq(C.c_void_p(base), b0, C.c_void_p(sbase + 4 * nl * per), nb_emb, main.cuda_stream), "convdr_grad_sumsq")
     _lib.check(L.convdr_grad_sumsq(C.c_void_p(base + 4 * e1), flat.numel() - e1, C.c_void_p(sbase + 4 * (nl * per + nb_emb)), nb_head,
                                    main.cuda_stream), "convdr_grad_sumsq")
     main.wait_stream(side)
@@ -1198,6 +1222,16 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
     else:
         teacher_embs = teacher_embs.detach()
         embs = model(concat_ids, concat_id_mask, **kw_s)
+    # KD term alone, no accumulation / weighting: `loss.backward()` would seed _MSE.backward with a ones scalar and multiply
+    # the stored gradient by it -- a fill and an elementwise launch on the chain between forward and backward -- so the
+    # encoder's backward is seeded with the gradient itself (bit-identical: the factor is exactly 1.0)
+    direct = (not getattr(args, "no_mse", False) and not getattr(args, "ranking_task", False) and gas == 1 and loss_weight == 1.0
+              and embs.requires_grad and os.environ.get("CONVDR_KD_DIRECT_BACKWARD", "1") != "0")
+    if direct:
+        loss1, seed = _mse_value_and_grad(embs, teacher_embs)
+        embs.backward(seed)
+        loss_out, loss2 = loss1, None
+        return _finish_step(args, model, optimizer, scheduler, ddp, force_overlap, do_step, gas, loss_out, loss1, loss2)
     loss1 = None if getattr(args, "no_mse", False) else mse_loss(embs, teacher_embs)
     loss, loss2 = loss1, None
     if getattr(args, "ranking_task", False):
@@ -1229,6 +1263,11 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
     if loss_weight != 1.0:
         loss = loss * float(loss_weight)
     loss.backward()
+    return _finish_step(args, model, optimizer, scheduler, ddp, force_overlap, do_step, gas, loss_out, loss1, loss2)
+
+
+def _finish_step(args, model, optimizer, scheduler, ddp, force_overlap, do_step, gas, loss_out, loss1, loss2):
+    """train_step after the backward: all-reduce, clip, optimizer, scheduler, zero_grad (run_convdr_train.py:172-193)."""
     if do_step:
         scale = 1.0
         if ddp is not None:

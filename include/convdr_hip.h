@@ -266,7 +266,9 @@ int convdr_wgrad(const void* dy, int N, int64_t ld_dy, const void* x, int K, int
  * /root/reference/drivers/run_convdr_train.py:52,178): makes `stream` wait until every gradient of encoder layer
  * `layer` written by the most recent convdr_encoder_backward on the current device is complete (the layers finish in
  * the order layers-1 .. 0; embeddings and head only with the whole call).  The caller then enqueues the collective for
- * that layer's slice of the gradient arena on `stream` while the backward of the layers below is still running. */
+ * that layer's slice of the gradient arena on `stream` while the backward of the layers below is still running.
+ * layer = -1: the embedding tables and the embedding LayerNorm -- written by the call's last kernels on its own stream,
+ * while the last weight-gradient branch may still be running (the call's stream only joins it afterwards). */
 int convdr_backward_wait_layer(int layer, convdr_stream_t stream);
 
 /* fp32 [n, k] row-major -> bf16 [k, n] (packing of the transposed weights) */

@@ -814,6 +814,38 @@ def test_layernorm_backward_straight_line_kernel_matches_general_kernel(dropout)
     margin("ln_bwd_rows_vs_general_rel_norm_p%g" % dropout, worst, 2e-3)
 
 
+def test_layernorm_forward_straight_line_kernel_matches_general_kernel():
+    """k_layernorm_rows (H = 768: row, gamma and beta requested together, no per-group guards; option "ln_rows" 1) against the
+    general k_layernorm (0) in the training forward AND the small-batch inference forward of a 3-layer roberta-base-wide model:
+    same formulas, FMA contraction is hipcc's choice per kernel, so a bf16 ulp of a hidden state flips now and then and the
+    embeddings agree to 1 - cos <= 1e-5 (measured 2.6e-6; the distance to the fp32 oracle is ~1e-4)."""
+    from convdr_amd import _lib
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    torch.manual_seed(6)
+    cfg = RobertaConfig(vocab_size=300, hidden_size=768, num_hidden_layers=3, num_attention_heads=12, intermediate_size=3072,
+                        max_position_embeddings=140, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = MSMarcoConfigDict["rdot_nll"].model_class(cfg).cuda()
+    rs = np.random.RandomState(6)
+    B, L = 21, 96
+    lens = rs.randint(10, L + 1, size=B).tolist()
+    ids, mask = _batch(rs, B, L, lens, vocab=300)
+    ids, mask = ids.cuda(), mask.cuda()
+    outs = {}
+    try:
+        for mode in (0, 1):
+            _lib.check(_lib.lib().convdr_set_option(b"ln_rows", mode), "set_option")
+            model.train()
+            a = model(ids, mask).detach().double().cpu().numpy()
+            model.eval()
+            with torch.no_grad():
+                b = model(ids, mask).double().cpu().numpy()
+            outs[mode] = (a, b)
+    finally:
+        _lib.lib().convdr_set_option(b"ln_rows", 1)
+    for k, name in ((0, "train"), (1, "eval")):
+        margin("ln_rows_vs_general_1-cos_%s" % name, (1 - cosine(outs[0][k], outs[1][k])).max(), 1e-5)
+
+
 @pytest.mark.parametrize("rows,N,K,pad", [(1000, 128, 256, 0), (77, 72, 40, 8), (4100, 768, 384, 0), (64, 8, 8, 0), (1, 136, 264, 16),
                                           (9001, 2304, 768, 0), (333, 264, 520, 8), (40000, 256, 320, 0)])
 def test_wgrad_tn_engine_matches_fp64(rows, N, K, pad):
@@ -1046,7 +1078,7 @@ def test_kd_step_at_configs2_size_matches_autograd(weights):
     # bars: ~3x the values measured on an MI355X for each kind of weights (the trained-statistics model is ~5x more sensitive
     # to operand rounding: its bf16-EMULATING oracle is 2e-4 from the fp32 one in the forward, the init model's 4e-5)
     bar = dict(t_emb=1e-3, s_emb=1e-3, loss=1e-3, cos=1e-3, norm=2e-2, gnorm=1e-2) if tr else \
-        dict(t_emb=2e-4, s_emb=2e-4, loss=2e-5, cos=2e-4, norm=6e-3, gnorm=2e-3)
+        dict(t_emb=2e-4, s_emb=2e-4, loss=1e-4, cos=2e-4, norm=6e-3, gnorm=2e-3)
 
     def build(seed):
         torch.manual_seed(seed)
@@ -1075,7 +1107,9 @@ def test_kd_step_at_configs2_size_matches_autograd(weights):
     loss.backward()
     margin(tag + "/teacher_emb_1-cos", 1 - cosine(t_emb.cpu().numpy(), t_ref.numpy()).min(), bar["t_emb"])      # init: measured 5.2e-5 (MI355X, r02)
     margin(tag + "/student_emb_1-cos", 1 - cosine(emb.detach().cpu().numpy(), e_ref.detach().numpy()).min(), bar["s_emb"])   # 4.2e-5
-    margin(tag + "/loss1_rel", abs(loss.item() - loss_ref.item()) / loss_ref.item(), bar["loss"])   # 4.4e-6 (north_star bar: 1e-3)
+    # (init: 4.5e-6 through round 5's evidence runs, 3.7e-5 since the straight-line LayerNorm kernels -- an MSE of two embeddings
+    #  that are each 4-5e-5 (1 - cos) from the oracle; the first figure was a lucky cancellation.  north_star bar: 1e-3)
+    margin(tag + "/loss1_rel", abs(loss.item() - loss_ref.item()) / loss_ref.item(), bar["loss"])
     named = dict(student.named_parameters())
     sample = ["embeddingHead.weight", "embeddingHead.bias", "norm.weight", "roberta.embeddings.LayerNorm.weight",
               "roberta.embeddings.position_embeddings.weight", "roberta.embeddings.word_embeddings.weight"]
