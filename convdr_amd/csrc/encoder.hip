@@ -13,9 +13,16 @@ struct EncBufs {
   int32_t *tok_id, *tok_pos;
   bf16_t *X, *Q, *K, *Vt, *ctx, *Hm, *cls_b, *cls_ctx, *cls_x, *cls_x1;
   float *Y, *cls_y, *cls_f, *head_y;
+  float* slab;       // split-contraction partial sums of the few-rows FFN2 (null above SPLITK_MAX_ROWS rows)
   int64_t ldt;
   size_t total;
 };
+
+// Few rows: the K = 3072 projection is cut into up to SPLITK_MAX_SPLIT contraction slices (gemm_resid_ln below) while its
+// 128 x 128 tiles fill at most half of the chip's 512 workgroup slots -- 42 token tiles x 6 feature tiles.
+constexpr int64_t SPLITK_MAX_ROWS = 42 * 128;
+constexpr int SPLITK_MAX_SPLIT = 4;
+static int64_t g_ffn2_splitk = 1;   // convdr_set_option("ffn2_splitk", 0): whole-contraction tiles (A/B, tests)
 
 static EncBufs enc_plan(const convdr_encoder_config* c, int64_t rows, int B, char* base) {
   EncBufs p;
@@ -34,6 +41,7 @@ static EncBufs enc_plan(const convdr_encoder_config* c, int64_t rows, int B, cha
   p.ctx = (bf16_t*)take(rs * H * 2);
   p.Hm = (bf16_t*)take(rs * I * 2);
   p.Y = (float*)take(rs * H * 4);
+  p.slab = rows <= SPLITK_MAX_ROWS ? (float*)take((size_t)SPLITK_MAX_SPLIT * rs * H * 4) : nullptr;
   const int64_t Bp = B + 128;
   p.cls_b = (bf16_t*)take(Bp * H * 2);
   p.cls_ctx = (bf16_t*)take(Bp * H * 2);
@@ -58,7 +66,7 @@ static bool fused_ln_applies(int64_t rows, int H, int K) {
 // a_blocked: A is in the EPI_GELU_BLK layout (only ever set when fused_ln_applies)
 static int gemm_resid_ln(const bf16_t* W, const bf16_t* Wks, const bf16_t* A, int64_t rows, int H, int K, const float* bias,
                          const bf16_t* R, const float* gamma, const float* beta, float eps, float* Yf, bf16_t* X,
-                         const char* name, hipStream_t st, bool a_blocked = false) {
+                         const char* name, hipStream_t st, bool a_blocked = false, float* slab = nullptr) {
   // measured at 262k rows: K = 768: 0.52 ms fused vs 0.49 + 0.19 ms (GEMM + LayerNorm); K = 3072: 1.33 vs 1.17 + 0.19 ms
   if (fused_ln_applies(rows, H, K)) {
     static DeviceOnce attr_done;
@@ -77,6 +85,26 @@ static int gemm_resid_ln(const bf16_t* W, const bf16_t* Wks, const bf16_t* A, in
     return 0;
   }
   GemmArgs g{};
+  // Few rows, long contraction (the frozen teacher's targets in a training step, a query batch of the evaluation loop): the
+  // 128 x 128 tiles of a whole-contraction launch fill a quarter of the chip and each is a 48-step latency chain (126
+  // workgroups, 48 us at 2.6 k rows); cut into 4 (2) slices while tiles x slices fit the 512 workgroup slots, and finished --
+  // partial sums + bias + residual + LayerNorm -- by one row kernel: 17 + 6 us.  The sum order differs from the whole-
+  // contraction tile's (fp32 rounding level).
+  int ns = 1;
+  if (slab && g_ffn2_splitk && H == 768 && K >= 2048 && rows <= SPLITK_MAX_ROWS) {
+    const int64_t tiles = ceil_div64(rows, 128) * (H / 128), slots = (int64_t)device_cu_count() * 2;
+    for (int c = SPLITK_MAX_SPLIT; c >= 2; c >>= 1)
+      if (tiles * c <= slots && K % (c * GEMM_BK) == 0) { ns = c; break; }
+  }
+  if (ns > 1) {
+    g.rows = rows; g.W = W; g.X = A; g.N = H; g.K = K; g.k_split_len = K / ns; g.Cf = slab;
+    if (int e = launch_gemm<EPI_SLAB_F32>(g, st, name)) return e;
+    ProfScope prof("layernorm", st);
+    hipLaunchKernelGGL(k_slab_finish_ln<3>, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, slab, ns, rows, bias, R, gamma, beta,
+                       eps, X);
+    CONVDR_CHECK_LAUNCH("k_slab_finish_ln");
+    return 0;
+  }
   g.rows = rows; g.W = W; g.X = A; g.N = H; g.K = K; g.bias = bias; g.Cf = Yf; g.R = R;
   if (int e = launch_gemm<EPI_RESID_F32>(g, st, name)) return e;
   ProfScope prof("layernorm", st);
@@ -170,7 +198,8 @@ int encoder_layer_forward(const convdr_encoder_config* c, const convdr_layer_wei
     g2.rows = n; g2.W = (const bf16_t*)w->w2; g2.X = p.Hm; g2.N = H; g2.K = I; g2.bias = w->b2; g2.Cf = p.Y; g2.R = x1;
     return launch_gemm<EPI_RESID_F32>(g2, st, "gemm_ffn2");
   }
-  return gemm_resid_ln((const bf16_t*)w->w2, (const bf16_t*)w->w2_ks, p.Hm, n, H, I, w->b2, x1, w->ln2_g, w->ln2_b, c->ln_eps, p.Y, p.X, "gemm_ffn2", st);
+  return gemm_resid_ln((const bf16_t*)w->w2, (const bf16_t*)w->w2_ks, p.Hm, n, H, I, w->b2, x1, w->ln2_g, w->ln2_b, c->ln_eps, p.Y, p.X, "gemm_ffn2", st,
+                       false, p.slab);
 }
 
 }  // namespace convdr
@@ -301,6 +330,10 @@ extern "C" int convdr_set_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "gelu_gp") == 0) {   // training: 1 = gelu' evaluated in the forward's FFN1 epilogue, multiplied in the FFN2 dgrad epilogue
     g_gelu_gp = value;
+    return 0;
+  }
+  if (strcmp(name, "ffn2_splitk") == 0) {   // few-rows FFN2: 1 (default) split contraction + finishing row kernel, 0 whole-contraction tiles
+    g_ffn2_splitk = value;
     return 0;
   }
   if (strcmp(name, "ln_rows") == 0) {   // forward LayerNorm of H = 768 rows: 1 (default) straight-line kernel, 0 the general one

@@ -237,6 +237,60 @@ static __global__ void __launch_bounds__(256) k_layernorm_rows(const float* __re
   }
 }
 
+// Split-contraction projection + residual + LayerNorm for FEW rows (H == 256 J): a K = 3072 projection of a few thousand rows is
+// 126 workgroups of 48 K steps -- a latency chain on a quarter of the chip (the frozen teacher's 64 x ~40-token targets, a query
+// batch of the evaluation loop).  The launcher cuts the contraction into `nsplit` slices (EPI_SLAB_F32: slab[s][row][H], no
+// bias), and this kernel finishes them: y = bias + sum_s slab[s] (fixed order) + residual, X = LayerNorm(y) -> bf16.
+template <int J>
+static __global__ void __launch_bounds__(256) k_slab_finish_ln(const float* __restrict__ slab, int nsplit, int64_t rows,
+                                                               const float* __restrict__ bias, const bf16_t* __restrict__ R,
+                                                               const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                               bf16_t* __restrict__ Xb) {
+  constexpr int H = 256 * J;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float4 x[J], gg[J], bb[J], part[4][J];
+  uint2 r[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int e0 = 256 * j + 4 * lane;
+    x[j] = *(const float4*)(bias + e0);
+    gg[j] = *(const float4*)(g + e0);
+    bb[j] = *(const float4*)(b + e0);
+    r[j] = *(const uint2*)(R + row * H + e0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      part[s][j] = *(const float4*)(slab + ((int64_t)(s < nsplit ? s : 0) * rows + row) * H + e0);   // (clamped: no branch around a load)
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < nsplit) { x[j].x += part[s][j].x; x[j].y += part[s][j].y; x[j].z += part[s][j].z; x[j].w += part[s][j].w; }
+    x[j].x += __uint_as_float(r[j].x << 16); x[j].y += __uint_as_float(r[j].x & 0xffff0000u);
+    x[j].z += __uint_as_float(r[j].y << 16); x[j].w += __uint_as_float(r[j].y & 0xffff0000u);
+    sum += x[j].x + x[j].y + x[j].z + x[j].w;
+  }
+  const float mean = wave_sum(sum) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const float a = x[j].x - mean, c = x[j].y - mean, d = x[j].z - mean, e = x[j].w - mean;
+    q += a * a + c * c + d * d + e * e;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int e0 = 256 * j + 4 * lane;
+    uint2 o;
+    o.x = pack_bf16x2((x[j].x - mean) * rstd * gg[j].x + bb[j].x, (x[j].y - mean) * rstd * gg[j].y + bb[j].y);
+    o.y = pack_bf16x2((x[j].z - mean) * rstd * gg[j].z + bb[j].z, (x[j].w - mean) * rstd * gg[j].w + bb[j].w);
+    *(uint2*)(Xb + row * H + e0) = o;
+  }
+}
+
 // fp32 rows -> LayerNorm -> bf16 rows: the straight-line kernel where it applies (convdr_set_option "ln_rows" 0: never)
 inline int64_t g_ln_rows = 1;
 static inline void launch_layernorm_bf16(const float* Y, int64_t rows, int H, const float* g, const float* b, float eps, bf16_t* Xb,

@@ -358,6 +358,8 @@ int convdr_adamw_step_packed(float* p, const float* g, float* m, float* v, int64
  * training backward of the attention in one workgroup per (sequence, head) for sequences of at most 256 tokens / always the
  * dQ kernel + the dK, dV kernel (default 1); "gelu_gp" = 1 / 0: gelu' evaluated in the training forward's FFN1 epilogue / the
  * pre-activation saved and a separate pass in the backward; "ip_fused_finish" = 1 / 0: one / three launches behind a scan;
+ * "ffn2_splitk" = 1 / 0: the K = 3072 projection of at most 5,376 packed rows as 4 / 2 contraction slices + a finishing row
+ * kernel / as whole-contraction tiles (default 1; fp32 summation order differs);
  * "ln_rows", "ln_bwd_rows" = straight-line LayerNorm forward (1 / 0) and backward (2 / 1 / 0) kernels for hidden size 768 against
  * the general ones (same formulas, rounding-level differences); "gemm_trace" / "gemm_trace_ln" = device buffer for the s_memtime phase stamps of a
  * `make TRACE=1` build (tools/gemm_trace*.py; 0 = off). */

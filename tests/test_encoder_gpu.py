@@ -113,6 +113,38 @@ def test_roberta_base_shape_matches_oracle():
     _check(emb2, ref2, "second call")
 
 
+@pytest.mark.parametrize("B,L", [(40, 96), (44, 128), (9, 24)])
+def test_few_rows_ffn2_split_contraction_matches_whole_contraction(B, L):
+    """Few packed rows (a query batch of the evaluation loop, the frozen teacher's targets of a training step): the K = 3072
+    projection is cut into 4 (<= 2.7 k rows) or 2 (<= 5.4 k rows) contraction slices and finished by k_slab_finish_ln (option
+    "ffn2_splitk" 1, default) instead of running as whole-contraction 128 x 128 tiles + k_layernorm (0).  Same products, another
+    fp32 summation order: embeddings of a 4-layer roberta-base-wide model agree to 1 - cos <= 1e-5 (and each with the fp32 oracle
+    to the suite's 1e-3 -- test_roberta_base_shape_matches_oracle runs the split path)."""
+    from convdr_amd import _lib
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    from tests.helpers import margin
+    torch.manual_seed(3)
+    model = MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig(num_hidden_layers=4)).cuda().eval()
+    rs = np.random.RandomState(B)
+    lens = rs.randint(L // 2, L + 1, size=B)
+    lens[0] = L
+    ids = rs.randint(3, 50000, size=(B, L)).astype(np.int64)
+    ids[:, 0] = 0
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    ids = ids * mask
+    ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    out = {}
+    try:
+        for mode in (0, 1):
+            _lib.check(_lib.lib().convdr_set_option(b"ffn2_splitk", mode), "set_option")
+            with torch.no_grad():
+                out[mode] = model.body_emb(ids_d, mask_d).double().cpu().numpy()
+    finally:
+        _lib.lib().convdr_set_option(b"ffn2_splitk", 1)
+    assert np.abs(out[0] - out[1]).max() > 0          # (the two paths really differ: the option reached the launcher)
+    margin("ffn2_splitk_vs_whole_1-cos_B%d" % B, (1 - cosine(out[0], out[1])).max(), 1e-5)
+
+
 def test_bench_size_batch_matches_oracle_on_a_sample():
     """BASELINE configs[1] encode batch (2048 x 128 tokens = 262,144 packed rows: the persistent 256 x 256 tiles, the
     fused projection + LayerNorm kernel with K-slice-major weights -- the kernels bench.py times).  The fp32 CPU oracle
