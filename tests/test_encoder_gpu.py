@@ -118,7 +118,7 @@ def test_few_rows_ffn2_split_contraction_matches_whole_contraction(B, L):
     """Few packed rows (a query batch of the evaluation loop, the frozen teacher's targets of a training step): the K = 3072
     projection is cut into 4 (<= 2.7 k rows) or 2 (<= 5.4 k rows) contraction slices and finished by k_slab_finish_ln (option
     "ffn2_splitk" 1, default) instead of running as whole-contraction 128 x 128 tiles + k_layernorm (0).  Same products, another
-    fp32 summation order: embeddings of a 4-layer roberta-base-wide model agree to 1 - cos <= 1e-5 (and each with the fp32 oracle
+    fp32 summation order: embeddings of a 4-layer roberta-base-wide model agree to 1 - cos <= 3e-5 (measured 7e-6; and each with the fp32 oracle
     to the suite's 1e-3 -- test_roberta_base_shape_matches_oracle runs the split path)."""
     from convdr_amd import _lib
     from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
@@ -142,7 +142,7 @@ def test_few_rows_ffn2_split_contraction_matches_whole_contraction(B, L):
     finally:
         _lib.lib().convdr_set_option(b"ffn2_splitk", 1)
     assert np.abs(out[0] - out[1]).max() > 0          # (the two paths really differ: the option reached the launcher)
-    margin("ffn2_splitk_vs_whole_1-cos_B%d" % B, (1 - cosine(out[0], out[1])).max(), 1e-5)
+    margin("ffn2_splitk_vs_whole_1-cos_B%d" % B, (1 - cosine(out[0], out[1])).max(), 3e-5)
 
 
 def test_bench_size_batch_matches_oracle_on_a_sample():

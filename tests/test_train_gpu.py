@@ -832,6 +832,9 @@ def test_layernorm_forward_straight_line_kernel_matches_general_kernel():
     ids, mask = ids.cuda(), mask.cuda()
     outs = {}
     try:
+        # (whole-contraction FFN2 for the few rows of this batch: its LayerNorm is then the kernel under test too; the split path
+        #  finishes with its own row kernel, tests/test_encoder_gpu.py)
+        _lib.check(_lib.lib().convdr_set_option(b"ffn2_splitk", 0), "set_option")
         for mode in (0, 1):
             _lib.check(_lib.lib().convdr_set_option(b"ln_rows", mode), "set_option")
             model.train()
@@ -842,6 +845,8 @@ def test_layernorm_forward_straight_line_kernel_matches_general_kernel():
             outs[mode] = (a, b)
     finally:
         _lib.lib().convdr_set_option(b"ln_rows", 1)
+        _lib.lib().convdr_set_option(b"ffn2_splitk", 1)
+    assert np.abs(outs[0][1] - outs[1][1]).max() > 0      # the option reached the launcher (the two kernels round differently there)
     for k, name in ((0, "train"), (1, "eval")):
         margin("ln_rows_vs_general_1-cos_%s" % name, (1 - cosine(outs[0][k], outs[1][k])).max(), 1e-5)
 
