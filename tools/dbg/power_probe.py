@@ -1,5 +1,5 @@
 """Is the encode power-capped?  Polls rocm-smi (power, sclk, mclk, temperature, perf level / power cap) every ~100 ms while a child
-process runs (a) the bench's encode loop (MFMA-bound), (b) an AdamW-sized streaming loop (HBM-bound), (c) nothing (idle)."""
+process runs (a) the bench's encode loop (MFMA-bound), (b) an AdamW-sized streaming loop (HBM-bound), (c) nothing (idle); `kd`: the configs[2] training step."""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -20,6 +20,9 @@ if mode == "encode":
             for _ in range(10):
                 m.body_emb(ids, mask)
             torch.cuda.synchronize()
+elif mode == "kd":
+    import bench
+    bench.train_kd_measure(dev, 0, 1, False, 900, 8, 64, with_kernels=False)
 elif mode == "stream":
     a = torch.zeros(1 << 28, device=dev); b = torch.ones(1 << 28, device=dev)
     t0 = time.time()
@@ -48,7 +51,7 @@ def smi():
         return {"error": repr(e)}
 
 
-for mode in ("idle", "encode", "stream"):
+for mode in (sys.argv[1:] or ["idle", "encode", "stream"]):
     p = subprocess.Popen([sys.executable, "-c", CHILD, mode], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     rows = []
     t0 = time.time()
