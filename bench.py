@@ -167,6 +167,48 @@ def _power_state():
     return out
 
 
+def power_under_load(run_steps, seconds=2.5):
+    """Socket power and shader clock WHILE the hot path runs (outside the timed region: `run_steps(n)` enqueues n more steps of the
+    timed workload): rocm-smi polled from a thread for `seconds`.  MI355X's package cap is 1400 W; the MFMA kernels of this path
+    sit at it (profiles/r05_power_probe.txt), which is what `clock_mhz_delivered` is the consequence of.  None when unreadable."""
+    import re
+    import subprocess
+    import threading
+    import torch
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                r = subprocess.run(["rocm-smi", "-d", "0", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10)
+                c = json.loads(r.stdout).get("card0", {})
+                w = [float(v) for k, v in c.items() if "power" in k.lower() and "max" not in k.lower()]
+                f = [int(re.sub(r"\D", "", v)) for k, v in c.items() if k.lower().startswith("sclk clock speed")]
+                if w and f:
+                    samples.append((time.perf_counter(), w[0], f[0]))
+            except Exception:
+                return
+            stop.wait(0.05)
+    try:
+        th = threading.Thread(target=poll, daemon=True)
+        t0 = time.perf_counter()
+        th.start()
+        while time.perf_counter() - t0 < seconds:
+            run_steps(4)
+            torch.cuda.synchronize()
+        stop.set()
+        th.join(timeout=12)
+        late = [(w, f) for t, w, f in samples if t - t0 > 0.4 * seconds]        # (rocm-smi's power figure is a moving average)
+        if not late:
+            return None
+        ws, fs = sorted(w for w, _ in late), sorted(f for _, f in late)
+        return {"socket_w_median": ws[len(ws) // 2], "socket_w_max": ws[-1], "sclk_mhz_median": fs[len(fs) // 2], "samples": len(late),
+                "source": "rocm-smi --showpower --showclocks polled while %.1f s of extra steps of the timed workload run" % seconds}
+    except Exception:
+        stop.set()
+        return None
+
+
 def flop_per_passage(L):
     return LINEAR_FLOP_PER_TOKEN * L + 36864 * L * L + 2 * H * D_OUT
 
@@ -1001,6 +1043,8 @@ def main():
         roof["peak_at_delivered_clock"] = MFMA_BF16_PEAK_TFLOPS * clock_mhz / 2400.0
         roof["frac_at_delivered_clock"] = dom_tf / roof["peak_at_delivered_clock"]
     roof["power"] = _power_state() if not args.no_extras else None     # (not in the profiler's child passes: rocm-smi is an exec)
+    if not args.no_extras and not dist_on and roof["power"] is not None:
+        roof["power_under_load"] = power_under_load(lambda n: [step(i) for i in range(n)])
     try:
         kname = "k_gemm<8, convdr::TileCfg<2, 4, 4, 2>"      # EPI_GELU_BLK on 256 x 256 tiles (k_gemm<1, ..> before round 3)
         rnd = next((r for r in ("r05", "r04", "r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r + "_bench_default.kernel_stats.txt"))), "r02")
