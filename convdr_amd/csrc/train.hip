@@ -169,7 +169,9 @@ static constexpr int dbg_skip() { return 0; }
 
 struct WgradFork {
   hipStream_t main, side;
-  hipEvent_t prod, fin, head_fin, emb_main;   // emb_main: the embedding gradients are written (recorded on the main stream, before the join)   // head_fin: the head's parameter-gradient jobs on the side stream have read p.part
+  hipEvent_t prod, fin;
+  hipEvent_t head_fin;   // the head's parameter-gradient jobs on the side stream have read p.part
+  hipEvent_t emb_main;   // the embedding gradients are written (recorded on the main stream, before the join)
   // "every gradient of layer l is written": one event on each stream (convdr_backward_wait_layer)
   hipEvent_t layer_main[TRAIN_MAX_LAYERS], layer_side[TRAIN_MAX_LAYERS];
   int layers_recorded;
@@ -444,16 +446,6 @@ struct ReduceList {
     return 0;
   }
 };
-
-// LayerNorm backward whose parameter gradients are finished at once on the same stream (head / CLS rows)
-static int ln_bwd(const float* dY, const bf16_t* dYadd, const float* Yin, int64_t rows, int H, const float* g, float eps, float* dXf,
-                  bf16_t* dXb, const TrainBufs& p, float* dbias, float* dgamma, float* dbeta, hipStream_t st) {
-  int blocks = 0;
-  if (int e = ln_bwd_kernel(dY, dYadd, Yin, rows, H, g, eps, dXf, dXb, p.part, &blocks, st)) return e;
-  ReduceList r;
-  r.add_ln(p.part, blocks, H, dbias, dgamma, dbeta);
-  return r.launch(st);
-}
 
 }  // namespace convdr
 
