@@ -958,11 +958,12 @@ class _StreamSets:
     Round 5 -- the choice checks itself on the REAL step (round 4 measured 1 process in 30-50 whose calibrated pair still
     serialised).  train_step stamps an event at its start; the period between two stamps, divided by the step's token count,
     is the step's cost.  After `PROBE` steps on set 0 the next `PROBE` run on set 1; whichever has the lower median cost
-    stays (set 1 must win by more than `MARGIN` to replace set 0).  From then on, three consecutive steps more than `DRIFT`
+    stays (set 1 must win by more than `MARGIN` to replace set 0; 2.5 %: the probe's own spread is ~1.5 %, a set in the
+    shared-queue mode costs 3-4 %).  From then on, three consecutive steps more than `DRIFT`
     above the best median this process has seen move the step to the other set.  Every decision is logged (logger
     "convdr_amd.train") and kept in `.decisions`.  Switching is safe between steps: every backward ends with the main stream
     waiting for its side streams.  CONVDR_STREAM_SELFCHECK=0 turns the watchdog off."""
-    PROBE, MARGIN, DRIFT = 4, 0.04, 0.08
+    PROBE, MARGIN, DRIFT = 4, 0.025, 0.08
 
     def __init__(self, device):
         self.device = device
@@ -1000,7 +1001,11 @@ class _StreamSets:
                 _log.warning("convdr_amd.train: stream calibration failed (%s): uncalibrated streams", e)
         s = [cands[i] for i in order]
         self.sets = [tuple(s[0:3]), tuple(s[3:6])]
-        if self.scores and self.scores[5][0] > 1.08 * self.scores[0][0]:
+        self.clusters = None
+        by_queue = self._sets_by_queue(cands, order, main) if (self.scores and not capturing) else None
+        if by_queue is not None:
+            self.sets = by_queue
+        elif self.scores and self.scores[5][0] > 1.08 * self.scores[0][0]:
             # fewer than six streams run beside the main one: the second set re-uses the good ones in other roles
             good = [cands[i] for us, i in self.scores if us <= 1.08 * self.scores[0][0]]
             if len(good) >= 2:
@@ -1008,6 +1013,61 @@ class _StreamSets:
             else:
                 self.sets[1] = self.sets[0]
         self._keep = cands
+
+    def _sets_by_queue(self, cands, order, main):
+        """Round 5, late: the roles of a set must not share a hardware queue with EACH OTHER either.  The step's +3 % mode
+        (19 % of fresh processes, profiles/r05_stream_queue_clusters.txt) was exactly the sets whose stream A (teacher / norms)
+        and stream B (weight-gradient branches) sat on one queue: A's per-layer norm kernels wait for events that B records, and
+        a waiting packet holds up whatever that queue carries behind it.  Streams are grouped by queue with a pairwise test --
+        one spinning thread on each of two streams (torch.cuda._sleep: no resource contention): together they take one spin
+        time on two queues, two on one -- and every set takes one stream from each of three groups.  None when the test is
+        unavailable or finds fewer than two groups (the caller keeps the order-of-calibration sets)."""
+        import time
+        sleep = getattr(torch.cuda, "_sleep", None)
+        if sleep is None or not self.scores:
+            return None
+        best, us_of = self.scores[0][0], {c: us for us, c in self.scores}
+        good = [i for i in order if us_of[i] <= 1.08 * best]      # (the streams that run beside the main one)
+        if len(good) < 2:
+            return None
+        spin = 200_000            # ~0.1 ms
+
+        def pair_us(x, y):
+            t = float("inf")
+            for _ in range(3):
+                torch.cuda.synchronize()
+                ev = torch.cuda.Event()
+                ev.record(main)
+                t0 = time.perf_counter()
+                for st in (x, y):
+                    with torch.cuda.stream(st):
+                        st.wait_event(ev)
+                        sleep(spin)
+                torch.cuda.synchronize()
+                t = min(t, time.perf_counter() - t0)
+            return t
+        try:
+            with torch.cuda.device(self.device):
+                one = pair_us(cands[good[0]], cands[good[0]]) / 2.0
+                groups, left = [], list(good)
+                while left:
+                    head, rest = left[0], left[1:]
+                    same = [j for j in rest if pair_us(cands[head], cands[j]) > 1.6 * one]
+                    groups.append([head] + same)
+                    left = [j for j in rest if j not in same]
+        except RuntimeError:
+            return None
+        self.clusters = groups
+        if len(groups) < 2:
+            return None
+        groups = sorted(groups, key=len, reverse=True)[:3]
+        sets = []
+        for k in range(2):
+            pick = [cands[g[k % len(g)]] for g in groups]
+            if len(pick) == 2:                     # two queues beside the main one: A and B apart, C rides with A
+                pick.append(pick[0])
+            sets.append(tuple(pick))
+        return sets
 
     def _apply(self):
         with torch.cuda.device(self.device):
@@ -1108,7 +1168,8 @@ def stream_decisions(device=None):
     """The stream watchdog's log for `device` (diagnostics): calibration scores and every decision taken so far."""
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     ss = _stream_sets(dev)
-    return {"scores_us": ss.scores, "active_set": ss.active, "decisions": list(ss.decisions), "medians": dict(ss.median),
+    return {"scores_us": ss.scores, "queue_groups": getattr(ss, "clusters", None), "active_set": ss.active,
+            "decisions": list(ss.decisions), "medians": dict(ss.median),
             "phase": ss.phase if ss.enabled and ss.sets[0] is not ss.sets[1] else "off"}
 
 

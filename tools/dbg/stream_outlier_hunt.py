@@ -12,8 +12,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     TR.reserve_streams(dev)
     d = bench.train_kd_measure(dev, 0, 1, False, 20, 16, 64, with_kernels=False, dropout=0.1)
     info = TR.stream_decisions(dev)
-    print("%.3f ms/step | calibration %s | active set %d | %s" %
-          (d["ms_per_step"], info["scores_us"], info["active_set"], " || ".join(info["decisions"])), flush=True)
+    print("%.3f ms/step | calibration %s | queue groups %s | active set %d | %s" %
+          (d["ms_per_step"], info["scores_us"], info.get("queue_groups"), info["active_set"], " || ".join(info["decisions"])), flush=True)
 else:
     for i in range(int(os.environ.get("N", "30"))):
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], stderr=subprocess.DEVNULL)
