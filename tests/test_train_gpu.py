@@ -1557,6 +1557,12 @@ def test_stream_watchdog_probes_both_sets_and_moves_on_drift():
     assert len(ss.sets) == 2 and all(len(s) == 3 for s in ss.sets) and ss.scores is not None
     if ss.sets[0] is not ss.sets[1]:
         assert len({id(x) for x in ss.sets[0]} & {id(x) for x in ss.sets[1]}) < 3
+    if ss.clusters is not None and len(ss.clusters) >= 2:
+        # sets formed by hardware queue: the teacher / norm stream (A) and the weight-gradient stream (B) of a set never share one
+        group_of = {id(ss._keep[i]): g for g, members in enumerate(ss.clusters) for i in members}
+        for st in ss.sets:
+            assert group_of[id(st[0])] != group_of[id(st[1])], (ss.clusters, [group_of[id(x)] for x in st])
+        assert sum(len(m) for m in ss.clusters) >= 4          # (MI355X: seven of eight candidates beside the main stream, three queues)
     # set 1 clearly cheaper -> kept; later drift -> back to set 0
     for c in (1.00, 1.01, 0.99, 1.00):
         ss._feed(0, c)
