@@ -33,6 +33,52 @@ def _rehearsal_device(local_rank):
     return 0 if os.environ.get("CONVDR_BENCH_SHARE_GPU") else local_rank
 
 
+def _launch_ranks_if_needed(args):
+    """`--gpus N` MEANS N ranks.  Called before anything touches the GPU (this process has imported neither torch nor the
+    HIP library yet; a process that has initialised the GPU is never re-exec'd).
+      * WORLD_SIZE set (torchrun / the driver's launch line) and == --gpus: this process is one of the ranks, go on.
+      * WORLD_SIZE set and != --gpus: exit 2 -- a line labelled n_gpus = WORLD_SIZE under a `--gpus N` command is the
+        worst failure mode a scaling run can have.
+      * WORLD_SIZE unset and --gpus N > 1: this process becomes the launcher: N children of this same command line, one per
+        device (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR = 127.0.0.1 / a free MASTER_PORT), rank 0's JSON line passes
+        through on the inherited stdout, and the launcher exits with the first non-zero child status (the others are
+        terminated) -- the one-process-per-GPU shape of gen_passage_embeddings.py:305-315 without needing torchrun."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s: refusing to run a mislabelled job "
+                             "(launch with --nproc-per-node == --gpus)\n" % (args.gpus, ws))
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    kids = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = set(range(args.gpus))
+    while live:
+        for r in sorted(live):
+            st = kids[r].poll()
+            if st is None:
+                continue
+            live.discard(r)
+            if st != 0 and rc == 0:
+                rc = st if st > 0 else 128 - st
+                sys.stderr.write("bench.py launcher: rank %d exited with status %d; stopping the other ranks\n" % (r, st))
+                for o in live:
+                    kids[o].terminate()       # (exact PIDs this launcher started)
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
 def _init_group(dev):
     """RCCL ("nccl" on ROCm).  CONVDR_BENCH_BACKEND=gloo is the companion of CONVDR_BENCH_SHARE_GPU: RCCL refuses two ranks
     on one device, gloo moves the same CUDA tensors through the host -- the launch line, the rank logic and every kernel
@@ -863,6 +909,10 @@ def main():
     ap.add_argument("--train-dropout", type=float, default=0.1,
                     help="student dropout of the train_kd workload (the reference's training configuration: 0.1)")
     args = ap.parse_args()
+    _launch_ranks_if_needed(args)
+    if os.environ.get("CONVDR_BENCH_LAUNCH_DRYRUN"):       # (tests/test_bench_launcher_cpu.py: the launcher without a GPU)
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}), flush=True)
+        sys.exit(int(os.environ.get("CONVDR_BENCH_LAUNCH_DRYRUN_FAIL_RANK", "-1")) == int(os.environ.get("RANK", "0")) and 7 or 0)
     if args.workload == "train_kd":
         return main_train(args)
 

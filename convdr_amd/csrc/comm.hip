@@ -10,6 +10,7 @@
 // whichever librccl.so is already mapped (RTLD_NOLOAD), else the system one.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <stdio.h>
 #include <string.h>
 
 #include "common.hpp"
@@ -28,19 +29,21 @@ struct Rccl {
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
+  char why[256] = "symbols missing";   // the reason `ok` is false (dlerror() is read ONCE, at the failure site: a second call returns NULL)
 };
 
-static Rccl& rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r;
-  tried = true;
+static Rccl load_rccl() {
+  Rccl r;
   const char* names[] = {"librccl.so", "librccl.so.1"};
   for (const char* n : names)
     if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // the copy this process already uses (torch's)
   for (const char* n : names)
     if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-  if (!r.h) return r;
+  if (!r.h) {
+    const char* e = dlerror();
+    snprintf(r.why, sizeof r.why, "%s", e ? e : "dlopen failed");
+    return r;
+  }
   auto sym = [&](const char* s) { return dlsym(r.h, s); };
   r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
@@ -51,6 +54,11 @@ static Rccl& rccl() {
   r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
   r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce && r.CommCount && r.CommUserRank;
+  return r;
+}
+
+static Rccl& rccl() {
+  static Rccl r = load_rccl();   // function-local static: initialised once, thread-safe (C++11)
   return r;
 }
 
@@ -70,7 +78,7 @@ using namespace convdr;
 static_assert(CONVDR_COMM_ID_BYTES == sizeof(ncclUniqueId), "convdr_hip.h: CONVDR_COMM_ID_BYTES must be RCCL's unique-id size");
 
 extern "C" int convdr_comm_unique_id(void* id_out_host) {
-  CONVDR_REQUIRE(rccl().ok, "convdr_comm: librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+  CONVDR_REQUIRE(rccl().ok, "convdr_comm: librccl.so could not be loaded (%s)", rccl().why);
   ncclUniqueId id;
   CONVDR_CHECK_RCCL(rccl().GetUniqueId(&id));
   memcpy(id_out_host, &id, sizeof id);
@@ -78,7 +86,7 @@ extern "C" int convdr_comm_unique_id(void* id_out_host) {
 }
 
 extern "C" int convdr_comm_init(convdr_comm_t* comm, int nranks, int rank, const void* unique_id_host) {
-  CONVDR_REQUIRE(rccl().ok, "convdr_comm: librccl.so could not be loaded");
+  CONVDR_REQUIRE(rccl().ok, "convdr_comm: librccl.so could not be loaded (%s)", rccl().why);
   CONVDR_REQUIRE(comm && unique_id_host && nranks >= 1 && rank >= 0 && rank < nranks, "convdr_comm_init: bad arguments (rank %d of %d)", rank, nranks);
   ncclUniqueId id;
   memcpy(&id, unique_id_host, sizeof id);

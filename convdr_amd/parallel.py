@@ -150,11 +150,13 @@ def shard_batch(batch, rank=None, world=None, return_weight=False):
     """This rank's contiguous slice of a GLOBAL batch (a tuple / list / dict of tensors or arrays whose first dimension is
     the batch): what nn.DataParallel's scatter hands replica `rank` (run_convdr_train.py:52,77-78).  For drivers that keep
     the reference's single global batch (e.g. to replay one of its runs); a DistributedSampler run never needs it.
-    A batch that does not divide over the ranks is cut like DataParallel cuts it (`shard_sizes`: the last replica short).
-    The reference computes its mean losses over the gathered outputs of ALL replicas, so with per-rank mean losses the
-    global gradient is sum_r (n_r / n) grad_r: return_weight=True also returns n_r W / n, the factor `train_step(...,
-    loss_weight=)` multiplies this rank's loss by before the backward (the all-reduce sums and 1 / W rides on the clip
-    pass).  A rank left without samples raises: it would still have to join the step's collectives."""
+    A batch that does not divide over the ranks is cut like DataParallel cuts it (`shard_sizes`: the last replica short)
+    -- but ONLY with return_weight=True.  The reference computes its mean losses over the gathered outputs of ALL replicas,
+    so with per-rank mean losses the global gradient is sum_r (n_r / n) grad_r: return_weight=True also returns n_r W / n,
+    the factor `train_step(..., loss_weight=)` multiplies this rank's loss by before the backward (the all-reduce sums and
+    1 / W rides on the clip pass).  Without the weight a ragged cut would silently train on the mean of per-rank means,
+    so return_weight=False raises ValueError for a batch that does not divide.  A rank left without samples
+    raises: it would still have to join the step's collectives."""
     W = _world() if world is None else int(world)
     r = (dist.get_rank() if W > 1 else 0) if rank is None else int(rank)
     if W == 1:
@@ -169,6 +171,9 @@ def shard_batch(batch, rank=None, world=None, return_weight=False):
         sizes = shard_sizes(n, W)
         if sizes[r] == 0:
             raise ValueError("shard_batch: a batch of %d leaves rank %d of %d without samples" % (n, r, W))
+        if n % W and not return_weight:
+            raise ValueError("shard_batch: a batch of %d does not divide over %d ranks; the ragged cut needs its loss weight "
+                             "(return_weight=True -> train_step(..., loss_weight=))" % (n, W))
         seen.append((n, sizes[r]))
         b = sum(sizes[:r])
         return x[b:b + sizes[r]]
@@ -194,7 +199,11 @@ class DataParallelStudent:
             if info is not None:
                 dist.broadcast(info["P"], 0, group=group)
                 self.broadcast_collectives += 1
-                done = {id(p) for p in info["params"]}
+                # only the parameters that still ALIAS the arena are synchronised by that broadcast (model.to() or a .data
+                # re-assignment after flatten_parameters re-homes them): the others take the per-tensor broadcast below
+                base = info["P"].data_ptr()
+                done = {id(p) for p in info["params"] if p.data_ptr() == base + 4 * info["off"][id(p)]}
+                self.rehomed_parameters = len(info["params"]) - len(done)
             for t in list(model.parameters()) + list(model.buffers()):
                 if id(t) not in done:
                     dist.broadcast(t.data, 0, group=group)

@@ -218,6 +218,11 @@ class FlatIPIndex:
             if arr.dtype == np.float32 and arr.ndim == 2 and arr.shape[0] * arr.shape[1] * 4 > chunk_bytes // 2:
                 return self._add_host_streamed(arr, chunk_bytes)
         from_host = not (isinstance(x, torch.Tensor) and x.is_cuda)
+        if isinstance(x, np.ndarray) and not x.flags.writeable:
+            # a read-only array (the mmap of a small block file): torch.as_tensor would alias it without knowing it must
+            # never write (a UserWarning today, undefined behaviour the day someone does) -- small by construction (large
+            # host blocks took the streamed path above), so it is copied first
+            x = np.array(x, dtype=np.float32, order="C")
         t = torch.as_tensor(x)
         if t.dtype != torch.float32:
             t = t.float()
@@ -371,6 +376,8 @@ class FlatIPIndex:
         import torch
         L = _lib.lib()
         cap = cap or self.cap
+        while cap < 2 * k and cap < 8192:      # the candidate list holds at least 2k entries (csrc/ip_topk.hip: k <= cap / 2)
+            cap *= 2
         if x3 is None:
             x3 = self.precision in ("bf16x3", "fp16x3")
         if x3:
@@ -449,12 +456,19 @@ class FlatIPIndex:
         qt = (self._pad_columns(qt) if self.d != self.d_in else qt.to(self.device)).contiguous()
         assert qt.dim() == 2 and qt.shape[1] == self.d
         k = int(k)
+        if k > self.MAX_K:
+            # the reference takes any --top_n (run_convdr_inference.py:316-319); the kernel pipeline's candidate lists end at
+            # 8192 entries, so larger k takes the chunked host-side route (exact, slow): see _search_large_k
+            return (qt, k, None, None, None, None, None)
         x3 = self.precision in ("bf16x3", "fp16x3") or (self.precision == "auto" and getattr(self, "_x3_first", False) and self.ntotal > 0)
         return (qt, k, x3) + tuple(self.search_device(qt, k, x3=x3))
 
     def search_finish(self, handle):
         import torch
         qt, k, x3, D, I, status, tau_retry = handle
+        if x3 is None:
+            self.stats = {"retried": 0, "rounds": 0, "x3_queries": 0, "x3_first": False, "rescaled": 0, "large_k": k}
+            return self._search_large_k(qt, k)
         nq = int(qt.shape[0])
         rescaled = 0
         n_range, n_bad = torch.stack([(status == STATUS_RANGE).sum(), (status != 0).sum()]).tolist()   # one host round trip
@@ -506,6 +520,68 @@ class FlatIPIndex:
             D[idx], I[idx] = Db, Ib
             self.stats["exhaustive_queries"] = len(bad)
         return D, I
+
+    MAX_K = 4096         # convdr_ip_search: k <= cap / 2, cap <= 8192
+
+    def _search_large_k(self, q, k, q_chunk=8):
+        """Exact top-k for k > MAX_K (any --top_n, run_convdr_inference.py:316-319) by chunking on the host side of the
+        same kernels: every slice of <= 4096 rows is RANKED COMPLETELY by the exhaustive plan (all rows candidates, canonical
+        fp64 scores, kq = rows), the slices' sorted lists are merged by a stable descending sort of the fp32-rounded scores
+        (rounding is monotone: only rows whose scores round to the SAME fp32 value can be out of canonical order, and only
+        across slices), and every run of equal fp32 scores that spans slices or straddles rank k is ranked once more as one
+        slice.  Slow (n / 4096 launch chains per 8 queries, an [8, n] sort), always the exhaustive exact answer."""
+        import torch
+        L = _lib.lib()
+        nq, n = int(q.shape[0]), self.ntotal
+        Dout = torch.full((nq, k), -3.4028234663852886e38, dtype=torch.float32, device=self.device)
+        Iout = torch.full((nq, k), -1, dtype=torch.int64, device=self.device)
+        if n == 0:
+            return Dout, Iout
+        cap, step = 8192, 4096
+
+        def exact(p32, pbf, m, kq, qq):
+            D = torch.empty((qq.shape[0], kq), dtype=torch.float32, device=self.device)
+            I = torch.empty((qq.shape[0], kq), dtype=torch.int64, device=self.device)
+            status = torch.empty(qq.shape[0], dtype=torch.int32, device=self.device)
+            tau_retry = torch.empty(qq.shape[0], dtype=torch.float32, device=self.device)
+            ws = self._workspace(L.convdr_ip_workspace_bytes(int(qq.shape[0]), m, self.d, kq, cap))
+            self._search_call(qq, int(qq.shape[0]), p32, pbf, None, m, kq, None, cap, 0, ws, D, I, status, tau_retry)
+            if int((status != 0).sum().item()):
+                raise _lib.ConvdrError("convdr_ip_search: exhaustive slice of %d rows not certified" % m)
+            return D, I
+
+        with torch.cuda.device(self.device):
+            for j0 in range(0, nq, q_chunk):
+                qq = q[j0:j0 + q_chunk].contiguous()
+                Ds, Is = [], []
+                for s0 in range(0, n, step):
+                    m = min(n, s0 + step) - s0
+                    D, I = exact(self._p32[s0:s0 + m], self._pbf[s0:s0 + m], m, m, qq)
+                    Ds.append(D)
+                    Is.append(I + s0)
+                Dall, Iall = torch.cat(Ds, 1), torch.cat(Is, 1)
+                order = torch.sort(Dall, dim=1, descending=True, stable=True).indices
+                Dall, Iall = torch.gather(Dall, 1, order), torch.gather(Iall, 1, order)
+                kk = min(k, n)
+                for j in range(qq.shape[0]):
+                    d, i = Dall[j], Iall[j]
+                    # end of the run of equal fp32 scores that contains rank kk - 1
+                    end = kk + int((d[kk:] == d[kk - 1]).sum().item()) if kk < n else kk
+                    d, i = d[:end].clone(), i[:end].clone()
+                    # runs of equal scores (start, length) with more than one member
+                    new = torch.ones(end, dtype=torch.bool, device=self.device)
+                    new[1:] = d[1:] != d[:-1]
+                    starts = torch.nonzero(new).flatten()
+                    lens = torch.diff(torch.cat([starts, torch.tensor([end], device=self.device)]))
+                    for b, ln in zip(starts[lens > 1].tolist(), lens[lens > 1].tolist()):
+                        if ln > step:
+                            raise _lib.ConvdrError("FlatIPIndex.search: %d passages share one fp32 score around rank %d; "
+                                                   "k > %d cannot order a tie group that large" % (ln, b, self.MAX_K))
+                        rows = torch.sort(i[b:b + ln]).values
+                        Dj, Ij = exact(self._p32[rows].contiguous(), self._pbf[rows].contiguous(), ln, ln, qq[j:j + 1].contiguous())
+                        d[b:b + ln], i[b:b + ln] = Dj[0], rows[Ij[0]]
+                    Dout[j0 + j, :kk], Iout[j0 + j, :kk] = d[:kk], i[:kk]
+        return Dout, Iout
 
     def _search_exhaustive(self, q, k):
         import torch

@@ -963,11 +963,11 @@ class _StreamSets:
     above the best median this process has seen move the step to the other set.  Every decision is logged (logger
     "convdr_amd.train") and kept in `.decisions`.  Switching is safe between steps: every backward ends with the main stream
     waiting for its side streams.  CONVDR_STREAM_SELFCHECK=0 turns the watchdog off."""
-    PROBE, MARGIN, DRIFT = 4, 0.025, 0.08
+    PROBE, MARGIN, DRIFT, REBASE = 4, 0.025, 0.08, 24
 
     def __init__(self, device):
         self.device = device
-        self.sets, self.scores, self.decisions = [], None, []
+        self.sets, self.scores, self.decisions = [], None, collections.deque(maxlen=64)
         self.active = 0
         self.enabled = os.environ.get("CONVDR_STREAM_SELFCHECK", "1") != "0"
         self.pending = collections.deque()      # (event at the start of a step, tokens of that step, set index)
@@ -976,6 +976,8 @@ class _StreamSets:
         self.phase = "probe0"
         self.skip = 2                           # steps whose period is not used (the first ones, and those around a switch)
         self.high = 0
+        self.moves = collections.deque(maxlen=4)     # step indices of the watchdog's last drift moves (re-baselining, below)
+        self.nsteps = 0
         self._calibrate()
         self._apply()
 
@@ -1106,6 +1108,9 @@ class _StreamSets:
     def _feed(self, k, cost):
         xs = self.samples.setdefault(k, [])
         xs.append(cost)
+        self.nsteps += 1
+        if len(xs) > 64:
+            del xs[:-16]
         med = float(np.median(xs[-self.PROBE:]))
         if self.phase == "probe0":
             if len(xs) >= self.PROBE:
@@ -1122,11 +1127,24 @@ class _StreamSets:
                 else:
                     self._decide("stream self-check: set 0 stays (%.4f vs %.4f ms per k-token on set 1)" % (self.median[0], med), 0)
         else:
-            best = min(self.median.values())
             if len(xs) >= self.PROBE and med < self.median.get(k, float("inf")):
                 self.median[k] = med
+            if not self.median:                  # (just re-baselined: no judgement until this set has PROBE fresh samples)
+                return
+            best = min(self.median.values())
             self.high = self.high + 1 if cost > (1.0 + self.DRIFT) * best else 0
             if self.high >= 3:
+                # Two drift moves within REBASE steps mean BOTH sets have just been seen "high": it is the workload that got
+                # dearer per token (longer sequences: attention is not linear in length; ranking documents), not a stream
+                # set gone bad -- `best` never rises by itself, so without this the watchdog would hop sets every ~5 steps
+                # for good.  Re-baseline: forget the medians, stay, probe this set afresh.
+                if self.moves and self.nsteps - self.moves[-1] <= self.REBASE:
+                    self.moves.clear()
+                    self.median = {}
+                    self._decide("stream self-check: both sets high within %d steps (%.4f vs %.4f ms per k-token): the workload "
+                                 "changed, not the streams -- re-baselining on set %d" % (self.REBASE, cost, best, k))
+                    return
+                self.moves.append(self.nsteps)
                 other = 1 - k
                 self.median.pop(other, None)     # (re-measured after the move; if it is no better the next drift moves back)
                 self._decide("stream self-check: three steps in a row %.0f %% above this process's best (%.4f vs %.4f ms per k-token):"
@@ -1147,12 +1165,13 @@ def _aux_streams(device):
     return _stream_sets(device).current()
 
 
-def _watch_step_begin(device, sig):
+def _watch_step_begin(device, sig, doc_tokens=0.0):
     concat_lens, target_lens, cshape, tshape = sig
-    # a step's work in tokens: the student's rows count three times (forward + backward), the teacher's once
+    # a step's work in tokens: the student's rows count three times (forward + backward), the teacher's once -- its target
+    # rows and, in a ranking step that re-encodes them, its document rows (doc_tokens)
     ws = float(np.sum(concat_lens)) if concat_lens is not None else float(cshape[0] * cshape[1])
     wt = float(np.sum(target_lens)) if target_lens is not None else float(tshape[0] * tshape[1])
-    _stream_sets(device).step_begin(3.0 * ws + wt)
+    _stream_sets(device).step_begin(3.0 * ws + wt + float(doc_tokens))
 
 
 def reserve_streams(device=None):
@@ -1204,8 +1223,12 @@ class TeacherEmbeddingCache:
     applied to run_convdr_train.py:110-112).  The teacher has no dropout in eval mode and never changes, so
     teacher_model(target_ids, target_id_mask) of a sample is the same tensor every epoch: from the second epoch on (or after a
     precompute pass) `train_step(..., teacher_embs=cache.lookup(ids))` replaces the teacher's forward -- 0.45-0.6 ms of a
-    9.8 ms configs[2] step -- with a row gather.  Numerically identical to the reference flow: the rows ARE earlier outputs
-    of the same forward.  The reference flow (teacher run every step) stays the default of train_step.
+    9.8 ms configs[2] step -- with a row gather.  The rows ARE earlier outputs of the same forward; they are bit-identical
+    to what the step's own teacher forward would produce only when that earlier forward saw the same packed-row count (the
+    launcher picks whole-contraction tiles, the split-K FFN2 or the fused LayerNorm path by row count, and the fp32 summation
+    order differs between them: 1 - cos ~ 1e-5, far inside the 1e-3 bar).  `fill(chunk=B)` with the training batch size (or
+    `put` from the first epoch's own steps) reproduces the training step's kernel path.  The reference flow (teacher run
+    every step) stays the default of train_step.
     Storage: one fp32 [capacity, E] device tensor + a host dict id -> row."""
 
     def __init__(self, capacity, dim=768, device="cuda"):
@@ -1266,7 +1289,8 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
     _set_mode(model, True)
     if teacher_model is not None:
         _set_mode(teacher_model, False)
-    _watch_step_begin(concat_ids.device, (concat_lens, target_lens, concat_ids.shape, target_ids.shape))
+    doc_tokens = float(doc_ids.numel()) if (getattr(args, "ranking_task", False) and doc_embs is None and doc_ids is not None) else 0.0
+    _watch_step_begin(concat_ids.device, (concat_lens, target_lens, concat_ids.shape, target_ids.shape), doc_tokens)
     # The frozen teacher's forward is independent of the student's and, at 64 x 64 tokens, fills barely a third of the
     # CUs: it runs on a side stream under the student's forward and is joined before the loss needs it.
     main = torch.cuda.current_stream()

@@ -621,3 +621,21 @@ def test_one_launch_finish_equals_the_three_launch_chain(torch_cuda, n, nq, k, d
     Dr, Ir = OS.flat_ip_search(Q, P, k)
     np.testing.assert_array_equal(out[1][1], Ir)
     np.testing.assert_array_equal(out[1][0], Dr)
+
+
+@pytest.mark.parametrize("n,nq,k,d", [(9000, 3, 3000, 64), (13000, 3, 5000, 64), (13000, 2, 13000, 128), (6000, 2, 9000, 64)])
+def test_top_n_above_the_kernel_limit_is_chunked_on_the_host(torch_cuda, n, nq, k, d):
+    """The reference takes any --top_n (run_convdr_inference.py:316-319).  k in (2048, 4096] needs the 8192-entry candidate
+    list; k > 4096 takes FlatIPIndex._search_large_k (slices ranked completely, merged, fp32-tie runs re-ranked): still the
+    oracle's (D, I), bit for bit -- with duplicated rows in different slices so that equal scores meet across slices and
+    across rank k."""
+    P, Q = synth_corpus(300 + n % 83, n, d), synth_corpus(9, nq, d)
+    P[n - 50:n - 10] = P[10:50]                 # exact duplicates 4096-row slices apart: cross-slice ties, index order decides
+    idx = _index(d)
+    idx.add(P)
+    D, I = idx.search(Q, k)
+    Dr, Ir = OS.flat_ip_search(Q, P, k)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D, Dr)
+    if k > 4096:
+        assert idx.stats.get("large_k") == k

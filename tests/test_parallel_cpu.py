@@ -298,3 +298,6 @@ def test_distributed_sampler_and_batch_sharding():
         assert abs(sum(w / W * b[0].mean().item() for b, w in got) - x.mean().item()) < 1e-6
     with pytest.raises(ValueError):
         parallel.shard_batch((torch.zeros(5, 2),), rank=3, world=4)      # torch.chunk(5, 4) = 2, 2, 1: rank 3 is empty
+    with pytest.raises(ValueError, match="return_weight"):
+        parallel.shard_batch((torch.zeros(7, 2),), rank=0, world=2)      # ragged cut without its loss weight: refused
+    assert parallel.shard_batch((torch.zeros(8, 2),), rank=1, world=2)[0].shape[0] == 4
