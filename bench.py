@@ -443,6 +443,22 @@ def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=
         comm["gradient_allreduce"]["one_collective_alone_GB_per_s_algorithmic"] = flat.numel() * 4 / 1e9 / (comm["gradient_allreduce"]["one_collective_alone_ms"] / 1e3)
         comm["constructor_broadcast_collectives"] = ddp.broadcast_collectives
         del big
+        # the same steps with the word-embedding gradient exchanged as (row ids, rows) -- DataParallelStudent(sparse_embedding=
+        # True): one all-gather + a rank-ordered local scatter-add instead of the 154 MB dense all-reduce that cannot start
+        # before the backward has ended.  Bytes of both forms per step and rank; the time is only meaningful over RCCL.
+        ddp_s = DataParallelStudent(student, broadcast=False, sparse_embedding=True)
+        for i in range(2):
+            TR.train_step(targs, student, teacher, opt, sched, batches[i % 4], ddp=ddp_s, force_overlap=dist_on and world == 1)
+        sync_all()
+        t3 = time.perf_counter()
+        for i in range(steps):
+            TR.train_step(targs, student, teacher, opt, sched, batches[i % 4], ddp=ddp_s, force_overlap=dist_on and world == 1)
+        sync_all()
+        t3 = torch.tensor([time.perf_counter() - t3], device=dev, dtype=torch.float64)
+        dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+        comm["gradient_allreduce"]["sparse_embedding_exchange"] = dict(
+            ddp_s.last_comm, ms_per_step=t3.item() / steps * 1e3, exposed_ms_per_step=(t3.item() - t2.item()) / steps * 1e3,
+            note="synthetic uniform token ids: ~14 k distinct ids per 64 x 256-token batch (the worst case; natural text repeats far more)")
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()

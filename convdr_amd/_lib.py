@@ -55,7 +55,9 @@ def lib():
                               "or `make -C convdr_amd/csrc`" % LIB_PATH)
         # torch first: libconvdr_hip.so must bind to the HIP runtime (libamdhip64) that torch has loaded, not a
         # second copy -- two runtimes in one process do not share devices, streams or allocations
-        import torch  # noqa: F401
+        # (CONVDR_LIB_NO_TORCH=1: tests/capi/san_driver.py only -- the host-sanitizer build is driven without torch in the process)
+        if not os.environ.get("CONVDR_LIB_NO_TORCH"):
+            import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in _SIGNATURES.items():
             f = getattr(_lib, name)

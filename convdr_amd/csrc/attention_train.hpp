@@ -15,6 +15,8 @@
 // Tiles arrive by LDS-DMA through a buffer descriptor whose window ends with the last packed row: rows past it read as
 // zeros (0 x finite, never 0 x junk, in the MFMAs whose other operand is masked to zero).  Two tile sets in flight.
 #pragma once
+#include <type_traits>
+
 #include "encoder_kernels.hpp"
 
 namespace convdr {
@@ -121,7 +123,21 @@ struct AttnTrainArgs {
   int64_t ldt;
   float scale;
   const int32_t* order;   // [B] or null: workgroup z works on sequence order[z] (k_len_order: longest first)
+  uint32_t* mbits;        // [heads][ATTM_PIECES][ldt] or null: the dropout keep bits of this forward, for k_attention_bwd_fused
+  float* cls32;           // [B, H] or null: the context row of every sequence's FIRST query in fp32 (last layer, CLS pooling): the
+                          // backward's D = dO . O of the only queries that carry gradient there -- see AttnBwdArgs::cls32
 };
+
+// Dropout keep bits, forward -> backward (round 6).  The mask stays DEFINED by csrc/dropout.hpp (oracle/dropout.py); the
+// forward, which has to evaluate the hash anyway, additionally leaves one bit per (query, key) behind, and the one-workgroup
+// backward reads bits instead of hashing again: the hash was 36 % of that kernel's instruction stream (227 of 625 VALU
+// instructions per 32 queries x 32 keys per wave, ISA count) for 2 instructions per element here.
+//   word (head, piece p = 2 * (key >> 6) + ((key >> 3) & 1), packed query row):
+//   bit  e = 16 * ((key >> 5) & 1) + 8 * ((key >> 4) & 1) + (key & 7)   -- a forward lane's 32 registers of one 64-key tile
+// i.e. exactly the 32 (kt, r) elements a forward lane (query, hi = (key >> 3) & 1) holds, in register order: the forward
+// assembles a word with no data movement, the backward lane (= key) extracts ITS bit of the words of the step's queries.
+// Only for sequences of at most ATTF_MAX_LEN = 256 tokens (four key tiles: ATTM_PIECES = 8), the one-workgroup backward.
+constexpr int ATTM_PIECES = 8;
 
 // Dispatch order of the attention kernels of a training step: sequences in descending length (ties: ascending index).
 // A ragged batch (configs[2]: 32 .. 256 tokens) gives these kernels workgroups of 1 .. 4 tiles x 1 .. 8 waves of work, three
@@ -140,6 +156,7 @@ static __global__ void __launch_bounds__(256) k_len_order(const int32_t* __restr
   order[rank] = b;
 }
 
+template <bool DROP>
 static __global__ void __launch_bounds__(256, 3) k_attention_train_fwd(const AttnTrainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K tile | V tile)
   const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
@@ -232,17 +249,21 @@ static __global__ void __launch_bounds__(256, 3) k_attention_train_fwd(const Att
     l = l * alpha + ps;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-    if (a.drop.thresh) {   // dropout on the probabilities (the softmax denominator above is that of the undropped row)
+    if constexpr (DROP) {   // dropout on the probabilities (the softmax denominator above is that of the undropped row)
       const uint32_t db = drop_att_base(base + qc, gridDim.y, h);
+      uint32_t word = 0u;   // keep bits of this lane's 32 elements, register order (see ATTM_PIECES)
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const int key = kv0 + 32 * kt + 16 * (r >> 3) + 8 * hi + (r & 7);
-          float m0, m1;
-          drop_pair(a.drop, db + (uint32_t)(key >> 1), m0, m1);
-          st[kt][r] *= m0; st[kt][r + 1] *= m1;
+          const uint32_t hh = drop_mix32((db + (uint32_t)(key >> 1)) ^ a.drop.key);
+          const bool k0 = (hh & 0xffffu) >= a.drop.thresh, k1 = (hh >> 16) >= a.drop.thresh;
+          st[kt][r] *= k0 ? a.drop.scale : 0.f;
+          st[kt][r + 1] *= k1 ? a.drop.scale : 0.f;
+          word |= (k0 ? 1u << (16 * kt + r) : 0u) | (k1 ? 2u << (16 * kt + r) : 0u);
         }
+      if (a.mbits && q < len) a.mbits[((int64_t)(h * ATTM_PIECES + 2 * it + hi)) * a.ldt + base + q] = word;
     }
 #define CONVDR_PV_STEP(S4, NEXT_ROW0, WAITN)                                                                    \
     {                                                                                                            \
@@ -267,6 +288,14 @@ static __global__ void __launch_bounds__(256, 3) k_attention_train_fwd(const Att
     const int r0 = q - (lane & 31);
     attn_park_store(smem + wave * 4096, o, inv, lane, a.ctx + (base + r0) * H + h * 64, H, plen - r0);
     if (q < plen && hi == 0) a.lse[(int64_t)h * a.ldt + base + q] = q < len ? m * c + __log2f(l) : 0.f;
+    if (a.cls32 && q == 0) {   // (accumulator layout: lane (query, hi) holds dims 32 dt + 8 g + 4 hi + 0..3 in o[dt][4 g + 0..3])
+      float* c32 = a.cls32 + (int64_t)b * H + h * 64 + 4 * hi;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(float4*)(c32 + 32 * dt + 8 * g) = make_float4(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+    }
   }
 }
 
@@ -292,7 +321,24 @@ struct AttnBwdArgs {
   int q_limit;         // dK / dV kernel: > 0 = only the first q_limit queries of a sequence carry gradient (last layer: the
                        // CLS query; a multiple of 64): the query loop stops there
   const int32_t* order;   // [B] or null: workgroup z works on sequence order[z] (k_len_order: longest first)
+  const uint32_t* mbits;  // k_attention_bwd_fused<true>: the forward's dropout keep bits (AttnTrainArgs::mbits)
+  // Round 6.  dS = P (dP - D) with D = dO . O is a small difference of large terms in a saturated head (P ~ one-hot: D ~ dP of
+  // the hot key), and O stored in bf16 puts a 2^-9 relative error into D that lands on the hot key's dS undiminished: on
+  // trained-model statistics the last layer's query-projection gradient sat 7.6e-2 (1 - cos) from fp32 for that reason alone
+  // (tests/test_train_gpu.py, cfg2_trained).  In that layer only the first query of a sequence carries gradient, so the
+  // forward keeps those B context rows in fp32 as well (AttnTrainArgs::cls32) and D of query 0 is taken from them: with the
+  // hot key's unnormalised probability exactly 1.0 in the forward, the D that results agrees with the backward's own P dP
+  // to fp32 rounding.  Null in every other layer (there the bf16 form is at the bf16-emulating oracle's own distance).
+  const float* cls32;     // [B, H] or null
+  unsigned long long* trace;   // TRACE builds (tools/dbg/attn_bwd_trace.py): [workgroup][2][16] s_memtime stamps, or null
 };
+#ifdef CONVDR_ENABLE_TRACE
+#define CONVDR_ATTB_STAMP(i)                                                                               \
+  if (a.trace && (threadIdx.x == 0 || threadIdx.x == 256))                                                  \
+    a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + (threadIdx.x >> 8) * 16 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define CONVDR_ATTB_STAMP(i)
+#endif
 
 constexpr int ATTB_DQ_SMEM = 2 * 2 * ATT_TILE;            // two sets of (K tile | V tile)
 constexpr int ATTB_DKV_SMEM = 2 * (2 * ATT_TILE + 512);   // two sets of (Q tile | dO tile | 64 LSE | 64 D)
@@ -340,6 +386,18 @@ static __global__ void __launch_bounds__(256, 2) k_attention_bwd_dq(const AttnBw
       for (int j = 0; j < 4; ++j)
         acc += __uint_as_float(x.u[j] << 16) * __uint_as_float(y.u[j] << 16) +
                __uint_as_float(x.u[j] & 0xffff0000u) * __uint_as_float(y.u[j] & 0xffff0000u);
+    }
+    if (a.cls32 && q == 0) {   // query 0 from the fp32 context row (AttnBwdArgs::cls32)
+      const float* o32 = a.cls32 + (int64_t)b * H + h * 64 + 8 * hi;
+      acc = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        union { bf16x8 v; uint32_t u[4]; } x;
+        x.v = dof[s];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc += __uint_as_float(x.u[j] << 16) * o32[16 * s + 2 * j] + __uint_as_float(x.u[j] & 0xffff0000u) * o32[16 * s + 2 * j + 1];
+      }
     }
     acc += __shfl_xor(acc, 32, 64);
     Di = acc;
@@ -624,7 +682,9 @@ constexpr int ATTF_K = 2 * ATTF_SET;                  // four K tiles (the seque
 constexpr int ATTF_DS = ATTF_K + 4 * ATT_TILE;        // two sets of four dS^T tiles: rows = keys, columns = the 64 queries of a step
 constexpr int ATTF_D = ATTF_DS + 8 * ATT_TILE;        // D of the sequence's queries (256 floats)
 constexpr int ATTF_PARK = ATTF_D + 1024;              // park regions of the four dQ waves (2 KB each)
-constexpr int ATTB_FUSED_SMEM = ATTF_PARK + 2 * 4096;
+constexpr int ATTF_M = ATTF_PARK + 2 * 4096;          // two sets of ATTM_PIECES x 64 dropout keep words (one per query of a step)
+constexpr int ATTF_M_SET = ATTM_PIECES * 256;
+constexpr int ATTB_FUSED_SMEM = ATTF_M + 2 * ATTF_M_SET;
 
 // one 8-row round of a 64-row tile per wave (eight waves: the whole tile)
 __device__ __forceinline__ void attn_stage_rows8(const AttnTileSrc& s, int64_t first_row, uint32_t col_bytes, char* lds, int wave,
@@ -660,10 +720,23 @@ __device__ __forceinline__ void attn_park_store_half(char* so, const f32x16& o, 
   __builtin_amdgcn_wave_barrier();
 }
 
+// Round 6 -- the instruction diet.  The kernel is bound by its waves' own instruction streams (MfmaUtil 7.8 %, 25 % of its HBM
+// floor): per 32 queries x 32 keys a wave issued 625 instructions for 16 MFMAs.  (i) DROP is a template parameter and the
+// keep bits come from the forward (ATTM_PIECES): 2 instructions per element instead of 14; (ii) the ragged last query step
+// is its own instantiation of the step body instead of two selects + a compare per element in every step; (iii) the softmax
+// scale is applied once to dK / dQ at the end (0.125: a power of two, the bf16 rounding of dS is unchanged bit for bit).
+template <bool DROP>
 static __global__ void __launch_bounds__(512, 1) k_attention_bwd_fused(const AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  CONVDR_ATTB_STAMP(0)
   const int b = a.order ? a.order[blockIdx.y] : (int)blockIdx.y, h = blockIdx.x;
   const int len = a.lens[b];
+#ifdef CONVDR_ENABLE_TRACE
+  if (a.trace && threadIdx.x == 0) {
+    a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 14] = (unsigned long long)len;
+    a.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + 15] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+  }
+#endif
   const int64_t base = a.cu[b];
   const int plen = a.cu[b + 1] - (int)base;
   const int lane = threadIdx.x & 63;
@@ -700,6 +773,7 @@ static __global__ void __launch_bounds__(512, 1) k_attention_bwd_fused(const Att
   const AttnTileSrc srcQ = attn_tile_src(a.QKV, H3, a.rows, lane);
   const AttnTileSrc srcO = attn_tile_src(a.dO, H, a.rows, lane);
   const AttnTileSrc srcL = attn_tile_src((const bf16_t*)a.LSE, 2 * a.ldt, a.heads, lane);
+  const AttnTileSrc srcM = attn_tile_src((const bf16_t*)a.mbits, 2 * a.ldt, DROP ? a.heads * ATTM_PIECES : 0, lane);
   const TrLane trl = tr_lane(lane);
   const uint32_t s0 = lds_off(smem);
   auto stage = [&](int q0, int buf) {
@@ -709,6 +783,13 @@ static __global__ void __launch_bounds__(512, 1) k_attention_bwd_fused(const Att
     if (wave == 0) {
       const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)(((int64_t)h * a.ldt + base + q0) * 4));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srcL.rsrc, (lptr_t)(set + 2 * ATT_TILE), 4, (uint32_t)lane * 4, soff, 0, 0);
+    }
+    if constexpr (DROP) {   // wave w: the keep words of piece w (key tile w >> 1, key half-groups w & 1) for the step's 64 queries
+      if ((wave >> 1) * 64 < len) {
+        const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)(((int64_t)(h * ATTM_PIECES + wave) * a.ldt + base + q0) * 4));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srcM.rsrc, (lptr_t)(smem + ATTF_M + buf * ATTF_M_SET + wave * 256), 4,
+                                                 (uint32_t)lane * 4, soff, 0, 0);
+      }
     }
   };
   const int qlen = (a.q_limit > 0 && a.q_limit < len) ? a.q_limit : len;   // queries that carry gradient (last layer: the CLS tile)
@@ -730,6 +811,18 @@ static __global__ void __launch_bounds__(512, 1) k_attention_bwd_fused(const Att
       for (int j = 0; j < 4; ++j)
         acc += __uint_as_float(x.u[j] << 16) * __uint_as_float(y.u[j] << 16) +
                __uint_as_float(x.u[j] & 0xffff0000u) * __uint_as_float(y.u[j] & 0xffff0000u);
+    }
+    if (a.cls32 && qd == 0) {   // query 0 from the fp32 context row (AttnBwdArgs::cls32)
+      const float* o32 = a.cls32 + (int64_t)b * H + h * 64 + 32 * dhalf;
+      acc = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        union { bf16x8 v; uint32_t u[4]; } x;
+        x.v = dox[s];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc += __uint_as_float(x.u[j] << 16) * o32[8 * s + 2 * j] + __uint_as_float(x.u[j] & 0xffff0000u) * o32[8 * s + 2 * j + 1];
+      }
     }
     acc += __shfl_xor(acc, 1, 64);
     if (dhalf == 0) sDall[qd] = acc;
@@ -773,121 +866,136 @@ static __global__ void __launch_bounds__(512, 1) k_attention_bwd_fused(const Att
       for (int s4 = 0; s4 < 4; ++s4) dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s4].v, sf[s4].v, dq, 0, 0, 0);
     }
     const int r0 = qs + 32 * qb;
-    const float keep = r0 + li < len ? 1.f : 0.f;
+    const float keep = r0 + li < len ? a.scale : 0.f;   // (dS was parked without the softmax scale)
     attn_park_store_half(smem + ATTF_PARK + (wave - 4) * 2048, dq, keep, lane, a.dQKV + (base + r0) * H3 + h * 64 + 32 * dtq, H3,
                          plen - r0);
   };
+  // this lane's dropout keep bit inside a word, and the piece its words come from (ATTM_PIECES)
+  const int e_lane = 16 * (wave & 1) + 8 * ((li >> 4) & 1) + (li & 7);
+  const int p_lane = 2 * (wave >> 1) + ((li >> 3) & 1);
+  const uint32_t drop_scale_bits = __float_as_uint(a.drop.scale);
+  // one query step of a wave that owns keys
+  auto step_body = [&](const int q0, const int buf, char* const ds_cur) __attribute__((always_inline)) {
+    const char* sQ = smem + buf * ATTF_SET;
+    const char* sdO = sQ + ATT_TILE;
+    const float* sLse = (const float*)(sQ + 2 * ATT_TILE);
+    const float* sD = sDall + q0;
+    const uint32_t* sM = (const uint32_t*)(smem + ATTF_M + buf * ATTF_M_SET + p_lane * 256);
+    const uint32_t tQ = s0 + buf * ATTF_SET, tO = tQ + ATT_TILE;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      const char* qp = sQ + (qt * 32 + qrow) * 128;
+      const char* op = sdO + (qt * 32 + qrow) * 128;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int ch = ((2 * s4 + hi) ^ qsw) * 16;
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qp + ch), kf[s4], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(op + ch), vf[s4], dp, 0, 0, 0);
+      }
+      TrFrag of[2][2], qf[2][2];
+      if (qt == 0) {
+        tr_frag<0>(tO, trl, 0, of[0][0]); tr_frag<0>(tO, trl, 1, of[0][1]);
+        tr_frag<0>(tQ, trl, 0, qf[0][0]); tr_frag<0>(tQ, trl, 1, qf[0][1]);
+      } else {
+        tr_frag<32>(tO, trl, 0, of[0][0]); tr_frag<32>(tO, trl, 1, of[0][1]);
+        tr_frag<32>(tQ, trl, 0, qf[0][0]); tr_frag<32>(tQ, trl, 1, qf[0][1]);
+      }
+      // register r <-> query q0 + 32 qt + 16 (r >> 3) + 8 hi + (r & 7)
+      uint32_t kw[16];
+      if constexpr (DROP) {   // the keep words of those 16 queries for this lane's piece: 2 x 8 consecutive words
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const uint4 w0 = *(const uint4*)(sM + 32 * qt + 16 * g + 8 * hi), w1 = *(const uint4*)(sM + 32 * qt + 16 * g + 8 * hi + 4);
+          kw[8 * g + 0] = w0.x; kw[8 * g + 1] = w0.y; kw[8 * g + 2] = w0.z; kw[8 * g + 3] = w0.w;
+          kw[8 * g + 4] = w1.x; kw[8 * g + 5] = w1.y; kw[8 * g + 6] = w1.z; kw[8 * g + 7] = w1.w;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = 32 * qt + 16 * (r >> 3) + 8 * hi + (r & 7);
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -sLse[qi]));
+        float pd = p, dpr = dp[r];
+        if constexpr (DROP) {   // P_dropped = P * m feeds dV, dP = dP_dropped * m feeds dS; m = keep ? 1 / (1 - p) : 0
+          const float m = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)kw[r], (uint32_t)e_lane, 1u) & drop_scale_bits);
+          dpr *= m;
+          pd *= m;
+        }
+        s[r] = pd;
+        dp[r] = p * (dpr - sD[qi]);   // dS (x softmax scale: applied to dK / dQ at the end)
+      }
+      // The step that reaches past the sequence's last query (only the last one, and only when the length is not a multiple
+      // of 64) zeroes those queries' P and dS -- selects, never 0 * junk -- behind a REAL wave-uniform branch: as a condition
+      // inside the loop above hipcc if-converted it into two selects + a compare per element of every step.
+      if (__builtin_expect(q0 + 64 > len, 0)) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = q0 + 32 * qt + 16 * (r >> 3) + 8 * hi + (r & 7) < len;
+          s[r] = ok ? s[r] : 0.f;
+          dp[r] = ok ? dp[r] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int r0 = half * 8;
+        if (half == 0) {
+          if (qt == 0) {
+            tr_frag<16>(tO, trl, 0, of[1][0]); tr_frag<16>(tO, trl, 1, of[1][1]);
+            tr_frag<16>(tQ, trl, 0, qf[1][0]); tr_frag<16>(tQ, trl, 1, qf[1][1]);
+          } else {
+            tr_frag<48>(tO, trl, 0, of[1][0]); tr_frag<48>(tO, trl, 1, of[1][1]);
+            tr_frag<48>(tQ, trl, 0, qf[1][0]); tr_frag<48>(tQ, trl, 1, qf[1][1]);
+          }
+        }
+        union { bf16x8 v; uint32_t u[4]; } pb, sb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pb.u[j] = pack_bf16x2(s[r0 + 2 * j], s[r0 + 2 * j + 1]);
+          sb.u[j] = pack_bf16x2(dp[r0 + 2 * j], dp[r0 + 2 * j + 1]);
+        }
+        if (half == 0) tr_wait4<8>(of[0][0], of[0][1], qf[0][0], qf[0][1]);
+        else tr_wait4<0>(of[1][0], of[1][1], qf[1][0], qf[1][1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[half][dt].v, pb.v, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[half][dt].v, sb.v, dk[dt], 0, 0, 0);
+        }
+        // dS of this lane's key for queries 32 qt + 16 half + 8 hi + 0..7: chunk 4 qt + 2 half + hi of the key's row
+        // (a lane whose key lies past the sequence holds a copy of the last key's values: zero)
+        const int chunk = 4 * qt + 2 * half + hi;
+        const uint4 z = key_ok ? make_uint4(sb.u[0], sb.u[1], sb.u[2], sb.u[3]) : make_uint4(0u, 0u, 0u, 0u);
+        *(uint4*)(ds_cur + ((chunk ^ ds_sw) << 4)) = z;
+      }
+    }
+  };
   int it = 0;
+  CONVDR_ATTB_STAMP(1)
   for (int q0 = 0; q0 < qlen; q0 += 64, ++it) {
     const int buf = it & 1;
     lds_dma_wait_all();
     __syncthreads();   // tile `it` has landed; dS^T of step it - 1 is complete; the set of step it - 2 is free
+    CONVDR_ATTB_STAMP(2 + 2 * it)
     if (it >= 1 && q0 + 64 < qlen) stage(q0 + 64, buf ^ 1);
     if (dq_wave && it >= 1) dq_phase(q0 - 64, buf ^ 1);
+    CONVDR_ATTB_STAMP(3 + 2 * it)
     char* const ds_cur = ds_rowp + buf * 4 * ATT_TILE;
-    if (active) {
-      const char* sQ = smem + buf * ATTF_SET;
-      const char* sdO = sQ + ATT_TILE;
-      const float* sLse = (const float*)(sQ + 2 * ATT_TILE);
-      const float* sD = sDall + q0;
-      const uint32_t tQ = s0 + buf * ATTF_SET, tO = tQ + ATT_TILE;
-      const bool ragged = q0 + 64 > len;
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        f32x16 s, dp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-        const char* qp = sQ + (qt * 32 + qrow) * 128;
-        const char* op = sdO + (qt * 32 + qrow) * 128;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const int ch = ((2 * s4 + hi) ^ qsw) * 16;
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(qp + ch), kf[s4], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(op + ch), vf[s4], dp, 0, 0, 0);
-        }
-        TrFrag of[2][2], qf[2][2];
-        if (qt == 0) {
-          tr_frag<0>(tO, trl, 0, of[0][0]); tr_frag<0>(tO, trl, 1, of[0][1]);
-          tr_frag<0>(tQ, trl, 0, qf[0][0]); tr_frag<0>(tQ, trl, 1, qf[0][1]);
-        } else {
-          tr_frag<32>(tO, trl, 0, of[0][0]); tr_frag<32>(tO, trl, 1, of[0][1]);
-          tr_frag<32>(tQ, trl, 0, qf[0][0]); tr_frag<32>(tQ, trl, 1, qf[0][1]);
-        }
-        float dmask[16];
-        if (a.drop.thresh) {   // (see k_attention_bwd_dkv: one hash per two elements, swapped between the lanes of a key pair)
-          const int odd = key & 1;
-#pragma unroll
-          for (int r = 0; r < 16; r += 2) {
-            const int qi_mine = 32 * qt + 16 * (r >> 3) + 8 * hi + (r & 7) + odd;
-            const uint32_t h_mine = drop_mix32((drop_att_base(base + q0 + qi_mine, a.heads, h) + (uint32_t)(kc >> 1)) ^ a.drop.key);
-            const uint32_t h_other = (uint32_t)__builtin_amdgcn_mov_dpp((int)h_mine, 0xB1, 0xF, 0xF, true);
-            const uint32_t h0 = odd ? h_other : h_mine, h1 = odd ? h_mine : h_other;
-            const uint32_t t0 = odd ? (h0 >> 16) : (h0 & 0xffffu), t1 = odd ? (h1 >> 16) : (h1 & 0xffffu);
-            dmask[r] = t0 >= a.drop.thresh ? a.drop.scale : 0.f;
-            dmask[r + 1] = t1 >= a.drop.thresh ? a.drop.scale : 0.f;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int qi = 32 * qt + 16 * (r >> 3) + 8 * hi + (r & 7);
-          float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -sLse[qi]));
-          float dpr = dp[r], pd = p;
-          if (a.drop.thresh) {
-            const float m = dmask[r];
-            dpr *= m;
-            pd *= m;
-          }
-          float ds = p * (dpr - sD[qi]) * a.scale;
-          if (ragged) {
-            const bool ok = q0 + qi < len;
-            pd = ok ? pd : 0.f;
-            ds = ok ? ds : 0.f;
-          }
-          s[r] = pd;
-          dp[r] = ds;
-        }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int r0 = half * 8;
-          if (half == 0) {
-            if (qt == 0) {
-              tr_frag<16>(tO, trl, 0, of[1][0]); tr_frag<16>(tO, trl, 1, of[1][1]);
-              tr_frag<16>(tQ, trl, 0, qf[1][0]); tr_frag<16>(tQ, trl, 1, qf[1][1]);
-            } else {
-              tr_frag<48>(tO, trl, 0, of[1][0]); tr_frag<48>(tO, trl, 1, of[1][1]);
-              tr_frag<48>(tQ, trl, 0, qf[1][0]); tr_frag<48>(tQ, trl, 1, qf[1][1]);
-            }
-          }
-          union { bf16x8 v; uint32_t u[4]; } pb, sb;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            pb.u[j] = pack_bf16x2(s[r0 + 2 * j], s[r0 + 2 * j + 1]);
-            sb.u[j] = pack_bf16x2(dp[r0 + 2 * j], dp[r0 + 2 * j + 1]);
-          }
-          if (half == 0) tr_wait4<8>(of[0][0], of[0][1], qf[0][0], qf[0][1]);
-          else tr_wait4<0>(of[1][0], of[1][1], qf[1][0], qf[1][1]);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[half][dt].v, pb.v, dv[dt], 0, 0, 0);
-            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[half][dt].v, sb.v, dk[dt], 0, 0, 0);
-          }
-          // dS of this lane's key for queries 32 qt + 16 half + 8 hi + 0..7: chunk 4 qt + 2 half + hi of the key's row
-          // (a lane whose key lies past the sequence holds a copy of the last key's values: zero)
-          const int chunk = 4 * qt + 2 * half + hi;
-          const uint4 z = key_ok ? make_uint4(sb.u[0], sb.u[1], sb.u[2], sb.u[3]) : make_uint4(0u, 0u, 0u, 0u);
-          *(uint4*)(ds_cur + ((chunk ^ ds_sw) << 4)) = z;
-        }
-      }
-    }
+    if (active) step_body(q0, buf, ds_cur);
   }
+  CONVDR_ATTB_STAMP(10)
   __syncthreads();   // the last step's dS^T is complete; the Q / dO tiles are dead
+  CONVDR_ATTB_STAMP(11)
   if (dq_wave) dq_phase((it - 1) * 64, (it - 1) & 1);
+  CONVDR_ATTB_STAMP(12)
   if (active) {
     const float keep = key_ok ? 1.f : 0.f;
     const int r0 = wave * 32;
-    attn_park_store(smem + wave * 4096, dk, keep, lane, a.dQKV + (base + r0) * H3 + H + h * 64, H3, plen - r0);
+    attn_park_store(smem + wave * 4096, dk, keep * a.scale, lane, a.dQKV + (base + r0) * H3 + H + h * 64, H3, plen - r0);
     attn_park_store(smem + wave * 4096, dv, keep, lane, a.dQKV + (base + r0) * H3 + 2 * H + h * 64, H3, plen - r0);
   }
+  CONVDR_ATTB_STAMP(13)
 }
 
 }  // namespace convdr

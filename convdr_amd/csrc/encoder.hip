@@ -27,7 +27,8 @@ static int64_t g_ffn2_splitk = 1;   // convdr_set_option("ffn2_splitk", 0): whol
 static EncBufs enc_plan(const convdr_encoder_config* c, int64_t rows, int B, char* base) {
   EncBufs p;
   size_t o = 0;
-  auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return base + at; };
+  // (integer arithmetic: the size-only call plans from a null base, and pointer arithmetic on null is undefined -- UBSan, make SAN=1)
+  auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return (char*)((uintptr_t)base + at); };
   const int H = c->hidden, I = c->intermediate;
   const int64_t rs = rows + 128;  // slack: attention K tiles / clamped reads
   p.ldt = align_up((size_t)rows + 64, 8);
@@ -322,6 +323,10 @@ extern "C" int convdr_set_option(const char* name, int64_t value) {
   }
   if (strcmp(name, "attn_bwd_fused") == 0) {   // training: 1 = one-workgroup attention backward for sequences <= 256 tokens
     g_attn_bwd_fused = value;
+    return 0;
+  }
+  if (strcmp(name, "embed_bwd_deterministic") == 0) {   // training: 1 = embedding-table gradients without atomics (k_embed_scatter_det)
+    g_embed_bwd_det = value;
     return 0;
   }
   if (strcmp(name, "ip_fused_finish") == 0) {   // search: 1 = cut + re-score + select in one launch per search (k_ip_finish), 0 = three launches

@@ -68,6 +68,9 @@ inline int64_t g_gemm_tile_policy = 0;
 // convdr_set_option "attn_bwd_fused": 1 (default) = sequences of at most 256 tokens take k_attention_bwd_fused (dQ, dK, dV in one
 // workgroup per (sequence, head)); 0 = always the dQ kernel + the dK / dV kernel (tests and A/B runs exercise both)
 inline int64_t g_attn_bwd_fused = 1;
+// convdr_set_option "embed_bwd_deterministic": 1 = the word / position embedding gradients are summed in token-row order by
+// table-row owners (k_embed_scatter_det) instead of with fp32 atomics: bitwise run-to-run reproducible like every other gradient
+inline int64_t g_embed_bwd_det = getenv("CONVDR_EMBED_BWD_DETERMINISTIC") ? atoi(getenv("CONVDR_EMBED_BWD_DETERMINISTIC")) : 0;
 // convdr_set_option "gelu_gp": 1 (default) = the training forward's FFN1 writes gelu'(pre-activation) (EPI_GELU_GP) and the backward's
 // FFN2 data-gradient GEMM multiplies by it in its epilogue (EPI_MUL_GP); 0 = the round-2..4 form (pre-activation saved, separate
 // k_dgelu_colsum pass).  Read by the forward AND its backward: change it only between steps.

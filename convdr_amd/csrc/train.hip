@@ -14,6 +14,7 @@ namespace convdr {
 struct LayerSave {
   bf16_t *Xin, *QKV, *ctx, *X1, *Hpre, *Hm;
   float *LSE, *Y1, *Y2;
+  uint32_t* Mbits;   // [heads][ATTM_PIECES][ldt]: dropout keep bits of the attention probabilities (attention_train.hpp)
 };
 
 // bf16 activation gradients of one layer that its weight-gradient products read (kept per layer: the weight-gradient
@@ -41,6 +42,7 @@ struct TrainBufs {
   // LayerNorm and FFN of that layer -- forward and backward -- run on compact [B, .] copies of those rows (c_*).
   bf16_t *c_ctx, *c_xin, *c_X1, *c_Hpre, *c_Hm;          // forward, kept for the backward
   float* c_Y1;
+  float* c_ctx32;   // the CLS rows of the last layer's attention output in fp32 (AttnBwdArgs::cls32)
   bf16_t *c_dYb, *c_dHpre, *c_dYb2, *c_dctx;             // backward
   float *c_dX1f, *c_dY1, *c_slab;
   size_t c_slab_elems;
@@ -71,7 +73,8 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
   p.L = P.layers;
   p.G = P.bwd;
   size_t o = 0;
-  auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return base + at; };
+  // (integer arithmetic: the size-only call plans from a null base, and pointer arithmetic on null is undefined -- UBSan, make SAN=1)
+  auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return (char*)((uintptr_t)base + at); };
   const int H = c->hidden, I = c->intermediate;
   const int64_t rs = rows + 128;
   p.Tp = (int64_t)align_up((size_t)rows, 64);
@@ -86,6 +89,7 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
     s.QKV = (bf16_t*)take(rs * 3 * H * 2);
     s.ctx = (bf16_t*)take(rs * H * 2);
     s.LSE = (float*)take((size_t)c->heads * p.ldt * 4);
+    s.Mbits = (uint32_t*)take((size_t)c->heads * ATTM_PIECES * p.ldt * 4);
     if (l + 1 == c->layers && !c->pool_mean) {   // CLS-only tail: these live in the compact c_* buffers
       s.X1 = s.Hpre = s.Hm = nullptr;
       s.Y1 = s.Y2 = nullptr;
@@ -132,6 +136,7 @@ static void train_plan(const convdr_encoder_config* c, int64_t rows, int B, char
   p.c_Hpre = (bf16_t*)take(Bp * I * 2);
   p.c_Hm = (bf16_t*)take(Bp * I * 2);
   p.c_Y1 = (float*)take(Bp * H * 4);
+  p.c_ctx32 = (float*)take(Bp * H * 4);
   p.c_dYb = (bf16_t*)take(Bp * H * 2);
   p.c_dHpre = (bf16_t*)take(Bp * I * 2);
   p.c_dYb2 = (bf16_t*)take(Bp * H * 2);
@@ -497,11 +502,16 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
     // copies of those rows (TrainBufs::c_*; dropout masks indexed by the packed row, so the result is the full layer's).
     const bool cls_tail = l + 1 == cfg->layers && !cfg->pool_mean;
     {
+      // (keep bits for the one-workgroup backward: whenever that kernel CAN take this batch -- the "attn_bwd_fused" option is
+      //  looked at by the backward only, so the bits are there whichever way it is set then)
       AttnTrainArgs a{s.QKV, rows, cu_seqlens, seq_lens, H, s.ctx, drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att), s.LSE, p.ldt, 0.125f,
-                      p.order};
+                      p.order, max_len <= ATTF_MAX_LEN ? s.Mbits : nullptr, cls_tail ? p.c_ctx32 : nullptr};
       ProfScope prof("attention", st);
-      if (!(dbg_skip() & 4))
-        hipLaunchKernelGGL(k_attention_train_fwd, dim3(cls_tail ? 1 : (max_len + 127) / 128, cfg->heads, B), dim3(256), 4 * ATT_TILE, st, a);
+      const dim3 grid(cls_tail ? 1 : (max_len + 127) / 128, cfg->heads, B);
+      if (!(dbg_skip() & 4)) {
+        if (a.drop.thresh) hipLaunchKernelGGL(k_attention_train_fwd<true>, grid, dim3(256), 4 * ATT_TILE, st, a);
+        else hipLaunchKernelGGL(k_attention_train_fwd<false>, grid, dim3(256), 4 * ATT_TILE, st, a);
+      }
       CONVDR_CHECK_LAUNCH("k_attention_train_fwd");
     }
     if (cls_tail) {
@@ -745,15 +755,21 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
       // (D[h, t] = dO . O per head is computed by the dQ kernel for its own queries and handed to the dK / dV kernel
       //  through p.Drow: no separate row-dot pass)
       AttnBwdArgs a{s.QKV, p.dctx, rows, s.LSE, cfg->heads, p.Drow, s.ctx, p.Drow, p.ldt, cu_seqlens, seq_lens, H, d.dQKV, 0.125f,
-                    drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att), last ? 64 : 0, p.order};
+                    drop_site(dseed, DROP_SITE_ATT_PROBS, l, p_att), last ? 64 : 0, p.order, s.Mbits, last ? p.c_ctx32 : nullptr,
+                    (l == 5) ? (unsigned long long*)g_attn_trace : nullptr};   // (TRACE builds, layer 5: tools/dbg/attn_bwd_trace.py)
       ProfScope prof("attention_bwd", st);
       if (g_attn_bwd_fused && max_len <= ATTF_MAX_LEN) {   // (last layer: q_limit = 64, one query step)
         static DeviceOnce attr_done;
-        if (attr_done.first())
-          CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_attention_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (attr_done.first()) {
+          CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_attention_bwd_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                ATTB_FUSED_SMEM));
-        if (!(dbg_skip() & 16))
-          hipLaunchKernelGGL(k_attention_bwd_fused, dim3(cfg->heads, B), dim3(512), ATTB_FUSED_SMEM, st, a);
+          CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_attention_bwd_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               ATTB_FUSED_SMEM));
+        }
+        if (!(dbg_skip() & 16)) {
+          if (a.drop.thresh) hipLaunchKernelGGL(k_attention_bwd_fused<true>, dim3(cfg->heads, B), dim3(512), ATTB_FUSED_SMEM, st, a);
+          else hipLaunchKernelGGL(k_attention_bwd_fused<false>, dim3(cfg->heads, B), dim3(512), ATTB_FUSED_SMEM, st, a);
+        }
       } else {
         const dim3 grid((max_len + 127) / 128, cfg->heads, B);
         hipLaunchKernelGGL(k_attention_bwd_dq, last ? dim3(1, cfg->heads, B) : grid, dim3(256), ATTB_DQ_SMEM, st, a);
@@ -809,10 +825,19 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     const int blocks = (int)(ceil_div64(rows, 4) < EMB_BWD_BLOCKS ? ceil_div64(rows, 4) : EMB_BWD_BLOCKS);
     ProfScope prof("embed_bwd", st);
     if (side_ok) CONVDR_CHECK_HIP(hipStreamWaitEvent(st, wf.head_fin, 0));   // p.part is rewritten here (long complete: first jobs of that stream)
+    // "embed_bwd_deterministic": the rows' gradients go to the free fp32 stream buffer, then owners of table rows add them
+    // in token-row order (train_kernels.hpp: k_embed_scatter_det)
+    float* o_rows = g_embed_bwd_det ? other : nullptr;
     hipLaunchKernelGGL(k_embed_bwd, dim3(blocks), dim3(256), 0, st, cur_f, cur_b, p.tok_id, p.tok_pos, rows, H, w->word_emb, w->pos_emb,
                        w->type_emb, w->emb_ln_g, cfg->ln_eps, gr->word_emb, gr->pos_emb, p.part,
-                       drop_site(dseed, DROP_SITE_EMB, 0, p_hid));
+                       drop_site(dseed, DROP_SITE_EMB, 0, p_hid), o_rows);
     CONVDR_CHECK_LAUNCH("k_embed_bwd");
+    if (o_rows) {
+      hipLaunchKernelGGL(k_embed_scatter_det, dim3(1024), dim3(256), 0, st, o_rows, p.tok_id, p.tok_id, rows, H, cfg->vocab, gr->word_emb);
+      hipLaunchKernelGGL(k_embed_scatter_det, dim3(cfg->max_pos < 1024 ? cfg->max_pos : 1024), dim3(256), 0, st, o_rows, p.tok_pos, p.tok_id,
+                         rows, H, cfg->max_pos, gr->pos_emb);
+      CONVDR_CHECK_LAUNCH("k_embed_scatter_det");
+    }
     float* outs[3] = {gr->emb_ln_g, gr->emb_ln_b, gr->type_emb};
     ReduceList r;
     for (int k = 0; k < 3; ++k) r.add(p.part + (size_t)k * H, blocks, (int64_t)3 * H, H, outs[k]);

@@ -611,7 +611,9 @@ __global__ void __launch_bounds__(256) k_embed_bwd(const float* __restrict__ dX,
                                                    const float* __restrict__ word, const float* __restrict__ pos,
                                                    const float* __restrict__ type0, const float* __restrict__ g,
                                                    float eps, float* __restrict__ d_word, float* __restrict__ d_pos,
-                                                   float* __restrict__ part, const DropSite drop) {
+                                                   float* __restrict__ part, const DropSite drop, float* __restrict__ o_rows) {
+  // o_rows non-null (convdr_set_option "embed_bwd_deterministic"): the row's gradient is written to o_rows[row] instead of
+  // being added into the tables with atomics; k_embed_scatter_det then adds the rows in row order (below)
   __shared__ float red[4][3][1024];
   // the wave-private staging strip of the atomics lives in the wave's own slice of `red`, which is written only after the
   // row loop (the two arrays together were exactly the 64 KB static-LDS limit)
@@ -677,9 +679,11 @@ __global__ void __launch_bounds__(256) k_embed_bwd(const float* __restrict__ dX,
         o.z = rstd * (d[j].z - m1 - y[j].z * m2);
         o.w = rstd * (d[j].w - m1 - y[j].w * m2);
         at[j].x += o.x; at[j].y += o.y; at[j].z += o.z; at[j].w += o.w;
-        *(float4*)&stage_w[e0] = o;
+        if (o_rows) *(float4*)(o_rows + row * H + e0) = o;
+        else *(float4*)&stage_w[e0] = o;
       }
     }
+    if (o_rows) continue;   // (wave-uniform)
     // one atomic instruction = 64 consecutive floats (two whole 128-byte lines), not 64 floats 16 bytes apart (eight
     // quarter-filled lines): the row goes through a wave-private LDS strip to change the lane -> column map.  Measured
     // on a configs[2] step: the kernel's 14 M lane-atomics cost 0.2 ms in the strided form and nothing measurable here.
@@ -704,6 +708,46 @@ __global__ void __launch_bounds__(256) k_embed_bwd(const float* __restrict__ dX,
   for (int i = threadIdx.x; i < 3 * H; i += 256) {
     const int k = i / H, e = i - k * H;
     part[((int64_t)blockIdx.x * 3 + k) * H + e] = red[0][k][e] + red[1][k][e] + red[2][k][e] + red[3][k][e];
+  }
+}
+
+// Deterministic form of the scatter above (the "deterministic re-run diff" is this build's race detector, and
+// fp32 atomics made the word / position gradients the two tensors it could not cover: 3e-5 of 495 between identical runs).
+// Workgroup w OWNS the table rows [w * per, (w + 1) * per): it walks the token rows in ascending order, 256 at a time, compacts
+// the ones that hit its range in order (ballot + prefix), and adds them to the table row by row -- element e of a table row is
+// only ever touched by thread e % 256 of its owner, in token-row order: no atomics, one fixed summation order.
+// Called once for the word table (ids = tok_id, alignment rows carry -1) and once for the position table.
+__global__ void __launch_bounds__(256) k_embed_scatter_det(const float* __restrict__ o_rows, const int32_t* __restrict__ ids,
+                                                           const int32_t* __restrict__ valid, int64_t rows, int H, int n_table,
+                                                           float* __restrict__ d_table) {
+  __shared__ int32_t list_row[256], list_id[256], wave_cnt[4];
+  const int per = (n_table + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = lo + per < n_table ? lo + per : n_table;
+  if (lo >= hi) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t r0 = 0; r0 < rows; r0 += 256) {
+    const int64_t row = r0 + threadIdx.x;
+    int id = -1;
+    if (row < rows && valid[row] >= 0) id = ids[row];
+    const bool hit = id >= lo && id < hi;
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = __popcll(bal & ((1ull << lane) - 1ull)), total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int c = wave_cnt[w];
+      before += w < wave ? c : 0;
+      total += c;
+    }
+    if (hit) { list_row[before] = (int32_t)(row - r0); list_id[before] = id; }
+    __syncthreads();
+    for (int i = 0; i < total; ++i) {
+      const float* src = o_rows + (r0 + list_row[i]) * H;
+      float* dst = d_table + (int64_t)list_id[i] * H;
+      for (int e = threadIdx.x; e < H; e += 256) dst[e] += src[e];
+    }
+    __syncthreads();   // the lists are rewritten by the next chunk
   }
 }
 

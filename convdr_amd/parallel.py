@@ -184,11 +184,75 @@ def shard_batch(batch, rank=None, world=None, return_weight=False):
     return out, nr * W / float(n)
 
 
-class DataParallelStudent:
-    """Gradient synchronisation for one-process-per-GPU training of the student."""
+def sparse_rows_allreduce(wgrad, group=None, token_ids=None):
+    """Sum over the ranks of a [V, H] fp32 gradient of which every rank touched only a few rows (the word-embedding table:
+    50,265 x 768 = 154 MB -- 31 % of roberta-base's gradient bytes and the one collective that cannot start before the
+    backward has ended -- of which a 64 x 256-token batch touches at most 16 k rows, a real one a few thousand).
+    Instead of a dense all-reduce: ONE all-gather of every rank's (row ids, summed rows), padded to the largest count, and
+    a local scatter-add.  In place; returns {"rows": this rank's count, "rows_max": the padded count, "bytes_gathered": ...}.
 
-    def __init__(self, model, group=None, broadcast=True):
+    Exact in fp32 up to summation order -- and, unlike an atomics scatter, IDENTICAL ON EVERY RANK (replicas must not drift):
+    the union of rows is zeroed, then the ranks' rows are added in rank order, each rank's ids unique within its call.
+    token_ids: optional tensor of the token ids this rank's step embedded (a superset of its non-zero rows is fine); without it
+    the non-zero rows are found by a pass over the gradient."""
+    W = _world(group)
+    V, H = wgrad.shape
+    if token_ids is not None:
+        rows = torch.unique(token_ids.reshape(-1).to(wgrad.device))
+        rows = rows[(rows >= 0) & (rows < V)]
+    else:
+        rows = torch.nonzero((wgrad != 0).any(dim=1)).flatten()
+    n = int(rows.numel())
+    stats = {"rows": n, "rows_max": n, "bytes_gathered": 0, "bytes_dense": int(V * H * 4)}
+    if W == 1:
+        return stats
+    cnt = torch.tensor([n], dtype=torch.int64, device=wgrad.device)
+    cnts = [torch.zeros_like(cnt) for _ in range(W)]
+    dist.all_gather(cnts, cnt, group=group)
+    cnts = [int(c.item()) for c in cnts]
+    nmax = max(max(cnts), 1)
+    # one buffer per rank: H gradient columns + the row id bit-cast into a float column (-1 = padding)
+    buf = torch.zeros((nmax, H + 1), dtype=torch.float32, device=wgrad.device)
+    ids32 = torch.full((nmax,), -1, dtype=torch.int32, device=wgrad.device)
+    if n:
+        buf[:n, :H] = wgrad.index_select(0, rows)
+        ids32[:n] = rows.to(torch.int32)
+    buf[:, H] = ids32.view(torch.float32)
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((W, nmax, H + 1), dtype=torch.float32, device=wgrad.device)
+        dist.all_gather_into_tensor(out, buf, group=group)
+    else:                                # gloo (the CPU tests) has no single-tensor all-gather
+        parts = [torch.empty_like(buf) for _ in range(W)]
+        dist.all_gather(parts, buf, group=group)
+        out = torch.stack(parts)
+    ids_all = [out[r, :cnts[r], H].contiguous().view(torch.int32).to(torch.int64) for r in range(W)]
+    for r in range(W):
+        if cnts[r]:
+            wgrad.index_fill_(0, ids_all[r], 0.0)
+    for r in range(W):                   # rank order, the same on every rank: replicas stay bit-identical
+        if cnts[r]:
+            wgrad.index_add_(0, ids_all[r], out[r, :cnts[r], :H])
+    stats.update(rows_max=nmax, bytes_gathered=int(W * nmax * (H + 1) * 4))
+    return stats
+
+
+class DataParallelStudent:
+    """Gradient synchronisation for one-process-per-GPU training of the student.
+
+    sparse_embedding: the word-embedding gradient (31 % of the bytes, complete only when the whole backward is) is exchanged
+    as (row ids, rows) with ONE all-gather + a local rank-ordered scatter-add (`sparse_rows_allreduce`) instead of a dense
+    all-reduce.  Off by default.  UNMEASURED ON HARDWARE (no multi-GPU node has been available): `last_comm` carries the
+    byte counts of both forms for every step so that the day a node is there the choice can be priced.
+    allreduce_dtype: "bf16" casts every per-layer bucket to bf16 for its collective and back (SURVEY section 5's option: half
+    the xGMI bytes, the sum rounded per hop); None / "fp32" (default): fp32, the reference's arithmetic."""
+
+    def __init__(self, model, group=None, broadcast=True, sparse_embedding=False, allreduce_dtype=None):
         self.model, self.group = model, group
+        self.sparse_embedding = bool(sparse_embedding)
+        if allreduce_dtype not in (None, "fp32", "bf16"):
+            raise ValueError("allreduce_dtype must be None, 'fp32' or 'bf16'")
+        self.allreduce_dtype = None if allreduce_dtype in (None, "fp32") else allreduce_dtype
+        self.last_comm = {}
         self.broadcast_collectives = 0
         if broadcast and _world(group) > 1:   # what the DDP constructor does (gen_passage_embeddings.py:64-69)
             # one collective for everything that lives in the flat parameter arena (train.flatten_parameters: ~200 tensors,
@@ -234,7 +298,23 @@ class DataParallelStudent:
         nl = len(tower.encoder.layer)
         return [(offs[5 + 16 * l], offs[5 + 16 * (l + 1)]) for l in range(nl)]
 
-    def allreduce_grads(self, force_overlap=False, average=True):
+    def _word_grad(self):
+        """The word-embedding gradient as a [V, H] tensor, or None."""
+        m = self.model.module if hasattr(self.model, "module") else self.model
+        emb = getattr(getattr(getattr(m, "roberta", None), "embeddings", None), "word_embeddings", None)
+        g = getattr(getattr(emb, "weight", None), "grad", None)
+        return g if (g is not None and g.dim() == 2 and g.dtype == torch.float32 and g.is_contiguous()) else None
+
+    def _reduce(self, t, async_op=False):
+        """Sum `t` over the ranks in place (optionally through bf16: self.allreduce_dtype)."""
+        if self.allreduce_dtype == "bf16":
+            h = t.to(torch.bfloat16)
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+            return None
+        return dist.all_reduce(t, group=self.group, async_op=async_op)
+
+    def allreduce_grads(self, force_overlap=False, average=True, token_ids=None):
         """Sum the gradients over the ranks; average=True also divides them by the world size, average=False returns that
         factor (1 / W) for the caller to fold into its clip / optimizer pass (train_step does: one pass over the 0.5 GB
         gradient arena less).  With the flat arena on a GPU the all-reduce runs UNDER the backward:
@@ -242,9 +322,11 @@ class DataParallelStudent:
         (28 MB of fp32 for roberta-base: large enough for the xGMI ring, 12 of them in flight behind each other) is
         queued on a communication stream behind that layer's completion events (convdr_backward_wait_layer), last
         layer first; embeddings + head follow the whole backward.  The compute stream waits for all of them at the
-        end.  (force_overlap: run this path at world size 1 too -- the single-GPU test of the stream logic.)"""
+        end.  (force_overlap: run this path at world size 1 too -- the single-GPU test of the stream logic.)
+        token_ids: this rank's embedded token ids (sparse_embedding: saves the pass that finds the non-zero rows)."""
         W = _world(self.group)
         scale = 1.0 / W
+        wg = self._word_grad() if self.sparse_embedding else None
 
         def finish(tensors):
             if average and W > 1:
@@ -262,6 +344,10 @@ class DataParallelStudent:
             if getattr(m.roberta, "_last_backward_arena", None) != flat.data_ptr():
                 buckets = None      # accumulated gradients (see train._EncoderFn.backward): one collective after the backward
         self.last_path = "overlapped" if buckets else "single"   # (instrumentation for the tests)
+        nbytes = sum(g.numel() for g in grads) * 4
+        self.last_comm = {"dense_bytes_per_rank": int(nbytes), "sparse_embedding": False, "allreduce_dtype": self.allreduce_dtype or "fp32"}
+        if wg is not None and flat is not None and wg.data_ptr() != flat.data_ptr():
+            wg = None                                  # (the arena does not start with the word table: dense)
         if buckets:
             from . import _lib
             L = _lib.lib()
@@ -275,19 +361,36 @@ class DataParallelStudent:
                 for l in reversed(range(len(buckets))):
                     _lib.check(L.convdr_backward_wait_layer(l, comm.cuda_stream), "convdr_backward_wait_layer")
                     b, e = buckets[l]
-                    works.append(dist.all_reduce(flat[b:e], group=self.group, async_op=True))
+                    works.append(self._reduce(flat[b:e], async_op=True))
                 comm.wait_stream(cur)              # embeddings and head: complete only with the whole backward
-                works.append(dist.all_reduce(flat[:buckets[0][0]], group=self.group, async_op=True))
+                e0 = 0
+                if wg is not None:                 # the word table as (ids, rows); position / type / LayerNorm stay dense
+                    self._note_sparse(sparse_rows_allreduce(wg, self.group, token_ids), nbytes)
+                    e0 = wg.numel()
+                works.append(dist.all_reduce(flat[e0:buckets[0][0]], group=self.group, async_op=True))
                 works.append(dist.all_reduce(flat[buckets[-1][1]:], group=self.group, async_op=True))
             for wk in works:
-                wk.wait()                          # the compute stream waits; the host does not
+                if wk is not None:
+                    wk.wait()                      # the compute stream waits; the host does not
             cur.wait_stream(comm)
             return finish([flat])
         if W == 1:
             return 1.0
         if flat is not None:                       # one arena, but not on a GPU (gloo tests): a single collective
-            dist.all_reduce(flat, group=self.group)
+            if wg is not None:
+                self._note_sparse(sparse_rows_allreduce(wg, self.group, token_ids), nbytes)
+                self._reduce(flat[wg.numel():])
+            else:
+                self._reduce(flat)
             return finish([flat])
         for g in grads:
-            dist.all_reduce(g, group=self.group)
+            if wg is not None and g is wg:
+                self._note_sparse(sparse_rows_allreduce(wg, self.group, token_ids), nbytes)
+            else:
+                self._reduce(g)
         return finish(grads)
+
+    def _note_sparse(self, st, nbytes):
+        self.last_comm.update(sparse_embedding=True, embedding_rows_this_rank=st["rows"], embedding_rows_padded=st["rows_max"],
+                              embedding_bytes_gathered=st["bytes_gathered"], embedding_bytes_dense=st["bytes_dense"],
+                              sparse_bytes_per_rank=int(nbytes - st["bytes_dense"] + st["bytes_gathered"]))

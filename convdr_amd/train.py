@@ -1316,7 +1316,7 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
         loss1, seed = _mse_value_and_grad(embs, teacher_embs)
         embs.backward(seed)
         loss_out, loss2 = loss1, None
-        return _finish_step(args, model, optimizer, scheduler, ddp, force_overlap, do_step, gas, loss_out, loss1, loss2)
+        return _finish_step(args, model, optimizer, scheduler, ddp, force_overlap, do_step, gas, loss_out, loss1, loss2, concat_ids)
     loss1 = None if getattr(args, "no_mse", False) else mse_loss(embs, teacher_embs)
     loss, loss2 = loss1, None
     if getattr(args, "ranking_task", False):
@@ -1348,17 +1348,20 @@ def train_step(args, model, teacher_model, optimizer, scheduler, batch, doc_ids=
     if loss_weight != 1.0:
         loss = loss * float(loss_weight)
     loss.backward()
-    return _finish_step(args, model, optimizer, scheduler, ddp, force_overlap, do_step, gas, loss_out, loss1, loss2)
+    return _finish_step(args, model, optimizer, scheduler, ddp, force_overlap, do_step, gas, loss_out, loss1, loss2, concat_ids)
 
 
-def _finish_step(args, model, optimizer, scheduler, ddp, force_overlap, do_step, gas, loss_out, loss1, loss2):
+def _finish_step(args, model, optimizer, scheduler, ddp, force_overlap, do_step, gas, loss_out, loss1, loss2, token_ids=None):
     """train_step after the backward: all-reduce, clip, optimizer, scheduler, zero_grad (run_convdr_train.py:172-193)."""
     if do_step:
         scale = 1.0
         if ddp is not None:
             # per-layer collectives under the backward when the gradients are fresh (parallel.py); SUM over ranks --
             # the 1 / world factor rides on the clip / AdamW pass instead of costing its own pass over 0.5 GB
-            scale = ddp.allreduce_grads(force_overlap=force_overlap, average=False)
+            # (token_ids: for DataParallelStudent(sparse_embedding=True) -- the ids this rank embedded, padding included: a
+            #  superset of the word-table rows its gradient touched; only valid without accumulation over micro-batches)
+            kw = {"token_ids": token_ids} if (getattr(ddp, "sparse_embedding", False) and gas == 1) else {}
+            scale = ddp.allreduce_grads(force_overlap=force_overlap, average=False, **kw)
         clip_grad_norm_(list(model.parameters()), args.max_grad_norm, defer_to=optimizer if isinstance(optimizer, AdamW) else None,
                         extra_scale=scale, overlap_backward=ddp is None and gas == 1)
         optimizer.step()

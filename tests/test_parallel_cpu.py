@@ -301,3 +301,64 @@ def test_distributed_sampler_and_batch_sharding():
     with pytest.raises(ValueError, match="return_weight"):
         parallel.shard_batch((torch.zeros(7, 2),), rank=0, world=2)      # ragged cut without its loss weight: refused
     assert parallel.shard_batch((torch.zeros(8, 2),), rank=1, world=2)[0].shape[0] == 4
+
+
+def _sparse_embedding_job(rank, world):
+    """DataParallelStudent(sparse_embedding=True): the word-embedding gradient travels as (row ids, rows) in ONE all-gather
+    and is summed locally in rank order; everything else dense.  Against the dense all-reduce of the same gradients."""
+    from convdr_amd import parallel, train as TR
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    torch.manual_seed(0)
+    cfg = RobertaConfig(vocab_size=300, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256,
+                        max_position_embeddings=40)
+    model = MSMarcoConfigDict["rdot_nll"].model_class(cfg)
+    info = TR.flatten_parameters(model)
+    params = info["params"]
+    g = torch.Generator().manual_seed(100 + rank)
+    n = sum(p.numel() for p in params)
+
+    def fresh_grads():
+        G = torch.randn(n, generator=torch.Generator().manual_seed(100 + rank))
+        o = 0
+        for p in params:
+            p.grad = G[o:o + p.numel()].view(p.shape)
+            o += p.numel()
+        wg = model.roberta.embeddings.word_embeddings.weight.grad
+        # every rank touched its own few rows (some shared with the other ranks: rows 5 and 7), the rest is exactly zero
+        mine = sorted({5, 7, 11 + rank, 40 + 3 * rank, 299 - rank})
+        keep = torch.zeros(wg.shape[0], dtype=torch.bool)
+        keep[mine] = True
+        wg[~keep] = 0.0
+        return G, mine
+    out = {}
+    for mode in ("dense", "sparse", "sparse_ids", "bf16"):
+        G, mine = fresh_grads()
+        ddp = parallel.DataParallelStudent(model, broadcast=False, sparse_embedding=mode.startswith("sparse"),
+                                           allreduce_dtype="bf16" if mode == "bf16" else None)
+        kw = {"token_ids": torch.tensor(mine + [0, 1])} if mode == "sparse_ids" else {}     # a superset (padding id etc.)
+        scale = ddp.allreduce_grads(average=False, **kw)
+        out[mode] = (G.clone(), scale, dict(ddp.last_comm))
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sparse_embedding_gradient_exchange_equals_the_dense_allreduce(world):
+    res = _run(_sparse_embedding_job, world, 29650 + world)
+    dense = res[0]["dense"][0]
+    for r in range(world):
+        assert torch.equal(res[r]["dense"][0], dense)                        # (gloo's all-reduce: identical on every rank)
+        for mode in ("sparse", "sparse_ids"):
+            G, scale, comm = res[r][mode]
+            assert scale == 1.0 / world
+            assert torch.equal(G, res[0][mode][0]), mode                      # replicas stay bit-identical
+            if world == 2:
+                assert torch.equal(G, dense), mode                           # a + b: no summation order to differ in
+            else:
+                assert torch.allclose(G, dense, rtol=1e-6, atol=1e-6), mode
+            assert comm["sparse_embedding"] and comm["embedding_rows_padded"] in (5, 7)
+            assert comm["embedding_bytes_gathered"] == world * comm["embedding_rows_padded"] * 129 * 4
+            assert comm["embedding_bytes_dense"] == 300 * 128 * 4
+            assert comm["sparse_bytes_per_rank"] < comm["dense_bytes_per_rank"]
+        Gb = res[r]["bf16"][0]
+        assert torch.allclose(Gb, dense, rtol=2e-2, atol=2e-2) and not torch.equal(Gb, dense)
+        assert res[r]["bf16"][2]["allreduce_dtype"] == "bf16"
