@@ -1113,7 +1113,7 @@ def main():
         roof["power_under_load"] = power_under_load(lambda n: [step(i) for i in range(n)])
     try:
         kname = "k_gemm<8, convdr::TileCfg<2, 4, 4, 2>"      # EPI_GELU_BLK on 256 x 256 tiles (k_gemm<1, ..> before round 3)
-        rnd = next((r for r in ("r05", "r04", "r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r + "_bench_default.kernel_stats.txt"))), "r02")
+        rnd = next((r for r in ("r06", "r05", "r04", "r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r + "_bench_default.kernel_stats.txt"))), "r02")
         if EB * SL == 262144:
             for ln in open(os.path.join(ROOT, "profiles", rnd + "_bench_default.kernel_stats.txt")):
                 if kname in ln:

@@ -21,3 +21,91 @@ def test_cpp_host_calls_the_c_abi_without_torch(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "capi host ok (bf16 scan)" in out.stdout and "capi host ok (fp16 scan)" in out.stdout, out.stdout
+
+
+def test_cpp_host_runs_the_encoder_and_a_training_step_without_torch(tmp_path, golden_dir):
+    """tests/capi/encoder_host.cpp: the REST of the boundary from a host with no Python in it (VERDICT r05 "What's missing" 2) --
+    convdr_cast_f32_bf16 / convdr_pack_kslice / convdr_pack_transposed, HOST arrays of device pointers, workspace sizing,
+    convdr_encoder_forward, then one KD step: convdr_encoder_train_forward -> convdr_mse_fwd_bwd -> convdr_encoder_backward ->
+    convdr_grad_norm_clip -> convdr_adamw_step.  The 2-layer H = 128 tower and the inputs are the reference-run fixture's
+    (tests/golden/encoder_rdot_nll.npz, case L64): the host's embeddings are checked against the REFERENCE's embeddings
+    (cosine within 1e-3, north_star) and against the Python host's (same kernels: bit for bit), the step against the
+    Python host's train_step (model.models + train.py) on the same batch.  Reference: model/models.py:140-148,
+    drivers/run_convdr_train.py:101-193."""
+    import json
+    import struct
+    from types import SimpleNamespace
+    import numpy as np
+    import torch
+    from convdr_amd import train as TR
+    from convdr_amd.model.models import MSMarcoConfigDict, RobertaConfig
+    from tests.helpers import cosine
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib_dir = os.path.join(ROOT, "convdr_amd")
+    exe = str(tmp_path / "encoder_host")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "capi", "encoder_host.cpp"),
+                           "-o", exe, "-L" + lib_dir, "-lconvdr_hip", "-Wl,-rpath," + lib_dir])
+    z = np.load(os.path.join(golden_dir, "encoder_rdot_nll.npz"))
+    cfg = json.loads(str(z["config"]))
+
+    def build():
+        m = MSMarcoConfigDict["rdot_nll"].model_class(RobertaConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, **cfg))
+        missing, unexpected = m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}, strict=False)
+        assert not unexpected
+        return m.cuda()
+    model = build()
+    TR.flatten_parameters(model)                          # the arena order IS the file's order (train._tower_params)
+    info = model.roberta._flat
+    P0 = info["P"].detach().cpu().numpy().copy()
+    ids, mask = z["L64/ids"].astype(np.int64), z["L64/mask"].astype(np.int64)
+    B, L = ids.shape
+    E = 768
+    rs = np.random.RandomState(3)
+    teacher = (z["L64/emb"] + 0.05 * rs.randn(B, E)).astype(np.float32)      # a KD target near the student's own embedding
+    hyper = dict(lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, wd=0.0, max_norm=1.0)
+    c = model.roberta.config
+    src = str(tmp_path / "in.bin")
+    with open(src, "wb") as f:
+        f.write(b"CVDRHOST")
+        f.write(struct.pack("<10i", c.hidden_size, c.num_attention_heads, c.num_hidden_layers, c.intermediate_size,
+                            model.roberta.embeddings.word_embeddings.num_embeddings, c.max_position_embeddings, c.pad_token_id, E, B, L))
+        f.write(struct.pack("<8f", c.layer_norm_eps, model.norm.eps, hyper["lr"], hyper["b1"], hyper["b2"], hyper["eps"], hyper["wd"], hyper["max_norm"]))
+        f.write(P0.astype("<f4").tobytes())
+        f.write(ids.astype("<i8").tobytes())
+        f.write(mask.astype("<i8").tobytes())
+        f.write(teacher.astype("<f4").tobytes())
+    dst = str(tmp_path / "out.bin")
+    out = subprocess.run([exe, src, dst], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "encoder host ok" in out.stdout, out.stdout + out.stderr
+    raw = np.fromfile(dst, dtype="<f4")
+    n = P0.size
+    assert raw.size == 2 * B * E + 4 + 2 * n
+    e_inf, e_trn = raw[:B * E].reshape(B, E), raw[B * E:2 * B * E].reshape(B, E)
+    loss, gnorm = float(raw[2 * B * E]), float(raw[2 * B * E + 1])
+    st = raw[2 * B * E + 2:2 * B * E + 4].view(np.int32)
+    G, P1 = raw[2 * B * E + 4:2 * B * E + 4 + n], raw[2 * B * E + 4 + n:]
+    assert st.tolist() == [0, 0]                                           # status words: inputs accepted
+    # (1) against the REFERENCE's embeddings of the same inputs
+    assert cosine(e_inf, z["L64/emb"]).min() > 1 - 1e-3 and cosine(e_trn, z["L64/emb"]).min() > 1 - 1e-3
+    # (2) against the Python host on the same kernels
+    ids_t, mask_t = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    model.eval()
+    with torch.no_grad():
+        e_py = model(ids_t, mask_t).cpu().numpy()
+    np.testing.assert_array_equal(e_inf, e_py)
+    args = SimpleNamespace(learning_rate=hyper["lr"], adam_epsilon=hyper["eps"], max_grad_norm=hyper["max_norm"], ranking_task=False,
+                           no_mse=False, num_negatives=0, gradient_accumulation_steps=1)
+    opt = TR.get_optimizer(args, model, weight_decay=0.0)
+    sched = TR.get_linear_schedule_with_warmup(opt, 0, 10 ** 9)            # (constant lr over this one step)
+    loss_py = TR.train_step(args, model, None, opt, sched, (ids_t, mask_t, ids_t, mask_t), teacher_embs=torch.from_numpy(teacher).cuda())[0]
+    P1_py = model.roberta._flat["P"].detach().cpu().numpy()
+    assert abs(loss - loss_py.item()) <= 1e-6 * max(1.0, abs(loss_py.item())), (loss, loss_py.item())
+    assert gnorm > 0 and np.isfinite(G).all()
+    upd, upd_py = P1 - P0, P1_py - P0
+    assert np.abs(upd_py).max() > 1e-4                                      # the step moved the weights ...
+    # ... and the C++ host moved them the same way: Adam's first step is lr * sign-like, so elements whose gradient is
+    # rounding noise may flip -- compare direction and size of the whole update, and element-wise where the gradient is not noise
+    cosu = float(upd @ upd_py / (np.linalg.norm(upd) * np.linalg.norm(upd_py)))
+    assert cosu > 0.999, cosu
+    big = np.abs(G) > 1e-6 * np.abs(G).max()
+    np.testing.assert_allclose(upd[big], upd_py[big], rtol=2e-3, atol=2e-6)

@@ -344,7 +344,7 @@ def test_train_steps_match_reference_run(golden_dir, fixture):
             # ... and the ABSOLUTE error, which is what north_star's "KD/MSE loss within 1e-3 fp32" is about when the loss itself
             # is 3e-4 (replay: student == teacher weights): an MSE over embeddings that are each ~5e-5 (1 - cos) from fp32 is
             # off by ~1e-5 in absolute terms whatever its own size (replay_b, loss1 ~ 2.2: 1.6e-3 absolute = 7e-4 relative)
-            bar1_abs = 6e-5 if tag == "replay" else 5e-3
+            bar1_abs = 1.5e-4 if tag == "replay" else 4.5e-3                      # measured <= 4.9e-5 / 1.4e-3 (MI355X, round 6)
             margin(tag + "/step%d_loss1_abs" % step, abs(l1.item() - float(z["loss1"][step])), bar1_abs)
             print("%s step %d: loss1 %.6e (reference run %.6e): abs err %.2e, rel %.2e" % (tag, step, l1.item(), float(z["loss1"][step]),
                   abs(l1.item() - float(z["loss1"][step])), abs(l1.item() - float(z["loss1"][step])) / max(float(z["loss1"][step]), 1e-30)))
@@ -1255,11 +1255,11 @@ def test_kd_step_at_configs2_size_matches_autograd(weights):
     # head whose softmax sits at p ~ 1 are small differences of large terms (dS = P (dP - D), D = dO . O): the bf16 rounding of the
     # FORWARD's operands alone moves them -- the bf16-EMULATING oracle (fp32 autograd through a forward that rounds where the
     # kernels round) is 0.7-1.4e-2 (1 - cos) from the fp32 oracle on the query projections of layers 0 / 5 and on the embedding
-    # tables, and the HIP path is as far from either as they are from each other -- and in the last layer, where only the 64 CLS
-    # queries carry gradient, the bf16-stored context in D = dO . O (flash attention's usual form) shows: 7.6e-2 on a gradient
-    # whose norm is 0.6 % of the layer's value-projection gradient.  So: every sampled parameter against fp32 with a loose bar
-    # (recorded), the parameters that carry the update (norm >= 10 % of the largest) with a tight one, the concatenated sample
-    # tight, and the emulating oracle's own distance from fp32 recorded beside them.
+    # tables, and the HIP path is as far from either as they are from each other.  In the last layer, where only the 64 CLS
+    # queries carry gradient, the bf16-stored context in D = dO . O (flash attention's usual form) used to show: 7.6e-2 on a
+    # gradient whose norm is 0.6 % of the layer's value-projection gradient -- closed in round 6 (fp32 CLS context rows for D).
+    # So: every sampled parameter against fp32 at 3x the measured worst, the parameters that carry the update (norm >= 10 % of
+    # the largest) with a tight bar, the concatenated sample tight, and the emulating oracle's own distance from fp32 beside them.
     sd_e = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd_s.items()}
     e_emu = OE.rdot_nll_emb(sd_e, ids_s, m_s, num_layers=NL, num_heads=12, emulate_bf16=True)
     torch.nn.functional.mse_loss(e_emu, t_ref).backward()
@@ -1270,7 +1270,12 @@ def test_kd_step_at_configs2_size_matches_autograd(weights):
         rows_.append((n, 1 - cos_(g_, r_), 1 - cos_(e_, r_), float(r_.norm()), g_, r_))
         print("%-70s 1-cos: hip/fp32 %.2e  emu/fp32 %.2e  |g| %.3e" % (n, rows_[-1][1], rows_[-1][2], rows_[-1][3]))
     big = max(r[3] for r in rows_)
-    margin(tag + "/grad_worst_1-cos_vs_fp32_oracle", max(r[1] for r in rows_), 0.25)                         # measured 7.6e-2 (layer 11 query)
+    # (round 5: 7.6e-2, the last layer's query projection -- D = dO . O on the bf16-stored context.  Round 6: the B CLS context rows
+    #  of that layer are kept in fp32 for D (AttnBwdArgs::cls32): that gradient is at 1.1e-3, and the worst sampled parameter is the
+    #  word-embedding table at 1.45e-2, where the bf16-emulating oracle itself sits at 1.35e-2: operand rounding, not a storage choice)
+    margin(tag + "/grad_worst_1-cos_vs_fp32_oracle", max(r[1] for r in rows_), 4.5e-2)                       # measured 1.45e-2 (word embeddings; emulating oracle 1.35e-2)
+    margin(tag + "/last_layer_query_grad_1-cos_vs_fp32_oracle",
+           max(r[1] for r in rows_ if "layer.11.attention.self.query" in r[0]), 3.5e-3)                      # measured 1.09e-3 (round 5: 7.6e-2)
     margin(tag + "/grad_worst_1-cos_vs_fp32_oracle_large_norm_params", max(r[1] for r in rows_ if r[3] >= 0.1 * big), 6e-3)   # measured 2.1e-3
     margin(tag + "/bf16_emulating_oracle_worst_1-cos_vs_fp32_oracle", max(r[2] for r in rows_), 0.05)        # 1.35e-2: inherent
     ga, ra = torch.cat([r[4] for r in rows_]), torch.cat([r[5] for r in rows_])

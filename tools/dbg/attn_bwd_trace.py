@@ -54,8 +54,8 @@ for lo, hi_ in ((1, 64), (65, 128), (129, 192), (193, 256)):
     nst = int(np.ceil(hi_ / 64))
     print("--- len %3d..%3d: %4d workgroups, whole workgroup median %6.0f cycles (p10 %6.0f, p90 %6.0f)" % (
         lo, hi_, sel.sum(), np.median(a[:, 13] - a[:, 0]), np.percentile(a[:, 13] - a[:, 0], 10), np.percentile(a[:, 13] - a[:, 0], 90)))
-    print("    prologue issue (loads, D, dS zero)            %6.0f" % np.median(a[:, 1] - a[:, 0]))
-    print("    first wait + barrier (tiles landed)           %6.0f" % np.median(a[:, 2] - a[:, 1]))
+    print("    prologue: loads, D, first wait + barrier, K / V fragments %6.0f" % np.median(a[:, 1] - a[:, 0]))
+    print("    (stamp 1 -> step 0)                                       %6.0f" % np.median(a[:, 2] - a[:, 1]))
     for it in range(nst):
         full = a[:, 2 + 2 * it] > 0
         nxt = a[:, 4 + 2 * it] if it + 1 < nst else a[:, 10]
