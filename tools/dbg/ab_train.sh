@@ -7,6 +7,8 @@ for rep in $(seq 1 ${2:-2}); do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d.get('kernels', {})
-print('[$v] step %.3f ms  %.0f samples/s | ' % (d['ms_per_step'], d['value']) + ' '.join('%s %.2f' % (n.replace('gemm_', ''), k[n]['ms_per_step']) for n in k))"
+import math
+bad = '' if math.isfinite(d.get('final_loss', float('nan'))) else '  !!! final_loss %s: THIS LIBRARY COMPUTES GARBAGE (NaN operands run faster: profiles/r06_kd_power_probe.txt) !!!' % d.get('final_loss')
+print('[$v] step %.3f ms  %.0f samples/s  loss %.5f%s | ' % (d['ms_per_step'], d['value'], d.get('final_loss', float('nan')), bad) + ' '.join('%s %.2f' % (n.replace('gemm_', ''), k[n]['ms_per_step']) for n in k))"
   done
 done

@@ -14,6 +14,11 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+# CONVDR_OPTS="name=value,name=value": convdr_set_option calls before the run (e.g. attn_bwd_fused=0)
+from convdr_amd import _lib  # noqa: E402
+for kv in filter(None, os.environ.get("CONVDR_OPTS", "").split(",")):
+    k, v = kv.split("=")
+    _lib.check(_lib.lib().convdr_set_option(k.encode(), int(v)), "convdr_set_option")
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 samples, stop = [], threading.Event()
@@ -43,7 +48,7 @@ stop.set()
 th.join(timeout=12)
 late = [s for s in samples if s[0] - t0 > 0.5 * (time.perf_counter() - t0)]
 ws, fs = sorted(s[1] for s in late), sorted(s[2] for s in late)
-print("[%s] step %.3f ms (first short run %.3f) | socket W median %.0f max %.0f | sclk median %d MHz (min %d max %d) | other clocks %s | %d samples" % (
-    os.path.basename(os.environ.get("CONVDR_HIP_LIB", "libconvdr_hip.so")), d["ms_per_step"], d0["ms_per_step"],
+print("[%s %s] step %.3f ms (first short run %.3f) | socket W median %.0f max %.0f | sclk median %d MHz (min %d max %d) | other clocks %s | %d samples" % (
+    os.path.basename(os.environ.get("CONVDR_HIP_LIB", "libconvdr_hip.so")), os.environ.get("CONVDR_OPTS", ""), d["ms_per_step"], d0["ms_per_step"],
     ws[len(ws) // 2] if ws else -1, ws[-1] if ws else -1, fs[len(fs) // 2] if fs else -1, fs[0] if fs else -1, fs[-1] if fs else -1,
     late[len(late) // 2][3] if late else None, len(late)))

@@ -1,17 +1,15 @@
+mkdir -p gpurun_out/r06j
 R=$GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-O=$R/gpurun_out/r06h
-mkdir -p $O
-cd /tmp
-for v in base dq2x; do
-  if [ "$v" = "base" ]; then lib=$R/convdr_amd/libconvdr_hip.so; else lib=$R/convdr_amd/libconvdr_hip_$v.so; fi
-  export CONVDR_HIP_LIB=$lib
-  rocprofv3 --kernel-trace --stats -d $O/prof_$v -o kd -- python3 $R/bench.py --workload train_kd --steps 5 --warmup 2 > $O/prof_$v.log 2>&1
-  DB=$(find $O/prof_$v -name "*.db" | head -1)
-  python3 $R/tools/rocpd_summary.py $DB > $O/$v.kernel_stats.txt
-  python3 $R/tools/train_timeline.py $DB > $O/$v.timeline.txt
-  python3 $R/tools/train_timeline.py $DB --dispatches > $O/$v.dispatches.txt
-done
-find $O -name "*.db" -delete; find $O -name "*.csv" -size +1M -delete
-cd $R
-head -30 $O/base.timeline.txt; head -30 $O/dq2x.timeline.txt
+run() { CONVDR_HIP_LIB=$R/convdr_amd/libconvdr_hip$1.so CONVDR_OPTS=$2 python tools/dbg/kd_power.py 250 2>&1 | grep "^\["; }
+{
+run "" ""
+run _w1 ""
+run _w2 ""
+run _w3 ""
+run _w4 ""
+run "" ""
+run _w2 ""
+run _w3 ""
+} > gpurun_out/r06j/kd_power.txt
+for v in w2 w3; do echo "=== $v"; CONVDR_HIP_LIB=$R/convdr_amd/libconvdr_hip_$v.so python tools/dbg/attn_fused_vs_split.py 2>&1 | grep -v "^Using\|amdgpu.ids"; done > gpurun_out/r06j/fused_vs_split.txt
+cat gpurun_out/r06j/kd_power.txt gpurun_out/r06j/fused_vs_split.txt

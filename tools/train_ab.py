@@ -39,7 +39,8 @@ def main():
             d = bench.train_kd_measure(dev, 0, 1, False, a.steps, 5, 64, dropout=a.dropout)
             kern = d["kernels"]
             res[name].append(d["ms_per_step"])
-            print("[%s] step %.3f ms  %.0f samples/s | " % (name, d["ms_per_step"], d["value"]) +
+            assert d["final_loss"] == d["final_loss"], "NaN loss: this configuration computes garbage (and NaN operands run faster)"
+            print("[%s] step %.3f ms  %.0f samples/s  loss %.5f | " % (name, d["ms_per_step"], d["value"], d["final_loss"]) +
                   " ".join("%s %.2f" % (n.replace("gemm_", ""), kern[n]["ms_per_step"]) for n in kern), flush=True)
     for name, _ in cfgs:
         print("median[%s] %.3f ms  (min %.3f)" % (name, statistics.median(res[name]), min(res[name])))
