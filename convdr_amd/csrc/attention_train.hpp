@@ -144,12 +144,7 @@ constexpr int ATTM_PIECES = 8;
 // rounds of them per CU; in batch order the last round is whatever the collate function put last, and the kernel ends
 // with a few CUs finishing 256-token sequences while the rest idle: heaviest first measured -18 % on the backward and
 // -8 % on the forward kernel (timing experiment with a sorted batch, round 4).  One thread per sequence, O(B) each.
-// n_first > 0 (convdr_set_option "attn_order_mix"): the first n_first places -- the sequences whose workgroups fill the chip when
-// the launch starts -- are the n_first / 2 longest followed by the n_first - n_first / 2 SHORTEST, the rest follows in descending
-// length.  With every CU starting on a 200+-token sequence the 256 workgroups of a backward launch pull their 130 KB of tiles at the
-// same moment, compute at the same moment and store at the same moment (profiles/r06_attn_bwd_trace_before.txt: 20 k cycles of a
-// 57 k-cycle workgroup go by before its first arithmetic); half of them starting on a short sequence takes the CUs out of step.
-static __global__ void __launch_bounds__(256) k_len_order(const int32_t* __restrict__ lens, int B, int32_t* __restrict__ order, int n_first) {
+static __global__ void __launch_bounds__(256) k_len_order(const int32_t* __restrict__ lens, int B, int32_t* __restrict__ order) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
   const int mine = lens[b];
@@ -157,11 +152,6 @@ static __global__ void __launch_bounds__(256) k_len_order(const int32_t* __restr
   for (int j = 0; j < B; ++j) {
     const int o = lens[j];
     rank += (o > mine) | ((o == mine) & (j < b));
-  }
-  if (n_first > 1 && B > n_first) {
-    const int half = n_first / 2, tail = n_first - half;   // tail: how many of the shortest move up
-    if (rank >= B - tail) rank = half + (rank - (B - tail));
-    else if (rank >= half) rank += tail;
   }
   order[rank] = b;
 }

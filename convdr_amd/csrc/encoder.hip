@@ -325,10 +325,6 @@ extern "C" int convdr_set_option(const char* name, int64_t value) {
     g_attn_bwd_fused = value;
     return 0;
   }
-  if (strcmp(name, "attn_order_mix") == 0) {   // training attention kernels: dispatch order (k_len_order)
-    g_attn_order_mix = value;
-    return 0;
-  }
   if (strcmp(name, "embed_bwd_deterministic") == 0) {   // training: 1 = embedding-table gradients without atomics (k_embed_scatter_det)
     g_embed_bwd_det = value;
     return 0;

@@ -68,9 +68,6 @@ inline int64_t g_gemm_tile_policy = 0;
 // convdr_set_option "attn_bwd_fused": 1 (default) = sequences of at most 256 tokens take k_attention_bwd_fused (dQ, dK, dV in one
 // workgroup per (sequence, head)); 0 = always the dQ kernel + the dK / dV kernel (tests and A/B runs exercise both)
 inline int64_t g_attn_bwd_fused = 1;
-// convdr_set_option "attn_order_mix": 1 = the dispatch order of the training attention kernels starts with half the chip on the longest
-// and half on the shortest sequences (attention_train.hpp: k_len_order); 0 = longest first throughout
-inline int64_t g_attn_order_mix = getenv("CONVDR_ATTN_ORDER_MIX") ? atoi(getenv("CONVDR_ATTN_ORDER_MIX")) : 0;
 // convdr_set_option "embed_bwd_deterministic": 1 = the word / position embedding gradients are summed in token-row order by
 // table-row owners (k_embed_scatter_det) instead of with fp32 atomics: bitwise run-to-run reproducible like every other gradient
 inline int64_t g_embed_bwd_det = getenv("CONVDR_EMBED_BWD_DETERMINISTIC") ? atoi(getenv("CONVDR_EMBED_BWD_DETERMINISTIC")) : 0;

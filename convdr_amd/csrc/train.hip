@@ -485,8 +485,7 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
   hipLaunchKernelGGL(k_seq_pack, dim3((B + 3) / 4), dim3(256), 0, st, input_ids, ids_are_int32, attention_mask, seq_lens, B, L,
                      cu_seqlens, cfg->kind, cfg->pad_idx, cfg->max_pos, cfg->vocab, p.tok_id, p.tok_pos, p.status);
   CONVDR_CHECK_LAUNCH("k_seq_pack");
-  hipLaunchKernelGGL(k_len_order, dim3((B + 255) / 256), dim3(256), 0, st, seq_lens, B, p.order,
-                     g_attn_order_mix ? device_cu_count() / cfg->heads : 0);
+  hipLaunchKernelGGL(k_len_order, dim3((B + 255) / 256), dim3(256), 0, st, seq_lens, B, p.order);
   CONVDR_CHECK_LAUNCH("k_len_order");
   hipLaunchKernelGGL(k_embed_ln, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, p.tok_id, p.tok_pos, rows, H,
                      w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, cfg->ln_eps, P.layers[0].Xin,
