@@ -310,10 +310,17 @@ def cpu_baseline(nq, d, k, L, budget_s=9.0):
             torch.topk(Q @ P.T, k, dim=1)
             r2 += 1
         return enc_rate, nq * n * r2 / (time.perf_counter() - t0), reps, r2
-    threads = min(64, avail)
-    run(threads, 2, 0.0, 1)                      # warm-up (thread pool, allocator)
+    # thread count: a short probe of 32 / 64 / 128 (VERDICT r05 "weak" 11: no intermediate counts were tried), the best one gets the
+    # bounded timed sample; `cores` is "the best thread count tried", never "the host"
+    cand = sorted({t for t in (32, 64, 128) if t <= avail} or {avail})
+    probe = {}
+    for t in cand:
+        run(t, 2, 0.0, 1)                        # warm-up (thread pool, allocator)
+        probe[t] = run(t, 16, 1.5, 3)[0]
+    threads = max(probe, key=probe.get)
     enc_rate, ip_rate, reps, r2 = run(threads, 16, budget_s, 20)
     out = {"value": enc_rate, "unit": "passages/s", "cores": threads, "host_cores": os.cpu_count(), "available_cores": avail,
+           "thread_probe_passages_per_s": {str(t): v for t, v in probe.items()},
            "kind": "port", "ip_pairs_per_s": ip_rate,
            "sample": "encode: 16 x %d-token passages x %d reps, fp32 torch oracle of RobertaDot_NLL_LN (12 x 768); "
                      "search: %d queries x %d passages x %d reps, fp32 SGEMM + topk(%d)" % (L, reps, nq, n, r2, k)}

@@ -987,14 +987,17 @@ static __global__ void __launch_bounds__(512, 1) k_attention_bwd_fused(const Att
   CONVDR_ATTB_STAMP(10)
   __syncthreads();   // the last step's dS^T is complete; the Q / dO tiles are dead
   CONVDR_ATTB_STAMP(11)
-  if (dq_wave) dq_phase((it - 1) * 64, (it - 1) & 1);
-  CONVDR_ATTB_STAMP(12)
+  // dK / dV leave FIRST (their park is the dead Q / dO region; the last dQ contraction reads the K tiles and the dS set, its own
+  // park is elsewhere): the stores drain under the dQ waves' last contraction instead of behind it (trace: 2.7 k + 2.6 k cycles in
+  // a row on waves 4..7 of a 256-token workgroup)
   if (active) {
     const float keep = key_ok ? 1.f : 0.f;
     const int r0 = wave * 32;
     attn_park_store(smem + wave * 4096, dk, keep * a.scale, lane, a.dQKV + (base + r0) * H3 + H + h * 64, H3, plen - r0);
     attn_park_store(smem + wave * 4096, dv, keep, lane, a.dQKV + (base + r0) * H3 + 2 * H + h * 64, H3, plen - r0);
   }
+  CONVDR_ATTB_STAMP(12)
+  if (dq_wave) dq_phase((it - 1) * 64, (it - 1) & 1);
   CONVDR_ATTB_STAMP(13)
 }
 
