@@ -242,3 +242,48 @@ def test_c_abi_collectives_over_rccl_one_rank():
         assert L.convdr_comm_init(C.byref(C.c_void_p()), 2, 5, ident) != 0 and b"rank 5 of 2" in L.convdr_last_error()
     finally:
         _lib.check(L.convdr_comm_destroy(comm), "convdr_comm_destroy")
+
+
+def _sparse_train_job(rank, world):
+    """The data-parallel KD step with the word-embedding gradient exchanged as (row ids, rows) -- DataParallelStudent(
+    sparse_embedding=True) -- against the same step with the dense all-reduce: real kernels, two processes on cuda:0 over gloo."""
+    from types import SimpleNamespace
+    from convdr_amd import parallel
+    from convdr_amd import train as TR
+    from tests.test_train_gpu import _batch, _tiny
+    rs = np.random.RandomState(17)
+    B = 8
+    ids, mask = _batch(rs, B, 40, [40, 17, 33, 1, 8, 25, 40, 12], vocab=60)      # 60 ids: the two halves share many rows
+    tid, tmask = _batch(rs, B, 16, [16, 9, 4, 16, 7, 3, 11, 16], vocab=60)
+    args = SimpleNamespace(learning_rate=1e-3, adam_epsilon=1e-8, max_grad_norm=1.0, ranking_task=False, no_mse=False,
+                           num_negatives=0, gradient_accumulation_steps=1)
+    dev = torch.device("cuda", 0)
+    half = slice(rank * B // world, (rank + 1) * B // world)
+
+    def run(sparse, bf16=False):
+        student, teacher = _tiny(seed=3).to(dev).train(), _tiny(seed=4).to(dev).eval()
+        TR.flatten_parameters(student)
+        opt = TR.get_optimizer(args, student, weight_decay=0.0)
+        sched = TR.get_linear_schedule_with_warmup(opt, 0, 10)
+        ddp = parallel.DataParallelStudent(student, sparse_embedding=sparse, allreduce_dtype="bf16" if bf16 else None)
+        batch = tuple(x[half].to(dev) for x in (ids, mask, tid, tmask))
+        loss = TR.train_step(args, student, teacher, opt, sched, batch, ddp=ddp)[0]
+        torch.cuda.synchronize()
+        return loss.item(), student.roberta._flat["P"].detach().cpu().clone(), dict(ddp.last_comm), ddp.last_path
+    l_d, P_d, comm_d, path_d = run(False)
+    l_s, P_s, comm_s, path_s = run(True)
+    l_b, P_b, comm_b, _ = run(False, bf16=True)
+    return (l_d, l_s, float((P_d - P_s).abs().max()), comm_s, path_d, path_s, float((P_d - P_b).abs().max()), comm_b["allreduce_dtype"],
+            P_s.double().sum().item())
+
+
+def test_two_ranks_sparse_embedding_exchange_equals_the_dense_allreduce_on_real_kernels():
+    out = _run(_sparse_train_job, 2, 29647)
+    for l_d, l_s, dmax, comm, path_d, path_s, dmax_bf16, dt, digest in out:
+        assert l_d == l_s                                   # same forward
+        assert dmax == 0.0, dmax                            # two ranks: a + b has no summation order -> the SAME weights after the step
+        assert path_d == path_s == "overlapped"             # both ran the per-layer collectives under the backward
+        assert comm["sparse_embedding"] and 0 < comm["embedding_rows_padded"] <= 60
+        assert comm["embedding_bytes_gathered"] < comm["embedding_bytes_dense"]
+        assert dt == "bf16" and 0 < dmax_bf16 < 5e-3        # bf16 buckets: a different (rounded) sum, a step of the same size
+    assert out[0][8] == out[1][8]                           # replicas bit-identical after the sparse step
