@@ -200,13 +200,19 @@ struct WgradFork {
       // one (convdr_train_set_side_stream; train.py:_aux_streams does that once per process).
       if (g_ext_side[cur_device_slot()]) side = g_ext_side[cur_device_slot()];
       else CONVDR_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-      CONVDR_CHECK_HIP(hipEventCreateWithFlags(&prod, hipEventDisableTiming));
-      CONVDR_CHECK_HIP(hipEventCreateWithFlags(&fin, hipEventDisableTiming));
-      CONVDR_CHECK_HIP(hipEventCreateWithFlags(&head_fin, hipEventDisableTiming));
-      CONVDR_CHECK_HIP(hipEventCreateWithFlags(&emb_main, hipEventDisableTiming));
+      // These events order streams of ONE device against each other; nothing on the host or on another device ever inspects them
+      // (the collectives of parallel.py wait for them on a stream of the same device).  hipEventDisableSystemFence: the record
+      // then does not carry a system-scope release (cache write-back + invalidate) of its own -- the kernels' own agent-scope
+      // fences order the data.  CONVDR_EVENT_SYSTEM_FENCE=1: the default flags of rounds 1-5 (A/B).
+      static const bool sys_fence = getenv("CONVDR_EVENT_SYSTEM_FENCE") && atoi(getenv("CONVDR_EVENT_SYSTEM_FENCE"));
+      const unsigned ef = hipEventDisableTiming | (sys_fence ? 0u : hipEventDisableSystemFence);
+      CONVDR_CHECK_HIP(hipEventCreateWithFlags(&prod, ef));
+      CONVDR_CHECK_HIP(hipEventCreateWithFlags(&fin, ef));
+      CONVDR_CHECK_HIP(hipEventCreateWithFlags(&head_fin, ef));
+      CONVDR_CHECK_HIP(hipEventCreateWithFlags(&emb_main, ef));
       for (int i = 0; i < TRAIN_MAX_LAYERS; ++i) {
-        CONVDR_CHECK_HIP(hipEventCreateWithFlags(&layer_main[i], hipEventDisableTiming));
-        CONVDR_CHECK_HIP(hipEventCreateWithFlags(&layer_side[i], hipEventDisableTiming));
+        CONVDR_CHECK_HIP(hipEventCreateWithFlags(&layer_main[i], ef));
+        CONVDR_CHECK_HIP(hipEventCreateWithFlags(&layer_side[i], ef));
       }
       ok = true;
     }
