@@ -259,6 +259,9 @@ def _sparse_train_job(rank, world):
                            num_negatives=0, gradient_accumulation_steps=1)
     dev = torch.device("cuda", 0)
     half = slice(rank * B // world, (rank + 1) * B // world)
+    # (the embedding-table gradients without atomics: otherwise two runs of the SAME path already differ in the last bit)
+    from convdr_amd import _lib
+    _lib.check(_lib.lib().convdr_set_option(b"embed_bwd_deterministic", 1), "convdr_set_option")
 
     def run(sparse, bf16=False):
         student, teacher = _tiny(seed=3).to(dev).train(), _tiny(seed=4).to(dev).eval()
