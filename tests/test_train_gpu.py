@@ -1710,7 +1710,11 @@ def test_stream_watchdog_probes_both_sets_and_moves_on_drift():
     opt = TR.get_optimizer(args, student, weight_decay=0.0)
     sched = TR.get_linear_schedule_with_warmup(opt, 0, 1000)
     losses = []
-    n = TR.settle_streams(lambda i: losses.append(TR.train_step(args, student, teacher, opt, sched, batch)[0]), dev, max_steps=40)
+    def one_step(i):
+        losses.append(TR.train_step(args, student, teacher, opt, sched, batch)[0])
+        torch.cuda.synchronize()          # (the watchdog reads step periods from events that have COMPLETED: on a cold box the host
+                                          #  of this tiny model can run 40 steps ahead of the GPU and the probe never gets its samples)
+    n = TR.settle_streams(one_step, dev, max_steps=40)
     info = TR.stream_decisions(dev)
     assert info["phase"] in ("steady", "off") and n <= 40
     if info["phase"] == "steady":
