@@ -17,16 +17,26 @@ def _worker(rank, world, port, fn, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ret[rank] = fn(rank, world)
+        import pickle
+        res = fn(rank, world)
+        with open(os.path.join(ret, "rank%d.pkl" % rank), "wb") as f:       # (`ret`: the parent's temporary directory)
+            pickle.dump(res, f)
     finally:
         dist.destroy_process_group()
 
 
 def _run(fn, world=2, port=29611):
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, fn, ret), nprocs=world, join=True)
-    return [ret[r] for r in range(world)]
+    # results come back through files, not through an mp.Manager: its server process is FORKED from a pytest process that has used
+    # the GPU, and on a cold box that server was once found dead ("ConnectionRefusedError" from the proxy: the soak run of round 6)
+    import pickle
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="convdr_mp_") as td:
+        mp.spawn(_worker, args=(world, port, fn, td), nprocs=world, join=True)
+        out = []
+        for r in range(world):
+            with open(os.path.join(td, "rank%d.pkl" % r), "rb") as f:
+                out.append(pickle.load(f))
+    return out
 
 
 def _search_job(rank, world):
