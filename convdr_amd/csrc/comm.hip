@@ -9,7 +9,20 @@
 // a collective library in one process do not share communicators), so the library is looked up at the first call --
 // whichever librccl.so is already mapped (RTLD_NOLOAD), else the system one.
 #include <dlfcn.h>
+// RCCL's header is used for its types only (every function is looked up with dlsym): a build host without the header still
+// builds the library -- the few ABI-stable declarations the wrappers need are restated below (the header was a
+// build dependency of the whole library).
+#if __has_include(<rccl/rccl.h>) && !defined(CONVDR_NO_RCCL_HEADER)   // (the macro: to compile the fallback branch on a host that has the header)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
+#endif
 #include <stdio.h>
 #include <string.h>
 
