@@ -156,6 +156,34 @@ int main(int argc, char** argv) {
   CV(convdr_adamw_step(dP, dG, dM, dV, o.n, lr, b1, b2, adam_eps, wd, 1, 1, nullptr, st));
   CK(hipStreamSynchronize(st));
 
+  // ---- the exchange steps of the ABI from a host without torch: a one-rank RCCL communicator (in-place all-reduce and all-gather are
+  // the identity at one rank; what is exercised is the binding: library lookup, unique id, init, ranks, collectives on `st`, destroy) ----
+  {
+    char id[CONVDR_COMM_ID_BYTES];
+    if (convdr_comm_unique_id(id) != 0) {
+      std::printf("convdr_comm: skipped (%s)\n", convdr_last_error());
+    } else {
+      convdr_comm_t comm = nullptr;
+      int nr = -1, rk = -1;
+      CV(convdr_comm_init(&comm, 1, 0, id));
+      CV(convdr_comm_ranks(comm, &nr, &rk));
+      float *dA, *dB;
+      CK(hipMalloc(&dA, 4096 * 4)); CK(hipMalloc(&dB, 4096 * 4));
+      CK(hipMemcpyAsync(dA, dG, 4096 * 4, hipMemcpyDeviceToDevice, st));
+      CV(convdr_comm_allreduce_f32(comm, dA, dA, 4096, st));
+      CV(convdr_comm_allgather(comm, dA, dB, 4096 * 4, st));
+      CK(hipStreamSynchronize(st));
+      std::vector<float> a(4096), bb(4096), g0(4096);
+      CK(hipMemcpy(a.data(), dA, 4096 * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(bb.data(), dB, 4096 * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(g0.data(), dG, 4096 * 4, hipMemcpyDeviceToHost));
+      const bool same = std::memcmp(a.data(), g0.data(), 4096 * 4) == 0 && std::memcmp(bb.data(), g0.data(), 4096 * 4) == 0;
+      CV(convdr_comm_destroy(comm));
+      if (nr != 1 || rk != 0 || !same) { std::printf("convdr_comm: MISMATCH (ranks %d/%d, identity %d)\n", rk, nr, (int)same); return 4; }
+      std::printf("convdr_comm ok: 1-rank communicator, all-reduce + all-gather on the host's own stream\n");
+    }
+  }
+
   std::vector<float> out1((size_t)B * E), out2((size_t)B * E), newP(o.n), G(o.n);
   float loss = 0, norm[2] = {0, 0};
   int32_t st1 = 0, st2 = 0;

@@ -77,6 +77,8 @@ def test_cpp_host_runs_the_encoder_and_a_training_step_without_torch(tmp_path, g
     dst = str(tmp_path / "out.bin")
     out = subprocess.run([exe, src, dst], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "encoder host ok" in out.stdout, out.stdout + out.stderr
+    assert "convdr_comm ok" in out.stdout or "convdr_comm: skipped" in out.stdout, out.stdout     # (skipped: no librccl.so on the loader's path)
+    print(out.stdout.strip())
     raw = np.fromfile(dst, dtype="<f4")
     n = P0.size
     assert raw.size == 2 * B * E + 4 + 2 * n
