@@ -54,8 +54,8 @@ for lo, hi_ in ((1, 64), (65, 128), (129, 192), (193, 256)):
     nst = int(np.ceil(hi_ / 64))
     print("--- len %3d..%3d: %4d workgroups, whole workgroup median %6.0f cycles (p10 %6.0f, p90 %6.0f)" % (
         lo, hi_, sel.sum(), np.median(a[:, 13] - a[:, 0]), np.percentile(a[:, 13] - a[:, 0], 10), np.percentile(a[:, 13] - a[:, 0], 90)))
-    print("    prologue: loads, D, first wait + barrier, K / V fragments %6.0f" % np.median(a[:, 1] - a[:, 0]))
-    print("    (stamp 1 -> step 0)                                       %6.0f" % np.median(a[:, 2] - a[:, 1]))
+    print("    prologue issue (loads, D, dS zero)            %6.0f" % np.median(a[:, 1] - a[:, 0]))
+    print("    first wait + barrier (tiles landed)           %6.0f" % np.median(a[:, 2] - a[:, 1]))
     for it in range(nst):
         full = a[:, 2 + 2 * it] > 0
         nxt = a[:, 4 + 2 * it] if it + 1 < nst else a[:, 10]
@@ -66,8 +66,8 @@ for lo, hi_ in ((1, 64), (65, 128), (129, 192), (193, 256)):
                 np.median(nxt[full] - a[:, 2 + 2 * it][full]),
                 np.median(b[full, 3 + 2 * it] - b[full, 2 + 2 * it]), np.median((np.where(b[:, 4 + 2 * it] > 0, b[:, 4 + 2 * it], b[:, 10]) if it + 1 < 4 else b[:, 10])[full] - b[full, 3 + 2 * it])))
     print("    last barrier                                  %6.0f" % np.median(a[:, 11] - a[:, 10]))
-    print("    final dq phase (wave 4)                       %6.0f" % np.median(b[:, 12] - b[:, 11]))
-    print("    dK / dV park + stores (wave 0)                %6.0f" % np.median(a[:, 13] - a[:, 12]))
+    print("    dK / dV park + stores (wave 0)                %6.0f" % np.median(a[:, 12] - a[:, 11]))
+    print("    final dq phase after its own stores (wave 4)  %6.0f" % np.median(b[:, 13] - b[:, 12]))
 # per-CU layout: the workgroups of the busiest and of a median CU
 order = np.argsort(w0[:, 0])
 by = {}
