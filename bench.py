@@ -62,6 +62,15 @@ def _launch_ranks_if_needed(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    import signal
+
+    def _stop(signum, frame):          # the launcher was told to stop: so are the ranks it started (exact PIDs, never a pattern)
+        for k in kids:
+            if k.poll() is None:
+                k.terminate()
+        sys.exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, _stop)
     rc = 0
     live = set(range(args.gpus))
     while live:

@@ -39,3 +39,34 @@ def test_matching_world_size_runs_as_a_rank_and_default_is_one_process():
 def test_launcher_exits_with_a_failing_ranks_status():
     r = _run(["--gpus", "2"], CONVDR_BENCH_LAUNCH_DRYRUN_FAIL_RANK="1")
     assert r.returncode == 7 and "rank 1 exited" in r.stderr
+
+
+def test_launcher_passes_a_termination_on_to_its_ranks(tmp_path):
+    """SIGTERM to the launcher ends the ranks it started (a driver that times the launcher out must not leave ranks behind)."""
+    import signal
+    import time
+    script = tmp_path / "slow_rank.py"
+    # a stand-in for bench.py's rank body: the launcher function itself is imported from bench.py and given this file's argv
+    script.write_text(
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "class A: gpus = 2\n"
+        "bench.__file__ = __file__\n"
+        "bench._launch_ranks_if_needed(A)\n"
+        "open(os.path.join(%r, 'rank%%s.pid' %% os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+        "time.sleep(120)\n" % (ROOT, str(tmp_path)))
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.Popen([sys.executable, str(script)], env=e)
+    t0 = time.time()
+    while time.time() - t0 < 60 and not all((tmp_path / ("rank%d.pid" % r)).exists() for r in range(2)):
+        time.sleep(0.1)
+    pids = [int((tmp_path / ("rank%d.pid" % r)).read_text()) for r in range(2)]
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    t0 = time.time()
+    alive = pids
+    while alive and time.time() - t0 < 20:
+        alive = [q for q in alive if os.path.exists("/proc/%d" % q) and "Z" not in open("/proc/%d/stat" % q).read().split()[2]]
+        time.sleep(0.1)
+    assert not alive, alive
