@@ -164,8 +164,8 @@ static int cur_device_slot() {
 }
 
 // Timing-only experiments (`make TRACE=1` library only: the results are garbage): CONVDR_DBG_SKIP drops whole classes of
-// launches -- 1 gelu', 2 LayerNorm backward, 4 forward attention, 8 weight gradients, 16 attention backward, 64 forward
-// LayerNorm -- to measure what each class costs the STEP (tools/dbg/skip_probe.sh, profiles/r04_train_kd_sensitivity.txt).
+// launches -- 1 gelu', 2 LayerNorm backward, 4 forward attention, 8 weight gradients, 16 attention backward, 32 bias column sums (zero partials instead), 64 forward
+// LayerNorm, 128 the per-layer gradient-norm partials (zeros instead) -- to measure what each class costs the STEP (tools/dbg/skip_probe.sh, profiles/r04_train_kd_sensitivity.txt).
 #ifdef CONVDR_ENABLE_TRACE
 static int dbg_skip() { static const int v = getenv("CONVDR_DBG_SKIP") ? atoi(getenv("CONVDR_DBG_SKIP")) : 0; return v; }
 #else
@@ -787,9 +787,14 @@ extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const c
     if (fork_wgrad)
       if (int e = wf.fork()) return e;
     {
-      hipLaunchKernelGGL(k_colsum_bf16, dim3((3 * H + 255) / 256, chunks), dim3(256), 0, ss, d.dQKV, rows, 3 * H, d.part_bqkv);
-      if (!last && g_gelu_gp)
-        hipLaunchKernelGGL(k_colsum_bf16, dim3((I + 255) / 256, chunks), dim3(256), 0, ss, d.dHpre, rows, I, d.part_b1);
+      if (dbg_skip() & 32) {   // (timing bound only: zero partials instead of the column sums)
+        CONVDR_CHECK_HIP(hipMemsetAsync(d.part_bqkv, 0, sizeof(float) * (size_t)chunks * 3 * H, ss));
+        if (!last && g_gelu_gp) CONVDR_CHECK_HIP(hipMemsetAsync(d.part_b1, 0, sizeof(float) * (size_t)chunks * I, ss));
+      } else {
+        hipLaunchKernelGGL(k_colsum_bf16, dim3((3 * H + 255) / 256, chunks), dim3(256), 0, ss, d.dQKV, rows, 3 * H, d.part_bqkv);
+        if (!last && g_gelu_gp)
+          hipLaunchKernelGGL(k_colsum_bf16, dim3((I + 255) / 256, chunks), dim3(256), 0, ss, d.dHpre, rows, I, d.part_b1);
+      }
       CONVDR_CHECK_LAUNCH("k_colsum_bf16");
       ReduceList r;
       if (!last) r.add_ln(d.part_ln2, blocks_ln2, H, lg->b2, lg->ln2_g, lg->ln2_b);
@@ -954,7 +959,8 @@ extern "C" int convdr_grad_norm_clip(float* grads, int64_t n, float max_norm, fl
 
 extern "C" int convdr_grad_sumsq(const float* x, int64_t n, float* partials, int nblocks, convdr_stream_t stream) {
   CONVDR_REQUIRE(n >= 0 && nblocks >= 1 && nblocks <= 1024, "convdr_grad_sumsq: bad n / nblocks (%lld, %d)", (long long)n, nblocks);
-  hipLaunchKernelGGL(k_sumsq_partial, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, x, n, partials);
+  if (dbg_skip() & 128) CONVDR_CHECK_HIP(hipMemsetAsync(partials, 0, sizeof(float) * (size_t)nblocks, (hipStream_t)stream));   // (timing bound only)
+  else hipLaunchKernelGGL(k_sumsq_partial, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, x, n, partials);
   CONVDR_CHECK_LAUNCH("k_sumsq_partial");
   return 0;
 }
