@@ -31,25 +31,33 @@ __global__ void __launch_bounds__(256) k_transpose_f32_bf16(const float* __restr
 constexpr int TR_MAX_JOBS = 64;
 struct TransposeJob { const float* in; bf16_t* out; int n, k, tiles_k, tile_end; };
 struct TransposeJobs { TransposeJob j[TR_MAX_JOBS]; int count; };
+// NO LDS, on purpose: this launch (20,880 tiles for a roberta-base student) runs on a side stream UNDER the forward, whose
+// 256 x 256 GEMM workgroups need all 160 KB of a CU's LDS to start -- a flood of small workgroups that each hold a 16 KB tile keeps
+// every CU partly occupied and the forward's next GEMM waits for the flood to drain (the LDS form cost the step 0.48 ms for 0.17 ms
+// of kernel: profiles/r06_ab_transpose.txt).  A wave owns 64 rows n x 16 columns k of a 64 x 64 tile: each lane reads 64
+// contiguous bytes of its row (the four waves of the workgroup take the four quarters of the rows' 256-byte spans, so every
+// 128-byte line is consumed by two neighbouring waves) and the wave stores sixteen 128-byte rows of the transposed matrix.
 __global__ void __launch_bounds__(256) k_transpose_f32_bf16_batch(const TransposeJobs a) {
-  __shared__ float tile[64][65];
   int ji = 0;
   for (int i = 0; i + 1 < a.count; ++i)
     if ((int)blockIdx.x >= a.j[i].tile_end) ji = i + 1;
   const TransposeJob& q = a.j[ji];
   const int t = (int)blockIdx.x - (ji ? a.j[ji - 1].tile_end : 0);
   const int n = q.n, k = q.k;
-  const int k0 = (t % q.tiles_k) * 64, n0 = (t / q.tiles_k) * 64;
-  const float* __restrict__ in = q.in;
-  bf16_t* __restrict__ out = q.out;
-  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    tile[r][c] = (n0 + r < n && k0 + c < k) ? in[(int64_t)(n0 + r) * k + k0 + c] : 0.f;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;  // out row = k0 + r, col = n0 + c
-    if (k0 + r < k && n0 + c < n) out[(int64_t)(k0 + r) * n + n0 + c] = f32_to_bf16(tile[c][r]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k0 = (t % q.tiles_k) * 64 + 16 * wave, row = (t / q.tiles_k) * 64 + lane;
+  const float* __restrict__ in = q.in + (int64_t)row * k + k0;
+  bf16_t* __restrict__ out = q.out + (int64_t)k0 * n + row;
+  if (row >= n || k0 >= k) return;
+  float v[16];
+  if (k0 + 16 <= k && (((uintptr_t)in) & 15) == 0) {
+    const float4 x0 = *(const float4*)in, x1 = *(const float4*)(in + 4), x2 = *(const float4*)(in + 8), x3 = *(const float4*)(in + 12);
+    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+    v[8] = x2.x; v[9] = x2.y; v[10] = x2.z; v[11] = x2.w; v[12] = x3.x; v[13] = x3.y; v[14] = x3.z; v[15] = x3.w;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[(int64_t)j * n] = f32_to_bf16(v[j]);
+  } else {
+    for (int j = 0; j < 16 && k0 + j < k; ++j) out[(int64_t)j * n] = f32_to_bf16(in[j]);
   }
 }
 

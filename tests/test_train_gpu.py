@@ -279,6 +279,36 @@ def test_adamw_and_grad_norm_on_slices_that_are_not_16_byte_aligned():
             assert b[:off].abs().sum().item() == 0 and b[off + n:].abs().sum().item() == 0
 
 
+def test_batched_transposed_weight_packing_is_exact_for_ragged_and_unaligned_matrices():
+    """convdr_pack_transposed (the per-step refresh of the data-gradient GEMMs' W^T copies: one launch for all matrices, no LDS)
+    against torch's own transpose + round-to-nearest-even bf16 cast, bit for bit: full 64 x 64 tiles, ragged edges in both
+    directions, a row length that is not a multiple of 4 and a source that starts 4 bytes into a 16-byte line (scalar path);
+    nothing outside the destinations is written."""
+    import ctypes as C
+    from convdr_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(5)
+    shapes = [(768, 768), (64, 64), (70, 100), (1, 16), (130, 66), (65, 7), (256, 48)]
+    pad = 3                                        # floats between the matrices: sources at every alignment
+    src_off, total = [], 1
+    for n, k in shapes:
+        src_off.append(total)
+        total += n * k + pad
+    base = torch.from_numpy(rs.randn(total).astype(np.float32)).cuda()
+    dst_off = np.concatenate([[0], np.cumsum([n * k + 5 for n, k in shapes])]).astype(np.int64)
+    out = torch.full((int(dst_off[-1]),), -7.0, dtype=torch.bfloat16, device="cuda")
+    cnt = len(shapes)
+    _lib.check(L.convdr_pack_transposed(_lib.ptr(base), cnt, (C.c_int64 * cnt)(*src_off), (C.c_int32 * cnt)(*[n for n, _ in shapes]),
+                                        (C.c_int32 * cnt)(*[k for _, k in shapes]), (C.c_int64 * cnt)(*dst_off[:-1].tolist()),
+                                        _lib.ptr(out), _lib.stream_ptr()), "convdr_pack_transposed")
+    torch.cuda.synchronize()
+    for (n, k), so, do in zip(shapes, src_off, dst_off[:-1]):
+        want = base[so:so + n * k].view(n, k).t().contiguous().to(torch.bfloat16)
+        got = out[int(do):int(do) + n * k].view(k, n)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (n, k)
+        assert (out[int(do) + n * k:int(do) + n * k + 5] == -7.0).all(), (n, k)
+
+
 @pytest.mark.parametrize("fixture", ["train_step.npz", "train_step_b.npz"])
 def test_train_steps_match_reference_run(golden_dir, fixture):
     """Replay the 4 optimizer steps the reference's own train() ran (tests/golden/make_golden.py::gen_train):
