@@ -139,6 +139,9 @@ register("convdr_encoder_train_forward", C.c_int, [C.POINTER(EncoderConfig), C.P
 register("convdr_encoder_backward", C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), C.POINTER(LayerWeightsT),
                                               _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, C.c_size_t, _p,
                                               C.POINTER(EncoderGrads), C.POINTER(Dropout), _p])
+register("convdr_encoder_backward_fresh", C.c_int, [C.POINTER(EncoderConfig), C.POINTER(EncoderWeights), C.POINTER(LayerWeightsT),
+                                                    _p, _p, _p, C.c_int, C.c_int64, C.c_int, _p, C.c_size_t, _p,
+                                                    C.POINTER(EncoderGrads), C.POINTER(Dropout), _p])
 register("convdr_backward_wait_layer", C.c_int, [C.c_int, _p])
 register("convdr_wgrad", C.c_int, [_p, C.c_int, C.c_int64, _p, C.c_int, C.c_int64, C.c_int64, _p, C.c_size_t, _p, _p])
 register("convdr_transpose_f32_bf16", C.c_int, [_p, C.c_int, C.c_int, _p, _p])

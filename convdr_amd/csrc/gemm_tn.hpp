@@ -301,7 +301,7 @@ constexpr int TN_MAX_PROBLEMS = 8;
 struct GemmTnProblem {
   const bf16_t* Rm;    // [rows, ldr]: its columns land on accumulator registers -> contiguous output index (k of dW[n, k])
   const bf16_t* Lm;    // [rows, ldl]: its columns land on lanes -> output row (n of dW[n, k])
-  float* out;          // nsplit == 1: dW [NL][NR], accumulated into (+=);  nsplit > 1: slabs [nsplit][NL][NR], overwritten
+  float* out;          // nsplit == 1: dW [NL][NR], accumulated into (+=; GemmTnArgs::overwrite: =);  nsplit > 1: slabs [nsplit][NL][NR], overwritten
   int64_t ldr, ldl;
   int NR, NL;          // columns of Rm / Lm that take part
   int tilesR;          // tiles along NR
@@ -321,6 +321,9 @@ struct GemmTnArgs {
   // workgroups are dispatched in (y, x) order, so a waiting slice-y workgroup implies every slice-(y - 1) workgroup is
   // already resident or done, and those never wait for anything younger.
   int* flags;
+  // nsplit == 1 / ordered slices: the first slice STORES its product instead of adding it to what dW holds (the caller promises a
+  // gradient buffer nobody has written yet: convdr_encoder_backward_fresh) -- no read of dW, and no fill of it before the backward
+  int overwrite;
 };
 
 template <class T>
@@ -386,7 +389,7 @@ static __global__ void __launch_bounds__(T::THREADS, 2) k_gemm_tn(const GemmTnAr
           const f32x16& v = acc.c[mt][nt];
           float4 o = make_float4(v[4 * gq + 0], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]);
           float4* dst = (float4*)(out + (size_t)n * q.NR + k);
-          if (!slab) {
+          if (!slab && !(a.overwrite && blockIdx.y == 0)) {
             const float4 c = *dst;
             o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
           }

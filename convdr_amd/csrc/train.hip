@@ -172,6 +172,10 @@ static int dbg_skip() { static const int v = getenv("CONVDR_DBG_SKIP") ? atoi(ge
 static constexpr int dbg_skip() { return 0; }
 #endif   // convdr_train_set_side_stream (before the first backward of the process)
 
+// convdr_encoder_backward_fresh: every parameter gradient except the embedding tables is STORED by the one kernel that completes it
+// (weight-gradient tiles, k_reduce_multi jobs) instead of added to the buffer's contents; set for the duration of that call only
+static thread_local bool t_bwd_overwrite = false;
+
 struct WgradFork {
   hipStream_t main, side;
   hipEvent_t prod, fin;
@@ -335,6 +339,7 @@ static int wgrad_launch(const WgradItem* it, int count, int64_t rows, float* sla
                  "wgrad: a contraction slice of %d x 64 rows x %lld columns exceeds the 2 GiB operand window (pass a slab so "
                  "that it can be split)", g.steps_per_split, (long long)max_ld);
   g.flags = nullptr;
+  g.overwrite = t_bwd_overwrite ? 1 : 0;
   if (ordered && nsplit > 1) {
     g.flags = (int*)slab;
     CONVDR_CHECK_HIP(hipMemsetAsync(g.flags, 0, (size_t)tiles * sizeof(int), st));
@@ -355,7 +360,7 @@ static int wgrad_launch(const WgradItem* it, int count, int64_t rows, float* sla
     for (int i = 0; i < count; ++i) {
       const int64_t n = (int64_t)g.p[i].NL * g.p[i].NR;
       hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)(ceil_div64(n / 4, 256) < 2048 ? ceil_div64(n / 4, 256) : 2048)),
-                         dim3(256), 0, st, g.p[i].out, nsplit, n, n, it[i].dW, 1);
+                         dim3(256), 0, st, g.p[i].out, nsplit, n, n, it[i].dW, t_bwd_overwrite ? 0 : 1);
       CONVDR_CHECK_LAUNCH("k_reduce_partials");
     }
   return 0;
@@ -452,6 +457,7 @@ struct ReduceList {
   }
   int launch(hipStream_t st) {
     if (!a.count) return 0;
+    a.overwrite = t_bwd_overwrite ? 1 : 0;
     hipLaunchKernelGGL(k_reduce_multi, dim3(blocks), dim3(256), 0, st, a);
     CONVDR_CHECK_LAUNCH("k_reduce_multi");
     return 0;
@@ -582,11 +588,37 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
   return 0;
 }
 
+static int encoder_backward(const convdr_encoder_config* cfg, const convdr_encoder_weights* w, const convdr_layer_weights_t* wt,
+                            const int32_t* cu_seqlens, const int32_t* seq_lens, const void* head_w_t, int B, int64_t rows, int max_len,
+                            void* workspace, size_t workspace_bytes, const float* d_out, const convdr_encoder_grads* gr,
+                            const convdr_dropout* dropout, convdr_stream_t stream);
+
 extern "C" int convdr_encoder_backward(const convdr_encoder_config* cfg, const convdr_encoder_weights* w,
                                        const convdr_layer_weights_t* wt, const int32_t* cu_seqlens, const int32_t* seq_lens,
                                        const void* head_w_t, int B, int64_t rows, int max_len, void* workspace,
                                        size_t workspace_bytes, const float* d_out, const convdr_encoder_grads* gr,
                                        const convdr_dropout* dropout, convdr_stream_t stream) {
+  t_bwd_overwrite = false;
+  return encoder_backward(cfg, w, wt, cu_seqlens, seq_lens, head_w_t, B, rows, max_len, workspace, workspace_bytes, d_out, gr, dropout,
+                          stream);
+}
+
+extern "C" int convdr_encoder_backward_fresh(const convdr_encoder_config* cfg, const convdr_encoder_weights* w,
+                                             const convdr_layer_weights_t* wt, const int32_t* cu_seqlens, const int32_t* seq_lens,
+                                             const void* head_w_t, int B, int64_t rows, int max_len, void* workspace,
+                                             size_t workspace_bytes, const float* d_out, const convdr_encoder_grads* gr,
+                                             const convdr_dropout* dropout, convdr_stream_t stream) {
+  t_bwd_overwrite = true;
+  const int e = encoder_backward(cfg, w, wt, cu_seqlens, seq_lens, head_w_t, B, rows, max_len, workspace, workspace_bytes, d_out, gr,
+                                 dropout, stream);
+  t_bwd_overwrite = false;
+  return e;
+}
+
+static int encoder_backward(const convdr_encoder_config* cfg, const convdr_encoder_weights* w, const convdr_layer_weights_t* wt,
+                            const int32_t* cu_seqlens, const int32_t* seq_lens, const void* head_w_t, int B, int64_t rows, int max_len,
+                            void* workspace, size_t workspace_bytes, const float* d_out, const convdr_encoder_grads* gr,
+                            const convdr_dropout* dropout, convdr_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (int e = check_train_config(cfg)) return e;
   if (int e = check_dropout(dropout, cfg, rows)) return e;

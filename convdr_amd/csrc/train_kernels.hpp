@@ -477,6 +477,7 @@ struct ReduceJob {
 struct ReduceJobs {
   ReduceJob j[REDUCE_MAX_JOBS];
   int count;
+  int overwrite;    // out = sum instead of out += sum (convdr_encoder_backward_fresh)
 };
 static __global__ void __launch_bounds__(256) k_reduce_multi(const ReduceJobs a) {
   __shared__ float red[16][17];
@@ -504,7 +505,7 @@ static __global__ void __launch_bounds__(256) k_reduce_multi(const ReduceJobs a)
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][c];
-    q.out[i] += t;
+    q.out[i] = a.overwrite ? t : q.out[i] + t;
   }
 }
 

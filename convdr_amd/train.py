@@ -311,6 +311,10 @@ def _lens_and_check(ids, mask, vocab, seq_lens=None):
     return lens_dev, lens_host
 
 
+_FRESH_BWD = os.environ.get("CONVDR_FRESH_BWD", "1") != "0"      # 0: the whole arena filled + convdr_encoder_backward (rounds 2-5; A/B)
+_POISON_FRESH_ARENA = False      # tests: NaN in every gradient the backward is supposed to STORE (convdr_encoder_backward_fresh)
+
+
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tower, head, input_ids, attention_mask, seq_lens, dropout, *params):
@@ -353,15 +357,23 @@ class _EncoderFn(torch.autograd.Function):
                                                        ws.numel(), _lib.ptr(out), drop, _lib.stream_ptr()),
                        "convdr_encoder_train_forward")
             _status_post(tower, ws)
-            # the zeroed gradient arena of this forward's backward (0.5 GB for roberta-base: a 64 us fill that used to be the
-            # first thing on the backward's critical path): allocated here, zeroed on the side stream under the forward
+            # the gradient arena of this forward's backward: allocated here, and its EMBEDDING prefix (the scatter-added tables +
+            # the embedding LayerNorm: 0.15 of the 0.5 GB for roberta-base) zeroed on the side stream under the forward; every other
+            # gradient is stored, not accumulated, by convdr_encoder_backward_fresh (rounds 2-5 filled all of it: 0.06 ms per step
+            # wherever the fill was put, and the weight-gradient tiles read the zeros back)
             ctx.grad_arena = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+            ctx.fresh_prefix = sum(p.numel() for p in params[:5])
             # (the arena comes from the main stream's pool but is first written on `side`: if this graph is dropped without a
             #  backward the block must not return to the main pool while the fill may still be pending)
             ctx.grad_arena.record_stream(side)
             with torch.cuda.stream(side):
                 ctx.packed_t = _packed_t(tower, head)
-                ctx.grad_arena.zero_()
+                if _POISON_FRESH_ARENA:
+                    ctx.grad_arena.fill_(float("nan"))
+                if _FRESH_BWD:
+                    ctx.grad_arena[:ctx.fresh_prefix].zero_()
+                else:
+                    ctx.grad_arena.zero_()
                 ctx.packed_t_ready = side.record_event()
         ctx.tower, ctx.head, ctx.dropout = tower, head, dropout
         ctx.packed = (c, w, _keep)           # the weights cannot change between a forward and its backward
@@ -381,7 +393,7 @@ class _EncoderFn(torch.autograd.Function):
         dev = grad_out.device
         go = grad_out.float().contiguous()
         sizes = [int(np.prod(s)) for s in ctx.shapes]
-        flat, ctx.grad_arena = ctx.grad_arena, None            # (zeroed under the forward; the wait on packed_t_ready below covers it)
+        flat, ctx.grad_arena = ctx.grad_arena, None            # (prefix zeroed under the forward; the wait on packed_t_ready below covers it)
         if flat is None:
             flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         views = [v.view(s) if len(s) != 1 else v for v, s in zip(flat.split_with_sizes(sizes), ctx.shapes)]
@@ -411,10 +423,11 @@ class _EncoderFn(torch.autograd.Function):
                 gr.head_w, gr.head_b, gr.head_ln_g, gr.head_ln_b = ptr[b], ptr[b + 1], ptr[b + 2], ptr[b + 3]
             dropout = ctx.dropout
             drop = None if dropout is None else C.byref(_lib.Dropout(float(dropout[0]), float(dropout[1]), int(dropout[2]) & 0xffffffff))
-            _lib.check(L_.convdr_encoder_backward(C.byref(c), C.byref(w), wt, _lib.ptr(cu), _lib.ptr(seq_lens),
-                                                  C.c_void_p(head_t) if head_t else None, B, rows, max_len, _lib.ptr(ws),
-                                                  ws.numel(), _lib.ptr(go), C.byref(gr), drop, _lib.stream_ptr()),
-                       "convdr_encoder_backward")
+            # (`flat` is this call's own arena: nothing else has written it -- autograd adds the views to existing .grad itself)
+            _lib.check((L_.convdr_encoder_backward_fresh if _FRESH_BWD else L_.convdr_encoder_backward)(C.byref(c), C.byref(w), wt, _lib.ptr(cu), _lib.ptr(seq_lens),
+                                                        C.c_void_p(head_t) if head_t else None, B, rows, max_len, _lib.ptr(ws),
+                                                        ws.numel(), _lib.ptr(go), C.byref(gr), drop, _lib.stream_ptr()),
+                       "convdr_encoder_backward_fresh")
         token.done = True      # (stream order: a later forward on this stream overwrites the workspace after these kernels)
         return (None, None, None, None, None, None) + tuple(views)
 

@@ -253,6 +253,18 @@ int convdr_encoder_backward(const convdr_encoder_config* cfg, const convdr_encod
                             size_t workspace_bytes, const float* d_out, const convdr_encoder_grads* grads,
                             const convdr_dropout* dropout, convdr_stream_t stream);
 
+/* The same backward for gradient buffers NOBODY HAS WRITTEN YET (what autograd hands loss.backward() on the first backward after
+ * zero_grad(): /root/reference/drivers/run_convdr_train.py:178,190): every gradient except the embedding tables is STORED by the one
+ * kernel that completes it (weight-gradient tiles, the partial-sum reductions) instead of added to the buffer's contents, so
+ * only grads->word_emb / pos_emb / type_emb / emb_ln_g / emb_ln_b must be zero on entry (the tables are scatter-added: token rows
+ * repeat) and the other buffers may hold anything.  Bit-identical to convdr_encoder_backward on all-zero buffers; saves the
+ * fill of, and one read of, every weight gradient (0.7 GB per step for roberta-base). */
+int convdr_encoder_backward_fresh(const convdr_encoder_config* cfg, const convdr_encoder_weights* w,
+                                  const convdr_layer_weights_t* wt, const int32_t* cu_seqlens, const int32_t* seq_lens,
+                                  const void* head_w_t, int B, int64_t rows, int max_len, void* workspace,
+                                  size_t workspace_bytes, const float* d_out, const convdr_encoder_grads* grads,
+                                  const convdr_dropout* dropout, convdr_stream_t stream);
+
 /* One weight gradient of the backward above, exposed for parity tests at arbitrary shapes:
  *   dW[n, k] += sum_t dy[t, n] * x[t, k]     (what autograd's Linear backward computes for
  *   /root/reference/drivers/run_convdr_train.py:178; dy / x bf16 row-major with row strides ld_dy / ld_x, fp32 out)

@@ -127,6 +127,58 @@ def test_backward_is_deterministic_and_accumulates():
             assert torch.allclose(p.grad, 2 * grads[0][n], rtol=1e-5, atol=1e-7), n
 
 
+@pytest.mark.parametrize("kind", ["rdot_nll", "rdot_nll_dropout", "rdot_nll_long", "dpr"])
+def test_fresh_backward_stores_every_gradient_it_does_not_accumulate(kind):
+    """convdr_encoder_backward_fresh (what autograd's first backward goes through: only the embedding prefix of the gradient
+    arena is zeroed, every other gradient must be STORED by the kernel that completes it): with the rest of the arena poisoned
+    with NaN the gradients are finite and bit-identical to those of an unpoisoned run -- a gradient the backward forgot to
+    write, or wrote by +=, would show as NaN.  roberta + head (CLS tail, with and without hidden dropout: the two routes of the
+    last layer's FFN2 bias), a > 128-token batch (two-query-tile attention), and a BERT tower with two token types (row 1 of
+    the type table receives no gradient and must come out zero)."""
+    from convdr_amd import train as TR
+    rs = np.random.RandomState(3)
+    if kind == "dpr":
+        from convdr_amd.model.models import MSMarcoConfigDict, BertConfig
+        torch.manual_seed(4)
+        cfg = BertConfig(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                         max_position_embeddings=64, type_vocab_size=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+        model = MSMarcoConfigDict["dpr"].model_class(type("A", (), {"bert_config": cfg})())
+        cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.0
+        ids, mask = _batch(rs, 4, 40, [40, 9, 23, 2])
+        E = 128
+    else:
+        model = _tiny()
+        if kind == "rdot_nll_dropout":
+            model.config.hidden_dropout_prob = model.config.attention_probs_dropout_prob = 0.1
+            model.dropout_seed = 1234
+        ids, mask = _batch(rs, 3, 130, [130, 64, 65]) if kind == "rdot_nll_long" else _batch(rs, 4, 48, [48, 20, 33, 5])
+        E = 768
+    model = model.cuda().train()
+    ids, mask = ids.cuda(), mask.cuda()
+    G = torch.from_numpy(rs.randn(ids.shape[0], E).astype(np.float32)).cuda()
+    runs = []
+    for poison in (False, True, True):
+        TR._POISON_FRESH_ARENA = poison
+        try:
+            model.zero_grad()
+            model.__dict__["_dropout_calls"] = 0       # the same masks every run
+            (model(ids, mask) * G).sum().backward()
+        finally:
+            TR._POISON_FRESH_ARENA = False
+        runs.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert len(runs[0]) > 20
+    for n, g0 in runs[0].items():
+        for r in runs[1:]:
+            assert torch.isfinite(r[n]).all(), n
+            if "word_embeddings" in n or "position_embeddings" in n:   # fp32 atomics: order may differ
+                assert torch.allclose(g0, r[n], rtol=1e-4, atol=1e-6), n
+            else:
+                assert torch.equal(g0, r[n]), n
+    if kind == "dpr":
+        t = [g for n, g in runs[1].items() if "question_model" in n and "token_type_embeddings" in n][0]
+        assert t[1].abs().max().item() == 0 and t[0].abs().max().item() > 0
+
+
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_embedding_gradients_without_atomics_are_bitwise_reproducible(dropout):
     """convdr_set_option("embed_bwd_deterministic", 1): the word / position embedding gradients are summed in token-row order
