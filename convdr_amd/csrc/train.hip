@@ -165,7 +165,7 @@ static int cur_device_slot() {
 
 // Timing-only experiments (`make TRACE=1` library only: the results are garbage): CONVDR_DBG_SKIP drops whole classes of
 // launches -- 1 gelu', 2 LayerNorm backward, 4 forward attention, 8 weight gradients, 16 attention backward, 32 bias column sums (zero partials instead), 64 forward
-// LayerNorm, 128 the per-layer gradient-norm partials (zeros instead), 256 the transposed-weight refresh -- to measure what each class costs the STEP (tools/dbg/skip_probe.sh, profiles/r04_train_kd_sensitivity.txt).
+// LayerNorm, 128 the per-layer gradient-norm partials (zeros instead), 256 the transposed-weight refresh (512: that launch twice) -- to measure what each class costs the STEP (tools/dbg/skip_probe.sh, profiles/r04_train_kd_sensitivity.txt).
 #ifdef CONVDR_ENABLE_TRACE
 static int dbg_skip() { static const int v = getenv("CONVDR_DBG_SKIP") ? atoi(getenv("CONVDR_DBG_SKIP")) : 0; return v; }
 #else
@@ -1062,6 +1062,8 @@ extern "C" int convdr_pack_transposed(const float* base, int count, const int64_
     if (tiles == 0) continue;
     if (dbg_skip() & 256) continue;   // (timing bound only: the data-gradient GEMMs then run on stale transposed weights)
     hipLaunchKernelGGL(k_transpose_f32_bf16_batch, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+    if (dbg_skip() & 512)   // (timing only: the launch twice -- what one more of it costs the step, with the product's operands)
+      hipLaunchKernelGGL(k_transpose_f32_bf16_batch, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
   }
   CONVDR_CHECK_LAUNCH("k_transpose_f32_bf16_batch");
   return 0;
