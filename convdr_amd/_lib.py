@@ -170,3 +170,5 @@ register("convdr_topk_merge", C.c_int, [_p, _p, C.c_int, C.c_int64, _p, _p, C.c_
                                         C.c_int64, _p])
 register("convdr_pack_transposed", C.c_int, [_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                              C.POINTER(C.c_int64), _p, _p])
+register("convdr_pack_transposed_bf16", C.c_int, [_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_int64), _p, _p])

@@ -1043,16 +1043,14 @@ extern "C" int convdr_scale_f32(float* x, int64_t n, const float* scale, convdr_
   return 0;
 }
 
-// Batched weight packing for the data-gradient GEMMs: for i < count, fp32 [n[i], k[i]] at base + src_off[i] (elements)
-// -> bf16 [k[i], n[i]] at out + dst_off[i] (elements).  Host arrays; one launch per matrix, no Python round trips.
-extern "C" int convdr_pack_transposed(const float* base, int count, const int64_t* src_off, const int32_t* n, const int32_t* k,
-                                      const int64_t* dst_off, void* out, convdr_stream_t stream) {
+static int pack_transposed(const void* base, bool src_bf16, int count, const int64_t* src_off, const int32_t* n, const int32_t* k,
+                           const int64_t* dst_off, void* out, hipStream_t stream) {
   for (int i0 = 0; i0 < count; i0 += TR_MAX_JOBS) {
     TransposeJobs a{};
     int tiles = 0;
     for (int i = i0; i < count && i < i0 + TR_MAX_JOBS; ++i) {
       TransposeJob& q = a.j[a.count++];
-      q.in = base + src_off[i];
+      q.in = src_bf16 ? (const void*)((const bf16_t*)base + src_off[i]) : (const void*)((const float*)base + src_off[i]);
       q.out = (bf16_t*)out + dst_off[i];
       q.n = n[i]; q.k = k[i];
       q.tiles_k = (k[i] + 63) / 64;
@@ -1061,10 +1059,24 @@ extern "C" int convdr_pack_transposed(const float* base, int count, const int64_
     }
     if (tiles == 0) continue;
     if (dbg_skip() & 256) continue;   // (timing bound only: the data-gradient GEMMs then run on stale transposed weights)
-    hipLaunchKernelGGL(k_transpose_f32_bf16_batch, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
-    if (dbg_skip() & 512)   // (timing only: the launch twice -- what one more of it costs the step, with the product's operands)
-      hipLaunchKernelGGL(k_transpose_f32_bf16_batch, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+    for (int rep = 0; rep < ((dbg_skip() & 512) ? 2 : 1); ++rep) {   // (512, timing only: the launch twice -- what one more of it costs the step)
+      if (src_bf16) hipLaunchKernelGGL(k_transpose_bf16_batch<true>, dim3((unsigned)tiles), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL(k_transpose_bf16_batch<false>, dim3((unsigned)tiles), dim3(256), 0, stream, a);
+    }
   }
-  CONVDR_CHECK_LAUNCH("k_transpose_f32_bf16_batch");
+  CONVDR_CHECK_LAUNCH("k_transpose_bf16_batch");
   return 0;
+}
+
+// Batched weight packing for the data-gradient GEMMs: for i < count, fp32 [n[i], k[i]] at base + src_off[i] (elements)
+// -> bf16 [k[i], n[i]] at out + dst_off[i] (elements).  Host arrays; one launch per 64 matrices, no Python round trips.
+extern "C" int convdr_pack_transposed(const float* base, int count, const int64_t* src_off, const int32_t* n, const int32_t* k,
+                                      const int64_t* dst_off, void* out, convdr_stream_t stream) {
+  return pack_transposed(base, false, count, src_off, n, k, dst_off, out, (hipStream_t)stream);
+}
+
+// The same from a bf16 source (the bf16 copy of the weights that convdr_adamw_step_packed keeps current): bits are moved, not rounded
+extern "C" int convdr_pack_transposed_bf16(const void* base, int count, const int64_t* src_off, const int32_t* n, const int32_t* k,
+                                           const int64_t* dst_off, void* out, convdr_stream_t stream) {
+  return pack_transposed(base, true, count, src_off, n, k, dst_off, out, (hipStream_t)stream);
 }

@@ -86,6 +86,9 @@ def _arena_owner(P):
     return tower
 
 
+_PACKT_FROM_BF16 = os.environ.get("CONVDR_PACKT_FROM_BF16", "1") != "0"      # 0: from the fp32 master weights (A/B)
+
+
 def _packed_t(tower, head):
     """Transposed bf16 weights for the data-gradient GEMMs (cached with the forward packing)."""
     c, w, keep = tower.packed(head)
@@ -112,8 +115,16 @@ def _packed_t(tower, head):
         if T is None:
             T = flat["Pt"] = torch.empty(int(dsts[-1]), dtype=torch.bfloat16, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(L.convdr_pack_transposed(_lib.ptr(flat["P"]), len(mats), src, n, k, dst, _lib.ptr(T), _lib.stream_ptr()),
-                       "convdr_pack_transposed")
+            Pb = flat.get("Pb")
+            if Pb is not None and _PACKT_FROM_BF16:
+                # tower.packed() above made sure the bf16 copy of the weight range is current (cast, or rewritten by the optimizer
+                # step itself): transposing THAT moves a third less data than re-rounding the fp32 master weights, same bits
+                srcb = (C.c_int64 * len(mats))(*[flat["off"][id(p)] - flat["w0"] for p, _ in mats])
+                _lib.check(L.convdr_pack_transposed_bf16(_lib.ptr(Pb), len(mats), srcb, n, k, dst, _lib.ptr(T), _lib.stream_ptr()),
+                           "convdr_pack_transposed_bf16")
+            else:
+                _lib.check(L.convdr_pack_transposed(_lib.ptr(flat["P"]), len(mats), src, n, k, dst, _lib.ptr(T), _lib.stream_ptr()),
+                           "convdr_pack_transposed")
         arr = (_lib.LayerWeightsT * len(tower.encoder.layer))()
         for i in range(len(tower.encoder.layer)):
             arr[i].wqkv_t, arr[i].wo_t, arr[i].w1_t, arr[i].w2_t = [T.data_ptr() + 2 * int(dsts[4 * i + j]) for j in range(4)]

@@ -341,9 +341,9 @@ def test_batched_transposed_weight_packing_is_exact_for_ragged_and_unaligned_mat
     L = _lib.lib()
     rs = np.random.RandomState(5)
     shapes = [(768, 768), (64, 64), (70, 100), (1, 16), (130, 66), (65, 7), (256, 48)]
-    pad = 3                                        # floats between the matrices: sources at every alignment
-    src_off, total = [], 1
-    for n, k in shapes:
+    pads = [8, 8, 8, 3, 3, 3, 3]                   # elements between the matrices: the first four sources 16-byte aligned in fp32 AND
+    src_off, total = [], 0                         # in bf16 (vector loads, also on the ragged 70 x 100), the rest at odd offsets (scalar path)
+    for (n, k), pad in zip(shapes, pads):
         src_off.append(total)
         total += n * k + pad
     base = torch.from_numpy(rs.randn(total).astype(np.float32)).cuda()
@@ -353,12 +353,19 @@ def test_batched_transposed_weight_packing_is_exact_for_ragged_and_unaligned_mat
     _lib.check(L.convdr_pack_transposed(_lib.ptr(base), cnt, (C.c_int64 * cnt)(*src_off), (C.c_int32 * cnt)(*[n for n, _ in shapes]),
                                         (C.c_int32 * cnt)(*[k for _, k in shapes]), (C.c_int64 * cnt)(*dst_off[:-1].tolist()),
                                         _lib.ptr(out), _lib.stream_ptr()), "convdr_pack_transposed")
+    # the same from a bf16 source (convdr_pack_transposed_bf16: what the training step uses -- the optimizer keeps a bf16 copy current)
+    base16 = base.to(torch.bfloat16)
+    out16 = torch.full((int(dst_off[-1]),), -7.0, dtype=torch.bfloat16, device="cuda")
+    _lib.check(L.convdr_pack_transposed_bf16(_lib.ptr(base16), cnt, (C.c_int64 * cnt)(*src_off), (C.c_int32 * cnt)(*[n for n, _ in shapes]),
+                                             (C.c_int32 * cnt)(*[k for _, k in shapes]), (C.c_int64 * cnt)(*dst_off[:-1].tolist()),
+                                             _lib.ptr(out16), _lib.stream_ptr()), "convdr_pack_transposed_bf16")
     torch.cuda.synchronize()
     for (n, k), so, do in zip(shapes, src_off, dst_off[:-1]):
         want = base[so:so + n * k].view(n, k).t().contiguous().to(torch.bfloat16)
-        got = out[int(do):int(do) + n * k].view(k, n)
-        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (n, k)
-        assert (out[int(do) + n * k:int(do) + n * k + 5] == -7.0).all(), (n, k)
+        for o in (out, out16):
+            got = o[int(do):int(do) + n * k].view(k, n)
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (n, k)
+            assert (o[int(do) + n * k:int(do) + n * k + 5] == -7.0).all(), (n, k)
 
 
 @pytest.mark.parametrize("fixture", ["train_step.npz", "train_step_b.npz"])
