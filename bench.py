@@ -1181,11 +1181,12 @@ def main():
             torch.cuda.empty_cache()
             keys = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "final_loss", "TFLOPs_dense_padded_count",
                     "TFLOPs_real_token_count_linear_only", "frac_of_bf16_mfma_peak_real_tokens", "kernels", "stream_selfcheck")
-            kd = train_kd_measure(dev, 0, 1, False, 10, 3, 64, dropout=0.1)       # the reference's training configuration
+            # (20 timed steps after 5 warm-up ones, like `--workload train_kd`: 10 / 3 read 0.0-0.2 ms higher than that line on the same box)
+            kd = train_kd_measure(dev, 0, 1, False, 20, 5, 64, dropout=0.1)       # the reference's training configuration
             line["train_kd"] = {kk: kd[kk] for kk in keys}
-            kd0 = train_kd_measure(dev, 0, 1, False, 10, 3, 64, with_kernels=False, dropout=0.0)
+            kd0 = train_kd_measure(dev, 0, 1, False, 20, 5, 64, with_kernels=False, dropout=0.0)
             line["train_kd_no_dropout"] = {kk: kd0[kk] for kk in ("value", "unit", "ms_per_step", "config", "final_loss")}
-            kdc = train_kd_measure(dev, 0, 1, False, 10, 3, 64, with_kernels=False, dropout=0.1, teacher_cache=True)
+            kdc = train_kd_measure(dev, 0, 1, False, 20, 5, 64, with_kernels=False, dropout=0.1, teacher_cache=True)
             line["train_kd_teacher_cache"] = {kk: kdc[kk] for kk in ("value", "unit", "ms_per_step", "config", "final_loss")}
             line["train_rank"] = train_rank_measure(dev)
             line["encode_loop"] = extras_encode_loop(dev, random_rdot_model().to(dev).eval())
