@@ -15,6 +15,7 @@
 //         int32 status words (inference, training), fp32 gradients [n] (after the clip), fp32 parameters after the step [n]
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -152,6 +153,29 @@ int main(int argc, char** argv) {
                                g(lo[l].w2), g(lo[l].b2), g(lo[l].g2), g(lo[l].be2)};
   convdr_encoder_grads gr{g(o.word), g(o.pos), g(o.type), g(o.eg), g(o.eb), lg.data(), g(o.head_w), g(o.head_b), g(o.head_g), g(o.head_bb)};
   CV(convdr_encoder_backward(&cfg, &w, lt.data(), dCu, dLens, head_t, B, rows, max_len, dWs2, ws2, dDs, &gr, nullptr, st));
+  // ---- convdr_encoder_backward_fresh on buffers nobody has written: everything behind the embedding prefix [0, w0) holds NaN on
+  // entry and must come out bit-identical to the accumulating call on zeros (the tables in front: fp32 atomics, order may differ) ----
+  {
+    std::vector<float> Gacc(o.n), Gfresh(o.n);
+    CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(Gacc.data(), dG, o.n * 4, hipMemcpyDeviceToHost));
+    CK(hipMemset(dG, 0, o.w0 * 4));
+    CK(hipMemset(dG + o.w0, 0xff, (o.n - o.w0) * 4));
+    CV(convdr_encoder_train_forward(&cfg, &w, dIds, 0, dMask, B, L, dCu, dLens, rows, max_len, dWs2, ws2, dOut2, nullptr, st));
+    CV(convdr_mse_fwd_bwd(dOut2, dT, (int64_t)B * E, 1.0f, dLoss, dDs, st));
+    CV(convdr_encoder_backward_fresh(&cfg, &w, lt.data(), dCu, dLens, head_t, B, rows, max_len, dWs2, ws2, dDs, &gr, nullptr, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(Gfresh.data(), dG, o.n * 4, hipMemcpyDeviceToHost));
+    const bool same = std::memcmp(Gacc.data() + o.w0, Gfresh.data() + o.w0, (size_t)(o.n - o.w0) * 4) == 0;
+    double worst = 0.0;
+    for (int64_t i = 0; i < o.w0; ++i) {
+      const double d = std::fabs((double)Gacc[i] - (double)Gfresh[i]), tol = 1e-6 + 1e-4 * std::fabs((double)Gacc[i]);
+      if (d / tol > worst) worst = d / tol;
+    }
+    if (!same || !(worst <= 1.0)) { std::printf("backward_fresh: MISMATCH (stored gradients identical %d, tables %.3g of tolerance)\n", (int)same, worst); return 5; }
+    std::printf("backward_fresh ok: %lld stored gradients bit-identical to the accumulating call, NaN-poisoned on entry\n", (long long)(o.n - o.w0));
+    CK(hipMemcpy(dG, Gacc.data(), o.n * 4, hipMemcpyHostToDevice));   // the step continues with the first call's gradients
+  }
   CV(convdr_grad_norm_clip(dG, o.n, max_norm, 1.0f, dScratch, dNorm, 1, st));
   CV(convdr_adamw_step(dP, dG, dM, dV, o.n, lr, b1, b2, adam_eps, wd, 1, 1, nullptr, st));
   CK(hipStreamSynchronize(st));

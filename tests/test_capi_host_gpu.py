@@ -78,6 +78,7 @@ def test_cpp_host_runs_the_encoder_and_a_training_step_without_torch(tmp_path, g
     out = subprocess.run([exe, src, dst], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "encoder host ok" in out.stdout, out.stdout + out.stderr
     assert "convdr_comm ok" in out.stdout or "convdr_comm: skipped" in out.stdout, out.stdout     # (skipped: no librccl.so on the loader's path)
+    assert "backward_fresh ok" in out.stdout, out.stdout      # the storing backward on NaN-poisoned buffers == the accumulating one on zeros
     print(out.stdout.strip())
     raw = np.fromfile(dst, dtype="<f4")
     n = P0.size
