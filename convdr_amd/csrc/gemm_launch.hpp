@@ -55,6 +55,13 @@ inline int launch_gemm_t(GemmArgs a, hipStream_t st, const char* prof_name) {
   if (!dbg_np && splits == 1 && grid > slots) grid = slots;
   const size_t lds = T::WAVES == 8 ? 160 * 1024 : T::SMEM_BYTES + T::TR * 4;
   hipLaunchKernelGGL((k_gemm<EPI, T>), dim3((unsigned)grid, splits), dim3(T::THREADS), lds, st, a);
+#ifdef CONVDR_ENABLE_TRACE
+  // CONVDR_DBG_DOUBLE (tools/dbg/double_probe.sh): a class of idempotent launches goes out TWICE -- the step's difference is that
+  // class's marginal cost with the product's own operands (1 = the training / inference forward's GEMMs, 2 = data-gradient GEMMs)
+  static const int dbl = getenv("CONVDR_DBG_DOUBLE") ? atoi(getenv("CONVDR_DBG_DOUBLE")) : 0;
+  if (dbl & (strcmp(prof_name, "gemm_dgrad") == 0 ? 2 : strncmp(prof_name, "gemm_", 5) == 0 && strcmp(prof_name, "gemm_cls") != 0 ? 1 : 0))
+    hipLaunchKernelGGL((k_gemm<EPI, T>), dim3((unsigned)grid, splits), dim3(T::THREADS), lds, st, a);
+#endif
   CONVDR_CHECK_LAUNCH("k_gemm");
   return 0;
 }

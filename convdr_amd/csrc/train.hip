@@ -166,10 +166,17 @@ static int cur_device_slot() {
 // Timing-only experiments (`make TRACE=1` library only: the results are garbage): CONVDR_DBG_SKIP drops whole classes of
 // launches -- 1 gelu', 2 LayerNorm backward, 4 forward attention, 8 weight gradients, 16 attention backward, 32 bias column sums (zero partials instead), 64 forward
 // LayerNorm, 128 the per-layer gradient-norm partials (zeros instead), 256 the transposed-weight refresh (512: that launch twice) -- to measure what each class costs the STEP (tools/dbg/skip_probe.sh, profiles/r04_train_kd_sensitivity.txt).
+// CONVDR_DBG_DOUBLE (same library; tools/dbg/double_probe.sh): a class of IDEMPOTENT launches goes out twice, results unchanged --
+// the step's difference is the class's marginal cost with the product's own operands (a skipped class leaves stale operands behind,
+// and the GEMMs' time depends on their operands: profiles/r06_ab_transpose.txt).  1 forward GEMMs, 2 data-gradient GEMMs (both in
+// gemm_launch.hpp), 4 weight gradients, 8 forward attention, 16 attention backward, 32 forward LayerNorm, 64 LayerNorm backward,
+// 128 bias column sums + their reductions (storing backward only), 256 gradient-norm partials.
 #ifdef CONVDR_ENABLE_TRACE
 static int dbg_skip() { static const int v = getenv("CONVDR_DBG_SKIP") ? atoi(getenv("CONVDR_DBG_SKIP")) : 0; return v; }
+static int dbg_double() { static const int v = getenv("CONVDR_DBG_DOUBLE") ? atoi(getenv("CONVDR_DBG_DOUBLE")) : 0; return v; }
 #else
 static constexpr int dbg_skip() { return 0; }
+static constexpr int dbg_double() { return 0; }
 #endif   // convdr_train_set_side_stream (before the first backward of the process)
 
 // convdr_encoder_backward_fresh: every parameter gradient except the embedding tables is STORED by the one kernel that completes it
@@ -354,6 +361,8 @@ static int wgrad_launch(const WgradItem* it, int count, int64_t rows, float* sla
     ProfScope prof("gemm_wgrad", st);
     if (!(dbg_skip() & 8))
       hipLaunchKernelGGL((k_gemm_tn<T>), dim3((unsigned)tiles, (unsigned)nsplit), dim3(T::THREADS), TnCfg<T>::SMEM_BYTES, st, g);
+    if ((dbg_double() & 4) && t_bwd_overwrite && !g.flags)   // (stores or slabs: idempotent)
+      hipLaunchKernelGGL((k_gemm_tn<T>), dim3((unsigned)tiles, (unsigned)nsplit), dim3(T::THREADS), TnCfg<T>::SMEM_BYTES, st, g);
     CONVDR_CHECK_LAUNCH("k_gemm_tn");
   }
   if (nsplit > 1 && !g.flags)
@@ -398,6 +407,7 @@ static int ln_bwd_kernel(const float* dY, const bf16_t* dYadd, const float* Yin,
   int blocks = (int)(ceil_div64(rows, 4) < LN_BWD_BLOCKS ? ceil_div64(rows, 4) : LN_BWD_BLOCKS);
   ProfScope prof("layernorm_bwd", st);
   if (!(dbg_skip() & 2))
+  for (int rep = 0; rep < ((dbg_double() & 64) ? 2 : 1); ++rep)
   {
     // g_ln_bwd_rows (option "ln_bwd_rows" / CONVDR_LN_BWD_ROWS): 0 = the general kernel everywhere (A/B), 1 = straight-line form without, 2 (default) = with the
     // register prefetch of the next row; CONVDR_LN_BWD_GRID: workgroups of the straight-line form.  configs[2] step, medians of
@@ -520,10 +530,11 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
                       p.order, max_len <= ATTF_MAX_LEN ? s.Mbits : nullptr, cls_tail ? p.c_ctx32 : nullptr};
       ProfScope prof("attention", st);
       const dim3 grid(cls_tail ? 1 : (max_len + 127) / 128, cfg->heads, B);
-      if (!(dbg_skip() & 4)) {
-        if (a.drop.thresh) hipLaunchKernelGGL(k_attention_train_fwd<true>, grid, dim3(256), 4 * ATT_TILE, st, a);
-        else hipLaunchKernelGGL(k_attention_train_fwd<false>, grid, dim3(256), 4 * ATT_TILE, st, a);
-      }
+      if (!(dbg_skip() & 4))
+        for (int rep = 0; rep < ((dbg_double() & 8) ? 2 : 1); ++rep) {
+          if (a.drop.thresh) hipLaunchKernelGGL(k_attention_train_fwd<true>, grid, dim3(256), 4 * ATT_TILE, st, a);
+          else hipLaunchKernelGGL(k_attention_train_fwd<false>, grid, dim3(256), 4 * ATT_TILE, st, a);
+        }
       CONVDR_CHECK_LAUNCH("k_attention_train_fwd");
     }
     if (cls_tail) {
@@ -554,7 +565,8 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
     g.drop = drop_site(dseed, DROP_SITE_ATTN_OUT, l, p_hid);
     if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_attn_out")) return e;
     if (!(dbg_skip() & 64))
-      launch_layernorm_bf16(s.Y1, rows, H, lw->ln1_g, lw->ln1_b, cfg->ln_eps, s.X1, st);
+      for (int rep = 0; rep < ((dbg_double() & 32) ? 2 : 1); ++rep)
+        launch_layernorm_bf16(s.Y1, rows, H, lw->ln1_g, lw->ln1_b, cfg->ln_eps, s.X1, st);
     CONVDR_CHECK_LAUNCH("k_layernorm");
     g = GemmArgs{};
     g.rows = rows; g.W = (const bf16_t*)lw->w1; g.X = s.X1; g.N = I; g.K = H; g.bias = lw->b1; g.Cb = s.Hm; g.Cb2 = s.Hpre;
@@ -568,7 +580,8 @@ extern "C" int convdr_encoder_train_forward(const convdr_encoder_config* cfg, co
     if (int e = launch_gemm<EPI_RESID_F32>(g, st, "gemm_ffn2")) return e;
     if (l + 1 < cfg->layers) {
       if (!(dbg_skip() & 64))
-        launch_layernorm_bf16(s.Y2, rows, H, lw->ln2_g, lw->ln2_b, cfg->ln_eps, P.layers[l + 1].Xin, st);
+        for (int rep = 0; rep < ((dbg_double() & 32) ? 2 : 1); ++rep)
+          launch_layernorm_bf16(s.Y2, rows, H, lw->ln2_g, lw->ln2_b, cfg->ln_eps, P.layers[l + 1].Xin, st);
       CONVDR_CHECK_LAUNCH("k_layernorm");
     } else if (cfg->pool_mean) {   // use_mean = True: masked mean of the whole last layer's output
       launch_layernorm_bf16(s.Y2, rows, H, lw->ln2_g, lw->ln2_b, cfg->ln_eps, p.Xout, st);
@@ -804,10 +817,11 @@ static int encoder_backward(const convdr_encoder_config* cfg, const convdr_encod
           CONVDR_CHECK_HIP(hipFuncSetAttribute((const void*)k_attention_bwd_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                ATTB_FUSED_SMEM));
         }
-        if (!(dbg_skip() & 16)) {
-          if (a.drop.thresh) hipLaunchKernelGGL(k_attention_bwd_fused<true>, dim3(cfg->heads, B), dim3(512), ATTB_FUSED_SMEM, st, a);
-          else hipLaunchKernelGGL(k_attention_bwd_fused<false>, dim3(cfg->heads, B), dim3(512), ATTB_FUSED_SMEM, st, a);
-        }
+        if (!(dbg_skip() & 16))
+          for (int rep = 0; rep < ((dbg_double() & 16) ? 2 : 1); ++rep) {
+            if (a.drop.thresh) hipLaunchKernelGGL(k_attention_bwd_fused<true>, dim3(cfg->heads, B), dim3(512), ATTB_FUSED_SMEM, st, a);
+            else hipLaunchKernelGGL(k_attention_bwd_fused<false>, dim3(cfg->heads, B), dim3(512), ATTB_FUSED_SMEM, st, a);
+          }
       } else {
         const dim3 grid((max_len + 127) / 128, cfg->heads, B);
         hipLaunchKernelGGL(k_attention_bwd_dq, last ? dim3(1, cfg->heads, B) : grid, dim3(256), ATTB_DQ_SMEM, st, a);
@@ -818,7 +832,7 @@ static int encoder_backward(const convdr_encoder_config* cfg, const convdr_encod
     // ---- the layer's weight-gradient branch: every operand is complete now; it runs beside the layers below ----
     if (fork_wgrad)
       if (int e = wf.fork()) return e;
-    {
+    for (int rep = 0; rep < ((dbg_double() & 128) && t_bwd_overwrite ? 2 : 1); ++rep) {
       if (dbg_skip() & 32) {   // (timing bound only: zero partials instead of the column sums)
         CONVDR_CHECK_HIP(hipMemsetAsync(d.part_bqkv, 0, sizeof(float) * (size_t)chunks * 3 * H, ss));
         if (!last && g_gelu_gp) CONVDR_CHECK_HIP(hipMemsetAsync(d.part_b1, 0, sizeof(float) * (size_t)chunks * I, ss));
@@ -992,7 +1006,9 @@ extern "C" int convdr_grad_norm_clip(float* grads, int64_t n, float max_norm, fl
 extern "C" int convdr_grad_sumsq(const float* x, int64_t n, float* partials, int nblocks, convdr_stream_t stream) {
   CONVDR_REQUIRE(n >= 0 && nblocks >= 1 && nblocks <= 1024, "convdr_grad_sumsq: bad n / nblocks (%lld, %d)", (long long)n, nblocks);
   if (dbg_skip() & 128) CONVDR_CHECK_HIP(hipMemsetAsync(partials, 0, sizeof(float) * (size_t)nblocks, (hipStream_t)stream));   // (timing bound only)
-  else hipLaunchKernelGGL(k_sumsq_partial, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, x, n, partials);
+  else
+    for (int rep = 0; rep < ((dbg_double() & 256) ? 2 : 1); ++rep)
+      hipLaunchKernelGGL(k_sumsq_partial, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, x, n, partials);
   CONVDR_CHECK_LAUNCH("k_sumsq_partial");
   return 0;
 }
