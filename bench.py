@@ -1021,9 +1021,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the warm-up steps run exactly what the timed ones do, INCLUDING the instrumentation (hipEvent pairs around every launch, the
+    # three timing events per step): the runtime creates its timestamp-signal pools on first use, and a one-off of that kind inside the
+    # timed region is a 2-3 ms / step reading error at 20 steps (seen once in ~10 fresh-box runs: search + fold 4.4 instead of 1.8 ms)
+    L_.convdr_prof_enable(1)
+    warm_ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.warmup)]
     for i in range(args.warmup):
-        out = step(i)
+        out = step(i, warm_ev[i])
     sync_all()
+    del warm_ev
     # workgroup 0 of every FFN1 launch stamps {s_memtime, s_memrealtime} at its start and end: the shader clock the roofline
     # kernel actually ran at in this run (the part is power-managed; boxes of the pool differ by 4-5 % on identical code)
     n_probe = 512
