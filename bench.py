@@ -14,6 +14,7 @@ the path's one real exchange step: the query embeddings are all-gathered, every 
 top-k lists are all-gathered and merged on the device (parallel.search_sharded_device, BASELINE configs[3]).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -408,11 +409,14 @@ def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=
     for i in range(warmup):
         step(i)
     sync_all()
+    gc.collect()
+    gc.disable()          # (as in the headline loop: no cyclic-GC pause of the enqueuing host inside the timed region)
     t0 = time.perf_counter()
     for i in range(steps):
         loss = step(i)[0]
     sync_all()
     el = time.perf_counter() - t0
+    gc.enable()
     kern = {}
     if with_kernels:
         # per-kernel breakdown from a separate short pass: the hipEvent pair around each of the ~450 launches of a step
@@ -1037,11 +1041,16 @@ def main():
     _lib.check(L_.convdr_set_option(b"clock_probe_slots", n_probe), "convdr_set_option")
     _lib.check(L_.convdr_set_option(b"clock_probe", clock_probe.data_ptr()), "convdr_set_option")
     L_.convdr_prof_enable(1)
+    # (no cyclic-GC pass inside the timed region: the search's one host round trip per step makes every host pause a GPU stall, and a
+    #  generation-2 collection of this process is tens of milliseconds)
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i, ev[i])
     sync_all()
     el = time.perf_counter() - t0
+    gc.enable()
     L_.convdr_set_option(b"clock_probe", 0)
     cp = clock_probe.cpu().numpy().astype(np.float64)
     cp = cp[cp[:, 3] > cp[:, 1]]                                 # the slots that were written (one per timed FFN1 launch)
