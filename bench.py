@@ -406,11 +406,11 @@ def train_kd_measure(dev, rank, world, dist_on, steps, warmup, Bt, with_kernels=
             step(i)
     else:
         settle_steps = TR.settle_streams(step, dev)
+    gc.collect()
+    gc.disable()          # (as in the headline loop: no cyclic-GC pause of the enqueuing host inside the timed region; in front of the warm-up)
     for i in range(warmup):
         step(i)
     sync_all()
-    gc.collect()
-    gc.disable()          # (as in the headline loop: no cyclic-GC pause of the enqueuing host inside the timed region)
     t0 = time.perf_counter()
     for i in range(steps):
         loss = step(i)[0]
@@ -1028,6 +1028,11 @@ def main():
     # the warm-up steps run exactly what the timed ones do, INCLUDING the instrumentation (hipEvent pairs around every launch, the
     # three timing events per step): the runtime creates its timestamp-signal pools on first use, and a one-off of that kind inside the
     # timed region is a 2-3 ms / step reading error at 20 steps (seen once in ~10 fresh-box runs: search + fold 4.4 instead of 1.8 ms)
+    # (no cyclic-GC pass inside the timed region: the search's one host round trip per step makes every host pause a GPU stall, and a
+    #  generation-2 collection of this process is tens of milliseconds.  Collected HERE, in front of the warm-up: a host pause directly in
+    #  front of the timed steps lets the part drop its clocks, and the first timed kernels then run 20 % slow)
+    gc.collect()
+    gc.disable()
     L_.convdr_prof_enable(1)
     warm_ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.warmup)]
     for i in range(args.warmup):
@@ -1041,10 +1046,6 @@ def main():
     _lib.check(L_.convdr_set_option(b"clock_probe_slots", n_probe), "convdr_set_option")
     _lib.check(L_.convdr_set_option(b"clock_probe", clock_probe.data_ptr()), "convdr_set_option")
     L_.convdr_prof_enable(1)
-    # (no cyclic-GC pass inside the timed region: the search's one host round trip per step makes every host pause a GPU stall, and a
-    #  generation-2 collection of this process is tens of milliseconds)
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i, ev[i])
