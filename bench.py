@@ -189,7 +189,7 @@ def live_kernel_trace(kname, timeout=300):
     td = tempfile.mkdtemp(prefix="convdr_kt_")
     try:
         subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "-d", td, "--", sys.executable, os.path.join(ROOT, "bench.py"),
-                        "--steps", "4", "--warmup", "2", "--passages", "65536", "--queries", "64", "--no-cpu-baseline", "--no-extras"],
+                        "--steps", "8", "--warmup", "4", "--passages", "65536", "--queries", "64", "--no-cpu-baseline", "--no-extras"],
                        cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                        timeout=timeout, check=True)
         rows = []
@@ -199,7 +199,8 @@ def live_kernel_trace(kname, timeout=300):
                     if kname in row["Kernel_Name"]:
                         rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
         rows.sort()
-        rows = rows[len(rows) // 3:]                 # the warm-up steps' dispatches (2 of 6 steps)
+        rows = rows[len(rows) // 3:]                 # the warm-up steps' dispatches (4 of 12 steps; 4 + 2 until late in round 6: a
+                                                     # 4-step pass read 0.400 where the next pass of the same command read 0.408)
         if not rows:
             return None
         return sum(e - b for b, e in rows) / len(rows) / 1e3, len(rows)

@@ -16,7 +16,7 @@ python bench.py --workload train_kd 2>$O/bench_kd.err | tail -1 > $O/bench_train
 CONVDR_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 4 --warmup 1 --no-cpu-baseline --no-extras 2>$O/bench_tr.err | tail -1 > $O/bench_torchrun1_forced_dist.json
 CONVDR_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 6 --warmup 2 --workload train_kd 2>$O/bench_tr_kd.err | tail -1 > $O/bench_torchrun1_forced_dist_train_kd.json
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python3 $R/bench.py --steps 4 --warmup 2 --passages 65536 --queries 64 --no-cpu-baseline --no-extras > $O/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python3 $R/bench.py --steps 8 --warmup 4 --passages 65536 --queries 64 --no-cpu-baseline --no-extras > $O/prof_bench.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_kd -o kd -- python3 $R/bench.py --workload train_kd --steps 5 --warmup 2 > $O/prof_kd.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_write.log 2>&1
