@@ -353,7 +353,7 @@ class _EncoderFn(torch.autograd.Function):
             ws = ent.ws
             drop = None if dropout is None else C.byref(_lib.Dropout(float(dropout[0]), float(dropout[1]), int(dropout[2]) & 0xffffffff))
             # the transposed weight copies are needed by the backward only: pack them on the side stream, under this
-            # forward (one LDS-free launch, train_kernels.hpp: k_transpose_f32_bf16_batch; behind the forward instead it measured
+            # forward (one LDS-free launch, train_kernels.hpp: k_transpose_bf16_batch; behind the forward instead it measured
             # the same, 9.03 vs 9.00 ms: profiles/r06_ab_transpose.txt).  The side
             # stream forks off BEFORE the forward is enqueued -- the weights are final in stream order here; forking after it
             # (rounds 2-4) made the packing wait for the whole forward and the loss wait for the packing: 0.08 ms per step
